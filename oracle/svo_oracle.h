@@ -1,0 +1,150 @@
+/*
+ * svo_oracle.h -- CPU restatement ("oracle") of the stereo-VO hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (stereo-visual-odometry_amd/) never links,
+ * imports or executes it and fails loudly when its HIP library is missing.
+ *
+ * PARITY UNPINNED: the reference (liuzhenboo/Stereo-Visual-Odometry) ships no
+ * tests, golden vectors or fixtures, and all of its hot-path arithmetic lives
+ * in OpenCV 3.x, which is neither vendored in /root/reference nor installed in
+ * this image.  This file restates the published OpenCV 3.4
+ * algorithms the reference calls, and is pinned only by
+ * analytic known-answer tests (tests/test_oracle_*.py).  Deliberate canonical
+ * choices that differ from upstream at the last-ulp level are marked
+ * "CANONICAL:" next to the code and listed in DESIGN.md.
+ *
+ * All functions are plain C, single-threaded unless noted, deterministic, and
+ * compiled with -ffp-contract=off so float results do not depend on FMA.
+ */
+#ifndef SVO_ORACLE_H
+#define SVO_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cv::KeyPoint field order (pt.x, pt.y, size, angle, response, octave, class_id). */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orc_keypoint;
+
+typedef struct { float x, y; } orc_pt2f;
+typedef struct { float x, y, z; } orc_pt3f;
+
+/* ---- a2: cv::FAST(img, kps, thr, nms) TYPE_9_16; reference src/tracking.cpp:94-113 ---- */
+/* Returns the number of keypoints found (may exceed cap; only cap are written). */
+int orc_fast9_16(const uint8_t *img, int w, int h, int pitch, int thr, int nms,
+                 orc_keypoint *out, int cap);
+
+/* ---- a3: pyramid + cv::calcOpticalFlowPyrLK; reference src/tracking.cpp:583-618 ---- */
+#define ORC_LK_MAX_LEVELS 8
+typedef struct {
+    int nlevels;                       /* maxLevel + 1 actually built */
+    int pad;                           /* REFLECT_101 border kept around every level (= win) */
+    int w[ORC_LK_MAX_LEVELS], h[ORC_LK_MAX_LEVELS];
+    int pitch[ORC_LK_MAX_LEVELS];      /* = w[l] + 2*pad */
+    uint8_t *data[ORC_LK_MAX_LEVELS];  /* padded buffer; pixel (x,y) at data[(y+pad)*pitch + x+pad] */
+} orc_pyramid;
+
+/* buildOpticalFlowPyramid(img, pyr, winSize, maxLevel): level l+1 = pyrDown(level l). */
+int  orc_pyramid_build(const uint8_t *img, int w, int h, int pitch, int win, int max_level,
+                       orc_pyramid *pyr);
+void orc_pyramid_free(orc_pyramid *pyr);
+/* one pyrDown step (5x5 [1 4 6 4 1], BORDER_REFLECT_101, (s+128)>>8); dst is ((w+1)/2)x((h+1)/2) */
+void orc_pyr_down(const uint8_t *src, int w, int h, int spitch, uint8_t *dst, int dpitch);
+
+/* calcOpticalFlowPyrLK(prev, next, prev_pts, next_pts, status, err, Size(win,win), max_level,
+ *                      TermCriteria(COUNT+EPS, max_iter, eps), flags = 0, min_eig)
+ * threads > 1 splits the point range over OpenMP threads (results do not depend on it). */
+int orc_lk_track(const orc_pyramid *prev, const orc_pyramid *next,
+                 const orc_pt2f *prev_pts, int n, orc_pt2f *next_pts, uint8_t *status,
+                 int win, int max_iter, double eps, float min_eig, int threads);
+
+/* ---- a4: Tracking::deleteBadmatchFeatures; reference src/tracking.cpp:623-660 ---- */
+/* keep[i] = 1 iff point i survives; returns M.  Points are NOT moved. */
+int orc_circular_keep(const orc_pt2f *p0, const orc_pt2f *p1, const orc_pt2f *p2,
+                      const orc_pt2f *p3, const orc_pt2f *p0r,
+                      const uint8_t *s0, const uint8_t *s1, const uint8_t *s2, const uint8_t *s3,
+                      int n, double match_err, uint8_t *keep);
+
+/* ---- a5: cv::triangulatePoints + convertPointsFromHomogeneous; src/tracking.cpp:288-294 ---- */
+void orc_triangulate(const double P1[12], const double P2[12], const orc_pt2f *x1,
+                     const orc_pt2f *x2, int n, orc_pt3f *out, float *out4 /* 4*n or NULL */);
+
+/* ---- a6: cv::solvePnPRansac(..., useExtrinsicGuess=true, iters, reproj, conf, inliers,
+ *          SOLVEPNP_ITERATIVE) + cv::Rodrigues; reference src/tracking.cpp:464-501 ---- */
+typedef struct {
+    double rvec[3], tvec[3];
+    double R[9];
+    int n_inliers;
+    int ransac_iters;      /* hypotheses evaluated before the adaptive stop */
+    int best_iter;         /* index of the winning hypothesis (-1: none) */
+    int lm_iters;
+    int ok;                /* solvePnPRansac's boolean result */
+} orc_pnp_result;
+
+int orc_pnp_ransac(const orc_pt3f *obj, const orc_pt2f *img, int n, const double K[9],
+                   int iterations, float reproj_err, double confidence,
+                   orc_pnp_result *res, uint8_t *inlier_mask /* n or NULL */);
+
+/* pieces exposed for unit tests */
+/* One-sided Jacobi SVD as used by cv::SVD for doubles.  At is n x m row-major (the TRANSPOSE
+ * of the m x n input, m >= n); on return its rows are the left singular vectors (if Vt given
+ * or want_u), W the singular values (descending), Vt the n x n right singular vectors. */
+void orc_jacobi_svd(double *At, int m, int n, double *W, double *Vt);
+int  orc_epnp(const double *pws, const double *us, int n, double fu, double fv, double uc,
+              double vc, double R[9], double t[3]);
+void orc_rodrigues_vec2mat(const double r[3], double R[9], double dRdr[27] /* or NULL */);
+void orc_rodrigues_mat2vec(const double R[9], double r[3]);
+uint32_t orc_rng_next(uint64_t *state);
+
+/* ---- a7: rotationMatrixToEulerAngles + gating + pose accumulation; src/tracking.cpp:305-329,
+ *          440-463 ---- */
+/* Returns 1 and right-multiplies pose (4x4 row-major) by inv([R t;0 1]) iff the motion passes
+ * the gates; min_t2/max_t2 are the squared-translation bounds (LK mode: 0.0005^2, 100). */
+int orc_gate_and_accumulate(const double R[9], const double t[3], double min_t2, double max_t2,
+                            double pose[16], double T_rel_inv[16] /* or NULL */);
+
+/* ---- a1: one LK-mode frame step (Tracking::LK_StereoF2F_PnP_Track, src/tracking.cpp:258-344),
+ *          given the t-1 keypoints already detected ---- */
+typedef struct {
+    int n_prev_kps;      /* FAST keypoints of frame t-1 fed to LK */
+    int n_cur_kps;       /* FAST keypoints of frame t (stored for the next step) */
+    int n_tracked;       /* survivors of the circular match */
+    int n_inliers;
+    int ok;              /* Track() return value */
+    int fail_stage;      /* 0 none, 1 <30 kps, 2 too few tracks, 3 inlier ratio, 4 rot gate, 5 trans gate */
+    double rvec[3], tvec[3], R[9];
+    double T_rel_inv[16];
+} orc_step_result;
+
+typedef struct {
+    double P1[12], P2[12];
+    double feature_match_error;
+    int    num_features_tracking;
+    double inlier_rate;
+    int    iterations;
+    float  reproj_err;
+    float  confidence;
+    int    fast_thr;
+} orc_track_params;
+
+/* threads: OpenMP threads for the LK point loop (1 = scalar port). */
+int orc_lk_track_step(const orc_track_params *prm,
+                      const uint8_t *prevL, const uint8_t *prevR,
+                      const uint8_t *curL, const uint8_t *curR, int w, int h, int pitch,
+                      const orc_keypoint *prev_kps, int n_prev,
+                      orc_keypoint *cur_kps, int cur_cap,
+                      double pose[16], orc_step_result *res,
+                      orc_pt2f *tracks /* 4*n_prev (t1l,t1r,t2r,t2l compacted) or NULL */,
+                      int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
