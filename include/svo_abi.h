@@ -1,0 +1,167 @@
+/*
+ * svo_abi.h -- C-ABI of the MI355X-native stereo-VO hot path (libsvo_hip.so).
+ *
+ * The reference (liuzhenboo/Stereo-Visual-Odometry) has no plugin/FFI layer: its hot path is
+ * the private part of lzb_vio::Tracking, which calls OpenCV 3.  Each entry point below replaces
+ * one of those call sites (cited as reference file:line); the host-side C++ mirror of
+ * lzb_vio::{System,Tracking,Frame,...} in stereo-visual-odometry_amd/host/ and the Python test
+ * binding both sit on top of exactly this surface.  INTEGRATION.md shows the reference-side
+ * binding a maintainer would add.
+ *
+ * Conventions
+ *  - plain C types only; every function returns an int status (SVO_OK == 0, < 0 hard error,
+ *    > 0 soft "tracking failed" reason mirroring the reference's failure exits); nothing throws
+ *    or aborts across the boundary; svo_last_error() gives a message for the last hard error.
+ *  - `mem` says where the caller's buffers live: SVO_MEM_HOST (copied H2D/D2H by the call) or
+ *    SVO_MEM_DEVICE (HBM pointers, e.g. a torch tensor's data_ptr(); no copies, results are
+ *    ordered on the context's stream -- call svo_sync() before reading them from another stream).
+ *  - one context per (thread, GPU); calls on a context are serialised by the caller.
+ *  - images are 8-bit grayscale, row-major, `pitch` bytes per row.
+ */
+#ifndef SVO_ABI_H
+#define SVO_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVO_ABI_VERSION 1
+
+/* status codes */
+#define SVO_OK                 0
+#define SVO_ERR_ARG           -1   /* bad argument / capacity exceeded */
+#define SVO_ERR_HIP           -2   /* a HIP runtime call failed */
+#define SVO_ERR_NOMEM         -3
+#define SVO_ERR_STATE         -4   /* e.g. pyramid slot not built */
+/* soft failures of one frame step == the reference's `return false` exits */
+#define SVO_FAIL_FEW_KEYPOINTS 1   /* src/tracking.cpp:261  (< 30 FAST corners)           */
+#define SVO_FAIL_FEW_TRACKS    2   /* src/tracking.cpp:274  (< num_features_tracking)      */
+#define SVO_FAIL_INLIER_RATIO  3   /* src/tracking.cpp:491  (inliers / tracked < rate)     */
+#define SVO_FAIL_ROTATION_GATE 4   /* src/tracking.cpp:308  (|euler| >= 0.1 rad)           */
+#define SVO_FAIL_TRANSL_GATE   5   /* src/tracking.cpp:311  (|t|^2 outside the window)     */
+
+#define SVO_MEM_HOST   0
+#define SVO_MEM_DEVICE 1
+
+typedef struct svo_ctx svo_ctx;
+
+typedef struct { float x, y; } svo_pt2f;                 /* cv::Point2f */
+typedef struct { float x, y, z; } svo_pt3f;              /* cv::Point3f */
+typedef struct {                                         /* cv::KeyPoint */
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} svo_keypoint;
+
+/* Mirrors the live keys of config/default.yaml + capacities. */
+typedef struct {
+    int32_t width, height;          /* image size, fixed per context                          */
+    int32_t max_keypoints;          /* capacity per image; exceeding it is SVO_ERR_ARG         */
+    int32_t max_batch;              /* frame pairs per svo_track_batch launch (>= 1)           */
+    int32_t num_slots;              /* pyramid slots for the stage API (>= 4)                  */
+    int32_t fast_threshold;         /* 20, hard-coded at src/tracking.cpp:99                   */
+    int32_t num_features_tracking;  /* config/default.yaml:69                                  */
+    int32_t iterations;             /* iterationsCount, :80                                    */
+    float   reproj_err;             /* reprojectionError, :81                                  */
+    float   confidence;             /* confidence, :82 (a float at src/tracking.cpp:481)       */
+    double  feature_match_error;    /* :66                                                     */
+    double  inlier_rate;            /* :77                                                     */
+    double  min_move2, max_move2;   /* squared translation gate; LK mode: 0.0005^2, 100 (:311) */
+    double  P1[12], P2[12];         /* projMatr1_/projMatr2_, src/parameter.cpp:44-45          */
+} svo_config;
+
+typedef struct {                    /* solvePnPRansac + Rodrigues outcome */
+    double rvec[3], tvec[3], R[9];
+    int32_t n_inliers, ransac_iters, best_iter, lm_iters, ok, _pad;
+} svo_pnp_result;
+
+typedef struct {                    /* one Tracking::AddFrame step (LK mode) */
+    int32_t ok;                     /* Track() result                                           */
+    int32_t fail_stage;             /* 0 or one of SVO_FAIL_*                                   */
+    int32_t n_prev_kps, n_cur_kps, n_tracked, n_inliers;
+    int32_t ransac_iters, lm_iters;
+    double  rvec[3], tvec[3], R[9];
+    double  T_rel_inv[16];          /* inv([R t; 0 1]) -- what frame_pose_ is multiplied by     */
+    double  pose[16];               /* frame_pose_ after this step (chained from the batch's
+                                       initial pose; failed steps leave it unchanged)           */
+} svo_step_result;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int         svo_abi_version(void);
+void        svo_default_config(svo_config *cfg, int width, int height);   /* default.yaml + KITTI rig */
+int         svo_create(const svo_config *cfg, int device, svo_ctx **out);
+void        svo_destroy(svo_ctx *ctx);
+const char *svo_last_error(const svo_ctx *ctx);
+int         svo_set_stream(svo_ctx *ctx, void *hip_stream);   /* NULL -> context's own stream */
+int         svo_sync(svo_ctx *ctx);
+int         svo_num_levels(const svo_ctx *ctx);               /* LK pyramid levels actually built */
+
+/* ---- stage API: one call per OpenCV call site of the reference ---------------------------- */
+
+/* cv::FAST(img, kps, threshold, nonmax)  -- src/tracking.cpp:101 (Detect_OpenCVFASTFeatures),
+ * src/ORBextractor.cpp:763,768.  Row-major ordered output. */
+int svo_fast_detect(svo_ctx *ctx, const uint8_t *img, int pitch, int mem, int threshold,
+                    int nonmax, svo_keypoint *out, int cap, int *n_out);
+
+/* buildOpticalFlowPyramid half of cv::calcOpticalFlowPyrLK (src/tracking.cpp:593-618): builds the
+ * padded 4-level pyramid of one image into slot `slot`; consecutive LK calls reuse it. */
+int svo_build_pyramid(svo_ctx *ctx, int slot, const uint8_t *img, int pitch, int mem);
+/* test/debug read-back of one level (without border) */
+int svo_read_pyramid_level(svo_ctx *ctx, int slot, int level, uint8_t *out, int out_pitch, int mem,
+                           int *w, int *h);
+
+/* cv::calcOpticalFlowPyrLK(prev, next, prev_pts, next_pts, status, err, Size(21,21), 3,
+ *   TermCriteria(COUNT+EPS, 30, 0.01), 0, 0.001)  -- src/tracking.cpp:593,600,607,613 */
+int svo_lk_track(svo_ctx *ctx, int slot_prev, int slot_next, const svo_pt2f *prev_pts, int n,
+                 svo_pt2f *next_pts, uint8_t *status, int mem);
+
+/* Tracking::LK_Robust_Find_MuliImage_MatchedFeatures incl. deleteBadmatchFeatures
+ * (src/tracking.cpp:583-660): the 4-call loop L1->R1->R2->L2->L1' fused per point, then the
+ * stable filter.  out_* receive the M survivors in input order; *m_out = M. */
+int svo_circular_match(svo_ctx *ctx, int slot_prevL, int slot_prevR, int slot_curL, int slot_curR,
+                       const svo_pt2f *t1_left, int n, svo_pt2f *out_t1_left,
+                       svo_pt2f *out_t1_right, svo_pt2f *out_t2_right, svo_pt2f *out_t2_left,
+                       int *m_out, int mem);
+
+/* cv::triangulatePoints + cv::convertPointsFromHomogeneous -- src/tracking.cpp:292-294, :190-192 */
+int svo_triangulate(svo_ctx *ctx, const double P1[12], const double P2[12], const svo_pt2f *x1,
+                    const svo_pt2f *x2, int n, svo_pt3f *out, int mem);
+
+/* cv::solvePnPRansac(obj, img, K, 0, rvec, t, true, iterations, reproj_err, confidence, inliers,
+ *   SOLVEPNP_ITERATIVE) + cv::Rodrigues -- src/tracking.cpp:485-488.  res is always a HOST
+ * struct; inlier_mask (n bytes, may be NULL) follows `mem`. */
+int svo_pnp_ransac(svo_ctx *ctx, const svo_pt3f *obj, const svo_pt2f *img, int n, const double K[9],
+                   int iterations, float reproj_err, double confidence, svo_pnp_result *res,
+                   uint8_t *inlier_mask, int mem);
+
+/* ---- fused API: Tracking::AddFrame in LK mode (src/tracking.cpp:49-77, 258-344) ------------ */
+
+/* Online step: feeds one stereo frame.  The first call only detects features (StereoInit_f2f,
+ * :78-92) and returns SVO_OK with res->ok = 1, n_prev_kps = 0.  Later calls track against the
+ * previous frame.  Returns SVO_OK (res->ok = 1), a SVO_FAIL_* code (res->ok = 0; the pose chain
+ * skips this step, as the reference does), or a hard error < 0.  res is a HOST struct. */
+int svo_add_frame(svo_ctx *ctx, const uint8_t *left, const uint8_t *right, int pitch, int mem,
+                  svo_step_result *res);
+int svo_reset(svo_ctx *ctx);                         /* back to INITING, pose = identity */
+int svo_get_pose(svo_ctx *ctx, double pose[16]);     /* frame_pose_ (src/tracking.h:117)  */
+
+/* Batched step: n_frames consecutive stereo frames resident in HBM (frame f at base +
+ * f*frame_stride), n_frames - 1 <= max_batch pairs processed as one set of launches
+ * (every consecutive pair is independent: SURVEY.md section 0 fact 3), poses chained on device.
+ * results: n_frames - 1 records, location per `results_mem`.  pose0 (host, may be NULL = identity)
+ * seeds the chain.  Frame 0's features are detected as part of the batch. */
+int svo_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t *right_frames,
+                    int pitch, int64_t frame_stride, int n_frames, const double *pose0,
+                    svo_step_result *results, int results_mem);
+
+/* Kernel-level timing of the last svo_track_batch / svo_add_frame, measured with HIP events on
+ * the context's stream: fills up to `cap` (name, milliseconds) pairs, returns the count.
+ * Enabled by svo_enable_timing(ctx, 1); adds event records between stages. */
+int svo_enable_timing(svo_ctx *ctx, int on);
+int svo_get_timing(svo_ctx *ctx, const char **names, float *ms, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVO_ABI_H */

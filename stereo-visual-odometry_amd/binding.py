@@ -1,0 +1,307 @@
+"""ctypes binding of libsvo_hip.so (include/svo_abi.h).  No compute happens in Python."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MEM_HOST, MEM_DEVICE = 0, 1
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+
+class SvoError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_keypoints", C.c_int32),
+                ("max_batch", C.c_int32), ("num_slots", C.c_int32), ("fast_threshold", C.c_int32),
+                ("num_features_tracking", C.c_int32), ("iterations", C.c_int32),
+                ("reproj_err", C.c_float), ("confidence", C.c_float),
+                ("feature_match_error", C.c_double), ("inlier_rate", C.c_double),
+                ("min_move2", C.c_double), ("max_move2", C.c_double),
+                ("P1", C.c_double * 12), ("P2", C.c_double * 12)]
+
+
+class PnPResult(C.Structure):
+    _fields_ = [("rvec", C.c_double * 3), ("tvec", C.c_double * 3), ("R", C.c_double * 9),
+                ("n_inliers", C.c_int32), ("ransac_iters", C.c_int32), ("best_iter", C.c_int32),
+                ("lm_iters", C.c_int32), ("ok", C.c_int32), ("_pad", C.c_int32)]
+
+
+class StepResult(C.Structure):
+    _fields_ = [("ok", C.c_int32), ("fail_stage", C.c_int32), ("n_prev_kps", C.c_int32),
+                ("n_cur_kps", C.c_int32), ("n_tracked", C.c_int32), ("n_inliers", C.c_int32),
+                ("ransac_iters", C.c_int32), ("lm_iters", C.c_int32),
+                ("rvec", C.c_double * 3), ("tvec", C.c_double * 3), ("R", C.c_double * 9),
+                ("T_rel_inv", C.c_double * 16), ("pose", C.c_double * 16)]
+
+
+STEP_DTYPE = np.dtype([("ok", "<i4"), ("fail_stage", "<i4"), ("n_prev_kps", "<i4"),
+                       ("n_cur_kps", "<i4"), ("n_tracked", "<i4"), ("n_inliers", "<i4"),
+                       ("ransac_iters", "<i4"), ("lm_iters", "<i4"), ("rvec", "<f8", 3),
+                       ("tvec", "<f8", 3), ("R", "<f8", 9), ("T_rel_inv", "<f8", 16),
+                       ("pose", "<f8", 16)])
+assert STEP_DTYPE.itemsize == C.sizeof(StepResult)
+
+
+def library_path():
+    return os.path.join(_HERE, "libsvo_hip.so")
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 build of csrc/ into libsvo_hip.so (cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return library_path()
+
+
+def load_library():
+    """dlopen libsvo_hip.so; raises SvoError when it is missing (there is no CPU fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise SvoError(f"{path} is missing: run __graft_entry__.build() (hipcc) first; "
+                       "this package has no CPU fallback")
+    lib = C.CDLL(path)
+    lib.svo_last_error.restype = C.c_char_p
+    lib.svo_last_error.argtypes = [C.c_void_p]
+    lib.svo_create.argtypes = [C.POINTER(Config), C.c_int, C.POINTER(C.c_void_p)]
+    lib.svo_destroy.argtypes = [C.c_void_p]
+    lib.svo_destroy.restype = None
+    lib.svo_default_config.argtypes = [C.POINTER(Config), C.c_int, C.c_int]
+    lib.svo_default_config.restype = None
+    lib.svo_track_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_int]
+    _LIB = lib
+    return lib
+
+
+def default_config(width, height, **overrides):
+    cfg = Config()
+    load_library().svo_default_config(C.byref(cfg), int(width), int(height))
+    for k, v in overrides.items():
+        if k in ("P1", "P2"):
+            arr = getattr(cfg, k)
+            for i, x in enumerate(np.asarray(v, np.float64).reshape(12)):
+                arr[i] = float(x)
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+def _ptr(a):
+    """Raw pointer + memory kind of a numpy array (host) or a torch tensor (host or cuda)."""
+    if a is None:
+        return None, MEM_HOST
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return C.c_void_p(a.ctypes.data), MEM_HOST
+    # torch tensor
+    assert a.is_contiguous()
+    return C.c_void_p(a.data_ptr()), (MEM_DEVICE if a.is_cuda else MEM_HOST)
+
+
+class Context:
+    """One svo_ctx: owns every device buffer of the hot path on one GPU."""
+
+    def __init__(self, width, height, device=0, **cfg_overrides):
+        self.lib = load_library()
+        self.cfg = default_config(width, height, **cfg_overrides)
+        h = C.c_void_p()
+        rc = self.lib.svo_create(C.byref(self.cfg), int(device), C.byref(h))
+        if rc != 0:
+            raise SvoError(f"svo_create failed with {rc} (no usable HIP device?) -- there is no CPU fallback")
+        self.h = h
+        self.width, self.height = int(width), int(height)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.svo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow_soft=False):
+        if rc < 0 or (rc > 0 and not allow_soft):
+            raise SvoError(f"svo call failed ({rc}): {self.lib.svo_last_error(self.h).decode()}")
+        return rc
+
+    # ---- misc -------------------------------------------------------------------------------
+    def sync(self):
+        self._check(self.lib.svo_sync(self.h))
+
+    def set_stream(self, stream_handle):
+        self._check(self.lib.svo_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    @property
+    def num_levels(self):
+        return self.lib.svo_num_levels(self.h)
+
+    def enable_timing(self, on=True):
+        self._check(self.lib.svo_enable_timing(self.h, int(on)))
+
+    def get_timing(self):
+        names = (C.c_char_p * 64)()
+        ms = (C.c_float * 64)()
+        n = self.lib.svo_get_timing(self.h, names, ms, 64)
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+    # ---- stage API --------------------------------------------------------------------------
+    def _img(self, img):
+        p, mem = _ptr(img)
+        pitch = img.strides[0] if isinstance(img, np.ndarray) else img.stride(0)
+        assert tuple(img.shape) == (self.height, self.width), (img.shape, self.height, self.width)
+        return p, int(pitch), mem
+
+    def fast_detect(self, img, threshold=20, nonmax=True, cap=None):
+        cap = cap or self.cfg.max_keypoints
+        p, pitch, mem = self._img(img)
+        out = np.zeros(cap, dtype=KP_DTYPE)
+        n = C.c_int(0)
+        self._check(self.lib.svo_fast_detect(self.h, p, pitch, mem, int(threshold), int(bool(nonmax)),
+                                             C.c_void_p(out.ctypes.data), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def build_pyramid(self, slot, img):
+        p, pitch, mem = self._img(img)
+        self._check(self.lib.svo_build_pyramid(self.h, int(slot), p, pitch, mem))
+
+    def read_pyramid_level(self, slot, level):
+        w, h = C.c_int(0), C.c_int(0)
+        self._check(self.lib.svo_read_pyramid_level(self.h, slot, level, None, 0, MEM_HOST,
+                                                    C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        self._check(self.lib.svo_read_pyramid_level(self.h, slot, level, C.c_void_p(out.ctypes.data),
+                                                    w.value, MEM_HOST, C.byref(w), C.byref(h)))
+        return out
+
+    def lk_track(self, slot_prev, slot_next, pts):
+        """pts: (n,2) float32 numpy (host) or torch cuda tensor -> (next_pts, status), same kind."""
+        if isinstance(pts, np.ndarray):
+            pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+            n = pts.shape[0]
+            out = np.zeros((n, 2), np.float32)
+            st = np.zeros(n, np.uint8)
+        else:
+            import torch
+            n = pts.shape[0]
+            out = torch.zeros((n, 2), dtype=torch.float32, device=pts.device)
+            st = torch.zeros(n, dtype=torch.uint8, device=pts.device)
+        pi, mem = _ptr(pts)
+        po, _ = _ptr(out)
+        ps, _ = _ptr(st)
+        self._check(self.lib.svo_lk_track(self.h, slot_prev, slot_next, pi, n, po, ps, mem))
+        if mem == MEM_DEVICE:
+            self.sync()
+        return out, st
+
+    def circular_match(self, slots, t1_left):
+        """slots = (prevL, prevR, curL, curR); returns the four compacted (M,2) arrays."""
+        if isinstance(t1_left, np.ndarray):
+            t1_left = np.ascontiguousarray(t1_left, np.float32).reshape(-1, 2)
+            n = t1_left.shape[0]
+            outs = [np.zeros((max(n, 1), 2), np.float32) for _ in range(4)]
+        else:
+            import torch
+            n = t1_left.shape[0]
+            outs = [torch.zeros((max(n, 1), 2), dtype=torch.float32, device=t1_left.device) for _ in range(4)]
+        pi, mem = _ptr(t1_left)
+        m = C.c_int(0)
+        self._check(self.lib.svo_circular_match(self.h, *[int(s) for s in slots], pi, n,
+                                                *[_ptr(o)[0] for o in outs], C.byref(m), mem))
+        return [o[:m.value] for o in outs]
+
+    def triangulate(self, P1, P2, x1, x2):
+        P1 = np.ascontiguousarray(P1, np.float64).reshape(12)
+        P2 = np.ascontiguousarray(P2, np.float64).reshape(12)
+        if isinstance(x1, np.ndarray):
+            x1 = np.ascontiguousarray(x1, np.float32).reshape(-1, 2)
+            x2 = np.ascontiguousarray(x2, np.float32).reshape(-1, 2)
+            out = np.zeros((x1.shape[0], 3), np.float32)
+        else:
+            import torch
+            out = torch.zeros((x1.shape[0], 3), dtype=torch.float32, device=x1.device)
+        p1, mem = _ptr(x1)
+        p2, _ = _ptr(x2)
+        self._check(self.lib.svo_triangulate(self.h, C.c_void_p(P1.ctypes.data), C.c_void_p(P2.ctypes.data),
+                                             p1, p2, x1.shape[0], _ptr(out)[0], mem))
+        if mem == MEM_DEVICE:
+            self.sync()
+        return out
+
+    def pnp_ransac(self, obj, img, K, iterations=500, reproj_err=0.5, confidence=0.99):
+        K = np.ascontiguousarray(K, np.float64).reshape(9)
+        if isinstance(obj, np.ndarray):
+            obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+            img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+            mask = np.zeros(max(obj.shape[0], 1), np.uint8)
+        else:
+            import torch
+            mask = torch.zeros(max(obj.shape[0], 1), dtype=torch.uint8, device=obj.device)
+        n = obj.shape[0]
+        res = PnPResult()
+        po, mem = _ptr(obj)
+        conf = float(np.float32(confidence))      # a float at reference src/tracking.cpp:481
+        self._check(self.lib.svo_pnp_ransac(self.h, po, _ptr(img)[0], n, C.c_void_p(K.ctypes.data),
+                                            int(iterations), C.c_float(reproj_err), C.c_double(conf),
+                                            C.byref(res), _ptr(mask)[0], mem))
+        if mem == MEM_DEVICE:
+            self.sync()
+            mask = mask.cpu().numpy()
+        return dict(ok=res.ok, rvec=np.array(res.rvec), tvec=np.array(res.tvec),
+                    R=np.array(res.R).reshape(3, 3), n_inliers=res.n_inliers,
+                    ransac_iters=res.ransac_iters, best_iter=res.best_iter, lm_iters=res.lm_iters,
+                    mask=np.asarray(mask[:n]).copy())
+
+    # ---- fused API --------------------------------------------------------------------------
+    def add_frame(self, left, right):
+        pl, pitch, mem = self._img(left)
+        pr, pitch_r, mem_r = self._img(right)
+        assert pitch == pitch_r and mem == mem_r
+        res = StepResult()
+        rc = self._check(self.lib.svo_add_frame(self.h, pl, pr, pitch, mem, C.byref(res)), allow_soft=True)
+        return rc, np.frombuffer(bytes(res), dtype=STEP_DTYPE)[0].copy()
+
+    def reset(self):
+        self._check(self.lib.svo_reset(self.h))
+
+    def get_pose(self):
+        pose = np.zeros(16)
+        self._check(self.lib.svo_get_pose(self.h, C.c_void_p(pose.ctypes.data)))
+        return pose.reshape(4, 4)
+
+    def track_batch(self, left_frames, right_frames, pose0=None, results=None):
+        """left/right_frames: torch cuda uint8 tensors (F, h, pitch>=w) viewed as (F, h, w).
+        Returns a numpy structured array of F-1 step results (or fills the given cuda tensor)."""
+        F = left_frames.shape[0]
+        assert left_frames.is_cuda and right_frames.is_cuda
+        assert left_frames.stride(2) == 1 and left_frames.stride() == right_frames.stride()
+        pitch, fstride = left_frames.stride(1), left_frames.stride(0)
+        p0 = None
+        if pose0 is not None:
+            pose0 = np.ascontiguousarray(pose0, np.float64).reshape(16)
+            p0 = C.c_void_p(pose0.ctypes.data)
+        if results is None:
+            out = np.zeros(F - 1, dtype=STEP_DTYPE)
+            rp, rmem = C.c_void_p(out.ctypes.data), MEM_HOST
+        else:
+            out = results
+            rp, rmem = C.c_void_p(results.data_ptr()), MEM_DEVICE
+        self._check(self.lib.svo_track_batch(self.h, C.c_void_p(left_frames.data_ptr()),
+                                             C.c_void_p(right_frames.data_ptr()), int(pitch), int(fstride),
+                                             int(F), p0, rp, rmem))
+        return out

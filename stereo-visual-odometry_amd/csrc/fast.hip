@@ -1,0 +1,174 @@
+// fast.hip -- FAST-9/16 corner detection with 3x3 non-max suppression and row-major ordered
+// output, for gfx950.  Replaces cv::FAST(img, kps, thr, true) at reference src/tracking.cpp:101
+// (Tracking::Detect_OpenCVFASTFeatures).  All-integer: bit-exact against oracle/fast.c.
+//
+// Two launches per batch of images:
+//   fast_score_kernel : one 64x16 pixel tile per 256-thread workgroup.  The raw tile (+4 halo)
+//       is staged in LDS once; the segment test + corner score are evaluated for the tile plus
+//       a 1-pixel ring (the NMS neighbours), NMS is done out of LDS, the suppressed score map
+//       (u8, 0 = no keypoint) goes to HBM with 64-byte coalesced row stores, and per-row
+//       keypoint counts are accumulated with one integer atomic per (row, tile).
+//   fast_emit_kernel  : one wave per image row; its output offset is the sum of the row counts
+//       above it (<= 17 coalesced loads), so keypoints come out in cv::FAST's row-major order
+//       without a sort or an append-atomic.
+// Algorithmic HBM bytes per image: W*H read + W*H score write/read + 12*N written.
+#include "svo_device.h"
+#include "svo_kernels.h"
+
+namespace svo {
+
+constexpr int kTileW = 64, kTileH = 16, kHalo = 4;
+constexpr int kRawW = kTileW + 2 * kHalo;   // 72
+constexpr int kRawH = kTileH + 2 * kHalo;   // 24
+constexpr int kScW = kTileW + 2;            // 66
+constexpr int kScH = kTileH + 2;            // 18
+
+// Bresenham circle, radius 3 (cv::FAST pattern 16), as byte offsets in the 72-wide LDS tile.
+__device__ __forceinline__ void load_circle(const uint8_t *c, int d[16], int v)
+{
+    constexpr int P = kRawW;
+    d[0] = v - c[3 * P];       d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];   d[3] = v - c[P + 3];
+    d[4] = v - c[3];           d[5] = v - c[-P + 3];      d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];
+    d[8] = v - c[-3 * P];      d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-P - 3];
+    d[12] = v - c[-3];         d[13] = v - c[P - 3];      d[14] = v - c[2 * P - 2];  d[15] = v - c[3 * P - 1];
+}
+
+// >= 9 contiguous set bits in a circular 16-bit mask
+__device__ __forceinline__ bool has_arc9(unsigned m16)
+{
+    unsigned m = m16 | (m16 << 16);
+    unsigned a = m & (m >> 1);
+    unsigned b = a & (a >> 2);
+    unsigned c = b & (b >> 4);
+    unsigned e = c & (m >> 8);
+    return (e & 0xFFFFu) != 0;
+}
+
+// Returns 0 for a non-corner, else cornerScore<16> (>= thr) -- or 1 when scores are not needed.
+__device__ __forceinline__ int fast_score_at(const uint8_t *c, int thr, bool want_score)
+{
+    int v = c[0];
+    // high-speed rejection on the compass points first (same outcome as the full test)
+    int d[16];
+    load_circle(c, d, v);
+    unsigned dark = 0, bright = 0;          // d > thr: pixel darker than centre; d < -thr: brighter
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        dark |= (unsigned)(d[k] > thr) << k;
+        bright |= (unsigned)(d[k] < -thr) << k;
+    }
+    if (!(has_arc9(dark) || has_arc9(bright))) return 0;
+    if (!want_score) return 1;
+    // min / max over every 9-arc d[s..s+8] by doubling
+    int mn[16], mx[16], t1[16], t2[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { t1[i] = min(d[i], d[(i + 1) & 15]); t2[i] = max(d[i], d[(i + 1) & 15]); }
+#pragma unroll
+    for (int i = 0; i < 16; i++) { mn[i] = min(t1[i], t1[(i + 2) & 15]); mx[i] = max(t2[i], t2[(i + 2) & 15]); }
+#pragma unroll
+    for (int i = 0; i < 16; i++) { t1[i] = min(mn[i], mn[(i + 4) & 15]); t2[i] = max(mx[i], mx[(i + 4) & 15]); }
+    int a0 = thr, bmin = 255;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        a0 = max(a0, min(t1[i], d[(i + 8) & 15]));
+        bmin = min(bmin, max(t2[i], d[(i + 8) & 15]));
+    }
+    int b0 = min(-a0, bmin);
+    return -b0 - 1;
+}
+
+__global__ __launch_bounds__(256) void fast_score_kernel(FastArgs a)
+{
+    __shared__ uint8_t raw[kRawH * kRawW];
+    __shared__ uint8_t sc[kScH * kScW];
+    const int b = blockIdx.z;
+    const uint8_t *img = a.img + (int64_t)b * a.img_stride;
+    uint8_t *score = a.score + (int64_t)b * a.score_stride;
+    int *rowcount = a.rowcount + (int64_t)b * a.rowcount_stride;
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+
+    // stage raw tile + halo; out-of-image bytes are never used by a valid centre
+    for (int i = tid; i < kRawH * kRawW; i += 256) {
+        int ry = i / kRawW, rx = i - ry * kRawW;
+        int gx = x0 - kHalo + rx, gy = y0 - kHalo + ry;
+        uint8_t v = 0;
+        if (gx >= 0 && gx < a.w && gy >= 0 && gy < a.h) v = img[(int64_t)gy * a.pitch + gx];
+        raw[i] = v;
+    }
+    __syncthreads();
+
+    // scores for the tile and its 1-pixel ring
+    for (int i = tid; i < kScH * kScW; i += 256) {
+        int sy = i / kScW, sx = i - sy * kScW;
+        int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
+        int s = 0;
+        if (gx >= 3 && gx < a.w - 3 && gy >= 3 && gy < a.h - 3)
+            s = fast_score_at(&raw[(sy + kHalo - 1) * kRawW + sx + kHalo - 1], a.thr, a.nms != 0);
+        sc[i] = (uint8_t)s;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < kTileH / 4; j++) {
+        int ly = threadIdx.y + 4 * j, lx = threadIdx.x;
+        int gx = x0 + lx, gy = y0 + ly;
+        const uint8_t *p = &sc[(ly + 1) * kScW + lx + 1];
+        int s = p[0];
+        if (a.nms && s) {
+            bool keep = s > p[-1] && s > p[1] && s > p[-kScW - 1] && s > p[-kScW] && s > p[-kScW + 1] &&
+                        s > p[kScW - 1] && s > p[kScW] && s > p[kScW + 1];
+            if (!keep) s = 0;
+        }
+        bool inimg = gx < a.w && gy < a.h;
+        if (!inimg) s = 0;
+        unsigned long long m = __ballot(s != 0);
+        if (inimg) score[(int64_t)gy * a.spitch + gx] = (uint8_t)s;
+        if (threadIdx.x == 0 && m && gy < a.h) atomicAdd(&rowcount[gy], __popcll(m));
+    }
+}
+
+// One wave per row: ordered emission of (x, y, response).
+__global__ __launch_bounds__(256) void fast_emit_kernel(FastArgs a)
+{
+    const int b = blockIdx.y;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (y >= a.h) return;
+    const uint8_t *score = a.score + (int64_t)b * a.score_stride + (int64_t)y * a.spitch;
+    const int *rowcount = a.rowcount + (int64_t)b * a.rowcount_stride;
+    int mine = rowcount[y];
+    bool last = (y == a.h - 1);
+    if (mine == 0 && !last) return;
+    // exclusive prefix over the rows above
+    int part = 0;
+    for (int r = lane; r < y; r += 64) part += rowcount[r];
+    int off = wave_sum_i32(part);
+    if (last && lane == 0) a.n_out[b] = off + mine;
+    if (mine == 0) return;
+    float2 *xy = a.kp_xy + (int64_t)b * a.kp_stride;
+    float *resp = a.kp_resp + (int64_t)b * a.kp_stride;
+    for (int x = lane; x < ((a.w + 63) & ~63); x += 64) {
+        int s = x < a.w ? score[x] : 0;
+        unsigned long long m = __ballot(s != 0);
+        if (s) {
+            int idx = off + __popcll(m & ((1ull << lane) - 1ull));
+            if (idx < a.cap) {
+                xy[idx] = make_float2((float)x, (float)y);
+                resp[idx] = a.nms ? (float)s : 0.f;
+            }
+        }
+        off += __popcll(m);
+    }
+}
+
+void launch_fast(const FastArgs &a, int batch, hipStream_t st)
+{
+    hipMemsetAsync(a.rowcount, 0, sizeof(int) * (size_t)a.rowcount_stride * batch, st);
+    dim3 g1((a.w + kTileW - 1) / kTileW, (a.h + kTileH - 1) / kTileH, batch), b1(64, 4, 1);
+    hipLaunchKernelGGL(fast_score_kernel, g1, b1, 0, st, a);
+    dim3 g2((a.h + 3) / 4, batch, 1), b2(256, 1, 1);
+    hipLaunchKernelGGL(fast_emit_kernel, g2, b2, 0, st, a);
+}
+
+}  // namespace svo

@@ -1,0 +1,453 @@
+// svo_abi.hip -- host side of the C-ABI declared in include/svo_abi.h: context lifecycle, buffer
+// ownership (ctx owns every device buffer; no allocation in the steady state) and the stage /
+// fused entry points that launch the HIP kernels.  There is NO CPU fallback in this library.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include "svo_ctx.h"
+
+using namespace svo;
+
+namespace svo {
+// geometry.hip / pipeline.hip
+int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes);
+int stage_triangulate(svo_ctx *ctx, const double P1[12], const double P2[12], const svo_pt2f *x1,
+                      const svo_pt2f *x2, int n, svo_pt3f *out, int mem);
+int stage_pnp_ransac(svo_ctx *ctx, const svo_pt3f *obj, const svo_pt2f *img, int n, const double K[9],
+                     int iterations, float reproj_err, double confidence, svo_pnp_result *res,
+                     uint8_t *inlier_mask, int mem);
+int pipeline_add_frame(svo_ctx *ctx, const uint8_t *left, const uint8_t *right, int pitch, int mem,
+                       svo_step_result *res);
+int pipeline_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t *right_frames, int pitch,
+                         int64_t frame_stride, int n_frames, const double *pose0,
+                         svo_step_result *results, int results_mem);
+}  // namespace svo
+
+static int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// Pyramid geometry: buildOpticalFlowPyramid stops adding levels once the next one would not
+// exceed the 21-pixel window ("if (sz.width <= winSize.width || sz.height <= winSize.height)").
+static void make_geom(int w, int h, PyrGeom *g)
+{
+    memset(g, 0, sizeof(*g));
+    int64_t off = 0;
+    int lw = w, lh = h;
+    for (int l = 0; l < kMaxLevels; l++) {
+        if (l > 0) {
+            int nw = (lw + 1) / 2, nh = (lh + 1) / 2;
+            if (nw <= kWin || nh <= kWin) break;
+            lw = nw; lh = nh;
+        }
+        g->w[l] = lw; g->h[l] = lh;
+        g->pitch[l] = align_up(lw + 2 * kPad, 64);
+        g->origin[l] = off + (int64_t)kPad * g->pitch[l] + kPad;
+        off += (int64_t)g->pitch[l] * (lh + 2 * kPad);
+        off = (off + 255) / 256 * 256;
+        g->nlevels = l + 1;
+    }
+    g->slot_bytes = off;
+}
+
+extern "C" int svo_abi_version(void) { return SVO_ABI_VERSION; }
+
+extern "C" void svo_default_config(svo_config *cfg, int width, int height)
+{
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->width = width; cfg->height = height;
+    cfg->max_keypoints = 8192;
+    cfg->max_batch = 1;
+    cfg->num_slots = 4;
+    cfg->fast_threshold = 20;               // src/tracking.cpp:99
+    cfg->num_features_tracking = 5;         // config/default.yaml:69
+    cfg->iterations = 500;                  // :80
+    cfg->reproj_err = 0.5f;                 // :81
+    cfg->confidence = 0.99f;                // :82
+    cfg->feature_match_error = 3.0;         // :66
+    cfg->inlier_rate = 0.01;                // :77
+    cfg->min_move2 = 0.0005 * 0.0005;       // LK mode, src/tracking.cpp:311
+    cfg->max_move2 = 100.0;
+    const double fx = 718.856, fy = 718.856, cx = 607.193, cy = 185.216, tx = -0.537;   // default.yaml:33-47
+    const double P1[12] = {fx, 0, cx, 0, 0, fy, cy, 0, 0, 0, 1, 0};
+    const double P2[12] = {fx, 0, cx, fx * tx, 0, fy, cy, 0, 0, 0, 1, 0};
+    memcpy(cfg->P1, P1, sizeof(P1));
+    memcpy(cfg->P2, P2, sizeof(P2));
+}
+
+static void free_all(svo_ctx *c)
+{
+    auto F = [](void *p) { if (p) (void)hipFree(p); };
+    F(c->slots); F(c->stage_img); F(c->score); F(c->rowcount); F(c->kp_xy); F(c->kp_resp); F(c->kp_n);
+    F(c->pts_in);
+    for (int i = 0; i < 4; i++) { F(c->pts_out[i]); F(c->status[i]); F(c->cmp[i]); }
+    F(c->keep); F(c->m_out); F(c->X3); F(c->pnp_ws); F(c->d_results); F(c->bslots);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    for (auto &m : c->marks) (void)hipEventDestroy(m.second);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+}
+
+extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
+{
+    if (!cfg || !out) return SVO_ERR_ARG;
+    *out = nullptr;
+    if (cfg->width < 32 || cfg->height < 32 || cfg->max_keypoints < 64 || cfg->max_batch < 1 ||
+        cfg->num_slots < 4 || cfg->width > 16384 || cfg->height > 16384)
+        return SVO_ERR_ARG;
+    svo_ctx *ctx = new (std::nothrow) svo_ctx();
+    if (!ctx) return SVO_ERR_NOMEM;
+    ctx->cfg = *cfg;
+    ctx->device = device;
+    for (int i = 0; i < 16; i++) ctx->pose[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        // fail loudly: this library has no CPU path
+        fprintf(stderr, "svo_create: no usable HIP device (count=%d, requested %d)\n", ndev, device);
+        delete ctx;
+        return SVO_ERR_HIP;
+    }
+    auto fail = [&](int code) { free_all(ctx); delete ctx; return code; };
+#define CK(call) do { if ((call) != hipSuccess) { fprintf(stderr, "svo_create: %s failed\n", #call); return fail(SVO_ERR_HIP); } } while (0)
+    CK(hipSetDevice(device));
+    CK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    make_geom(cfg->width, cfg->height, &ctx->geom);
+
+    const int w = cfg->width, h = cfg->height, cap = cfg->max_keypoints, B = cfg->max_batch;
+    const int n_img = B + 1;
+    ctx->n_img = n_img;
+    CK(hipMalloc(&ctx->slots, (size_t)cfg->num_slots * ctx->geom.slot_bytes));
+    CK(hipMemsetAsync(ctx->slots, 0, (size_t)cfg->num_slots * ctx->geom.slot_bytes, ctx->stream));
+    ctx->slot_built.assign(cfg->num_slots, 0);
+    ctx->stage_pitch = align_up(w, 256);
+    CK(hipMalloc(&ctx->stage_img, (size_t)ctx->stage_pitch * h * 2));
+    ctx->spitch = align_up(w, 64);
+    ctx->score_stride = (int64_t)ctx->spitch * h;
+    CK(hipMalloc(&ctx->score, (size_t)ctx->score_stride * n_img));
+    ctx->rowcount_stride = align_up(h, 64);
+    CK(hipMalloc(&ctx->rowcount, sizeof(int) * (size_t)ctx->rowcount_stride * n_img));
+    CK(hipMalloc(&ctx->kp_xy, sizeof(float2) * (size_t)cap * n_img));
+    CK(hipMalloc(&ctx->kp_resp, sizeof(float) * (size_t)cap * n_img));
+    CK(hipMalloc(&ctx->kp_n, sizeof(int) * (size_t)n_img));
+    CK(hipMalloc(&ctx->pts_in, sizeof(float2) * (size_t)cap * B));
+    for (int i = 0; i < 4; i++) {
+        CK(hipMalloc(&ctx->pts_out[i], sizeof(float2) * (size_t)cap * B));
+        CK(hipMalloc(&ctx->status[i], (size_t)cap * B));
+        CK(hipMalloc(&ctx->cmp[i], sizeof(float2) * (size_t)cap * B));
+    }
+    CK(hipMalloc(&ctx->keep, (size_t)cap * B));
+    CK(hipMalloc(&ctx->m_out, sizeof(int) * (size_t)B));
+    CK(hipMalloc(&ctx->X3, sizeof(float) * 3 * (size_t)cap * B));
+    if (geom_workspace_bytes(*cfg, B, &ctx->pnp_ws_bytes) != SVO_OK) return fail(SVO_ERR_ARG);
+    CK(hipMalloc(&ctx->pnp_ws, ctx->pnp_ws_bytes));
+    CK(hipMalloc(&ctx->d_results, sizeof(svo_step_result) * (size_t)B));
+    CK(hipMalloc(&ctx->bslots, (size_t)2 * n_img * ctx->geom.slot_bytes));
+    ctx->h_pinned_bytes = sizeof(svo_step_result) * (size_t)B + 4096 +
+                          (size_t)cap * (sizeof(float2) + sizeof(float)) + sizeof(int) * 64;
+    CK(hipHostMalloc(&ctx->h_pinned, ctx->h_pinned_bytes, hipHostMallocDefault));
+    CK(hipStreamSynchronize(ctx->stream));
+#undef CK
+    *out = ctx;
+    return SVO_OK;
+}
+
+extern "C" void svo_destroy(svo_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_all(ctx);
+    delete ctx;
+}
+
+extern "C" const char *svo_last_error(const svo_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int svo_set_stream(svo_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SVO_OK;
+}
+
+extern "C" int svo_sync(svo_ctx *ctx)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    return SVO_OK;
+}
+
+extern "C" int svo_num_levels(const svo_ctx *ctx) { return ctx ? ctx->geom.nlevels : 0; }
+
+extern "C" int svo_enable_timing(svo_ctx *ctx, int on)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    ctx->timing = on != 0;
+    return SVO_OK;
+}
+
+extern "C" int svo_get_timing(svo_ctx *ctx, const char **names, float *ms, int cap)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    int n = 0;
+    for (auto &t : ctx->last_times) {
+        if (n >= cap) break;
+        if (names) names[n] = t.first;
+        if (ms) ms[n] = t.second;
+        n++;
+    }
+    return n;
+}
+
+// Host images are copied into the context's staging buffer (aligned pitch); device images are
+// used in place.
+static int resolve_image(svo_ctx *ctx, const uint8_t *img, int pitch, int mem, int stage_idx,
+                         const uint8_t **dptr, int *dpitch)
+{
+    SVO_ARG(img != nullptr, "null image");
+    SVO_ARG(pitch >= ctx->cfg.width, "pitch < width");
+    if (mem == SVO_MEM_DEVICE) { *dptr = img; *dpitch = pitch; return SVO_OK; }
+    SVO_ARG(mem == SVO_MEM_HOST, "mem must be SVO_MEM_HOST or SVO_MEM_DEVICE");
+    uint8_t *dst = ctx->stage_img + (size_t)stage_idx * ctx->stage_pitch * ctx->cfg.height;
+    SVO_HIP(hipMemcpy2DAsync(dst, ctx->stage_pitch, img, pitch, ctx->cfg.width, ctx->cfg.height,
+                             hipMemcpyHostToDevice, ctx->stream));
+    *dptr = dst; *dpitch = ctx->stage_pitch;
+    return SVO_OK;
+}
+
+extern "C" int svo_fast_detect(svo_ctx *ctx, const uint8_t *img, int pitch, int mem, int threshold,
+                               int nonmax, svo_keypoint *out, int cap, int *n_out)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(out && n_out && cap >= 0, "null output");
+    SVO_HIP(hipSetDevice(ctx->device));
+    const uint8_t *d; int dp;
+    int rc = resolve_image(ctx, img, pitch, mem, 0, &d, &dp);
+    if (rc) return rc;
+    FastArgs a{};
+    a.img = d; a.pitch = dp; a.img_stride = 0;
+    a.w = ctx->cfg.width; a.h = ctx->cfg.height;
+    a.thr = threshold < 0 ? 0 : (threshold > 255 ? 255 : threshold);
+    a.nms = nonmax != 0;
+    a.score = ctx->score; a.spitch = ctx->spitch; a.score_stride = ctx->score_stride;
+    a.rowcount = ctx->rowcount; a.rowcount_stride = ctx->rowcount_stride;
+    a.kp_xy = ctx->kp_xy; a.kp_resp = ctx->kp_resp; a.kp_stride = ctx->cfg.max_keypoints;
+    a.n_out = ctx->kp_n; a.cap = ctx->cfg.max_keypoints;
+    launch_fast(a, 1, ctx->stream);
+    SVO_HIP(hipGetLastError());
+    // D2H through pinned scratch: count, then xy + response
+    int *h_n = (int *)ctx->h_pinned;
+    SVO_HIP(hipMemcpyAsync(h_n, ctx->kp_n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    int n = *h_n;
+    *n_out = n;
+    if (n > ctx->cfg.max_keypoints) { ctx->err = "FAST: keypoints exceed max_keypoints"; return SVO_ERR_ARG; }
+    if (n > cap) { ctx->err = "FAST: keypoints exceed caller capacity"; return SVO_ERR_ARG; }
+    if (n == 0) return SVO_OK;
+    float2 *h_xy = (float2 *)((char *)ctx->h_pinned + 256);
+    float *h_r = (float *)(h_xy + ctx->cfg.max_keypoints);
+    SVO_HIP(hipMemcpyAsync(h_xy, ctx->kp_xy, sizeof(float2) * n, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipMemcpyAsync(h_r, ctx->kp_resp, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    // cv::KeyPoint(pt, 7.f, -1, response, 0, -1); always a HOST array (it is an array of structs
+    // for the caller's std::vector<cv::KeyPoint>)
+    for (int i = 0; i < n; i++) {
+        out[i].x = h_xy[i].x; out[i].y = h_xy[i].y; out[i].size = 7.f; out[i].angle = -1.f;
+        out[i].response = h_r[i]; out[i].octave = 0; out[i].class_id = -1;
+    }
+    return SVO_OK;
+}
+
+extern "C" int svo_build_pyramid(svo_ctx *ctx, int slot, const uint8_t *img, int pitch, int mem)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(slot >= 0 && slot < ctx->cfg.num_slots, "slot out of range");
+    SVO_HIP(hipSetDevice(ctx->device));
+    const uint8_t *d; int dp;
+    int rc = resolve_image(ctx, img, pitch, mem, 0, &d, &dp);
+    if (rc) return rc;
+    PyrArgs a{};
+    a.g = ctx->geom; a.img = d; a.pitch = dp; a.img_stride = 0;
+    a.slots = ctx->slots + (size_t)slot * ctx->geom.slot_bytes; a.slot_stride = 0;
+    launch_pyramid(a, 1, ctx->stream);
+    SVO_HIP(hipGetLastError());
+    if (mem == SVO_MEM_HOST) SVO_HIP(hipStreamSynchronize(ctx->stream));   // staging buffer is reused
+    ctx->slot_built[slot] = 1;
+    return SVO_OK;
+}
+
+extern "C" int svo_read_pyramid_level(svo_ctx *ctx, int slot, int level, uint8_t *out, int out_pitch,
+                                      int mem, int *w, int *h)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(slot >= 0 && slot < ctx->cfg.num_slots, "slot out of range");
+    SVO_ARG(level >= 0 && level < ctx->geom.nlevels, "level out of range");
+    if (!ctx->slot_built[slot]) { ctx->err = "pyramid slot not built"; return SVO_ERR_STATE; }
+    const int lw = ctx->geom.w[level], lh = ctx->geom.h[level];
+    if (w) *w = lw;
+    if (h) *h = lh;
+    if (!out) return SVO_OK;
+    SVO_ARG(out_pitch >= lw, "out_pitch < level width");
+    SVO_HIP(hipSetDevice(ctx->device));
+    const uint8_t *s = ctx->slots + (size_t)slot * ctx->geom.slot_bytes;
+    if (mem == SVO_MEM_DEVICE) {
+        launch_pyr_read_level(ctx->geom, s, level, out, out_pitch, ctx->stream);
+        SVO_HIP(hipGetLastError());
+        return SVO_OK;
+    }
+    SVO_HIP(hipMemcpy2DAsync(out, out_pitch, s + ctx->geom.origin[level], ctx->geom.pitch[level], lw, lh,
+                             hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    return SVO_OK;
+}
+
+// copies n items in (host) or aliases (device)
+template <typename T>
+static int to_device(svo_ctx *ctx, const T *src, T *scratch, int n, int mem, const T **d)
+{
+    if (mem == SVO_MEM_DEVICE) { *d = src; return SVO_OK; }
+    SVO_HIP(hipMemcpyAsync(scratch, src, sizeof(T) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    *d = scratch;
+    return SVO_OK;
+}
+
+static void fill_lk_common(svo_ctx *ctx, LkArgs &a, int n)
+{
+    a.g = ctx->geom;
+    a.slot_stride = 0;
+    a.pts_stride = 0;
+    a.n_pts = nullptr; a.n_fixed = n; a.cap = n;
+    a.match_err = ctx->cfg.feature_match_error;
+    a.match_err_f = (float)ctx->cfg.feature_match_error;
+}
+
+extern "C" int svo_lk_track(svo_ctx *ctx, int slot_prev, int slot_next, const svo_pt2f *prev_pts, int n,
+                            svo_pt2f *next_pts, uint8_t *status, int mem)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(slot_prev >= 0 && slot_prev < ctx->cfg.num_slots && slot_next >= 0 &&
+            slot_next < ctx->cfg.num_slots, "slot out of range");
+    SVO_ARG(n >= 0 && n <= ctx->cfg.max_keypoints, "n exceeds max_keypoints");
+    SVO_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE, "bad mem");
+    if (!ctx->slot_built[slot_prev] || !ctx->slot_built[slot_next]) { ctx->err = "pyramid slot not built"; return SVO_ERR_STATE; }
+    if (n == 0) return SVO_OK;
+    SVO_ARG(prev_pts && next_pts && status, "null pointer");
+    SVO_HIP(hipSetDevice(ctx->device));
+    const float2 *d_in;
+    int rc = to_device<float2>(ctx, (const float2 *)prev_pts, ctx->pts_in, n, mem, &d_in);
+    if (rc) return rc;
+    LkArgs a{};
+    fill_lk_common(ctx, a, n);
+    a.ncalls = 1;
+    a.prev[0] = ctx->slots + (size_t)slot_prev * ctx->geom.slot_bytes;
+    a.next[0] = ctx->slots + (size_t)slot_next * ctx->geom.slot_bytes;
+    a.pts_in = d_in;
+    a.pts_out[0] = mem == SVO_MEM_DEVICE ? (float2 *)next_pts : ctx->pts_out[0];
+    a.status[0] = mem == SVO_MEM_DEVICE ? status : ctx->status[0];
+    launch_lk(a, 1, n, ctx->stream);
+    SVO_HIP(hipGetLastError());
+    if (mem == SVO_MEM_HOST) {
+        SVO_HIP(hipMemcpyAsync(next_pts, ctx->pts_out[0], sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        SVO_HIP(hipMemcpyAsync(status, ctx->status[0], (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        SVO_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return SVO_OK;
+}
+
+extern "C" int svo_circular_match(svo_ctx *ctx, int slot_prevL, int slot_prevR, int slot_curL, int slot_curR,
+                                  const svo_pt2f *t1_left, int n, svo_pt2f *out_t1_left,
+                                  svo_pt2f *out_t1_right, svo_pt2f *out_t2_right, svo_pt2f *out_t2_left,
+                                  int *m_out, int mem)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    const int sl[4] = {slot_prevL, slot_prevR, slot_curL, slot_curR};
+    for (int i = 0; i < 4; i++) {
+        SVO_ARG(sl[i] >= 0 && sl[i] < ctx->cfg.num_slots, "slot out of range");
+        if (!ctx->slot_built[sl[i]]) { ctx->err = "pyramid slot not built"; return SVO_ERR_STATE; }
+    }
+    SVO_ARG(n >= 0 && n <= ctx->cfg.max_keypoints, "n exceeds max_keypoints");
+    SVO_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE, "bad mem");
+    SVO_ARG(m_out != nullptr, "null m_out");
+    *m_out = 0;
+    if (n == 0) return SVO_OK;
+    SVO_ARG(t1_left && out_t1_left && out_t1_right && out_t2_right && out_t2_left, "null pointer");
+    SVO_HIP(hipSetDevice(ctx->device));
+    const float2 *d_in;
+    int rc = to_device<float2>(ctx, (const float2 *)t1_left, ctx->pts_in, n, mem, &d_in);
+    if (rc) return rc;
+    auto S = [&](int s) { return ctx->slots + (size_t)s * ctx->geom.slot_bytes; };
+    LkArgs a{};
+    fill_lk_common(ctx, a, n);
+    a.ncalls = 4;
+    // L1 -> R1 -> R2 -> L2 -> L1'   (src/tracking.cpp:593-618)
+    a.prev[0] = S(slot_prevL); a.next[0] = S(slot_prevR);
+    a.prev[1] = S(slot_prevR); a.next[1] = S(slot_curR);
+    a.prev[2] = S(slot_curR);  a.next[2] = S(slot_curL);
+    a.prev[3] = S(slot_curL);  a.next[3] = S(slot_prevL);
+    a.pts_in = d_in;
+    for (int i = 0; i < 4; i++) { a.pts_out[i] = ctx->pts_out[i]; a.status[i] = ctx->status[i]; }
+    a.keep = ctx->keep;
+    launch_lk(a, 1, n, ctx->stream);
+    CompactArgs c{};
+    c.keep = ctx->keep; c.n_pts = nullptr; c.n_fixed = n; c.pts_stride = 0; c.cap = n;
+    c.in[0] = d_in; c.in[1] = ctx->pts_out[0]; c.in[2] = ctx->pts_out[1]; c.in[3] = ctx->pts_out[2];
+    svo_pt2f *outs[4] = {out_t1_left, out_t1_right, out_t2_right, out_t2_left};
+    for (int i = 0; i < 4; i++) c.out[i] = mem == SVO_MEM_DEVICE ? (float2 *)outs[i] : ctx->cmp[i];
+    c.m_out = ctx->m_out;
+    launch_compact(c, 1, ctx->stream);
+    SVO_HIP(hipGetLastError());
+    int *h_m = (int *)ctx->h_pinned;
+    SVO_HIP(hipMemcpyAsync(h_m, ctx->m_out, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    *m_out = *h_m;
+    if (mem == SVO_MEM_HOST && *h_m > 0) {
+        for (int i = 0; i < 4; i++)
+            SVO_HIP(hipMemcpyAsync(outs[i], ctx->cmp[i], sizeof(float2) * (size_t)*h_m, hipMemcpyDeviceToHost, ctx->stream));
+        SVO_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return SVO_OK;
+}
+
+extern "C" int svo_triangulate(svo_ctx *ctx, const double P1[12], const double P2[12], const svo_pt2f *x1,
+                               const svo_pt2f *x2, int n, svo_pt3f *out, int mem)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    return stage_triangulate(ctx, P1, P2, x1, x2, n, out, mem);
+}
+
+extern "C" int svo_pnp_ransac(svo_ctx *ctx, const svo_pt3f *obj, const svo_pt2f *img, int n, const double K[9],
+                              int iterations, float reproj_err, double confidence, svo_pnp_result *res,
+                              uint8_t *inlier_mask, int mem)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    return stage_pnp_ransac(ctx, obj, img, n, K, iterations, reproj_err, confidence, res, inlier_mask, mem);
+}
+
+extern "C" int svo_add_frame(svo_ctx *ctx, const uint8_t *left, const uint8_t *right, int pitch, int mem,
+                             svo_step_result *res)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    return pipeline_add_frame(ctx, left, right, pitch, mem, res);
+}
+
+extern "C" int svo_reset(svo_ctx *ctx)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    ctx->online_frames = 0; ctx->online_cur = 0;
+    for (int i = 0; i < 16; i++) ctx->pose[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    return SVO_OK;
+}
+
+extern "C" int svo_get_pose(svo_ctx *ctx, double pose[16])
+{
+    if (!ctx || !pose) return SVO_ERR_ARG;
+    memcpy(pose, ctx->pose, sizeof(double) * 16);
+    return SVO_OK;
+}
+
+extern "C" int svo_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t *right_frames,
+                               int pitch, int64_t frame_stride, int n_frames, const double *pose0,
+                               svo_step_result *results, int results_mem)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    return pipeline_track_batch(ctx, left_frames, right_frames, pitch, frame_stride, n_frames, pose0,
+                                results, results_mem);
+}

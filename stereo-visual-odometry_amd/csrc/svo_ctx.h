@@ -1,0 +1,63 @@
+// svo_ctx.h -- the context object behind the C-ABI (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "../../include/svo_abi.h"
+#include "svo_kernels.h"
+
+struct svo_ctx {
+    svo_config cfg;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    svo::PyrGeom geom;
+
+    int n_img = 0;                    // images the batch buffers are sized for (max_batch + 1)
+    // ---- stage-API resources
+    uint8_t *slots = nullptr;         // num_slots pyramid slots
+    std::vector<char> slot_built;
+    uint8_t *stage_img = nullptr;     // device staging for host images (2 images, aligned pitch)
+    int stage_pitch = 0;
+    // ---- FAST scratch + outputs, n_img images
+    uint8_t *score = nullptr; int spitch = 0; int64_t score_stride = 0;
+    int *rowcount = nullptr; int64_t rowcount_stride = 0;
+    float2 *kp_xy = nullptr; float *kp_resp = nullptr; int *kp_n = nullptr;
+    // ---- LK buffers, max_batch items x max_keypoints
+    float2 *pts_in = nullptr;
+    float2 *pts_out[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint8_t *status[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint8_t *keep = nullptr;
+    float2 *cmp[4] = {nullptr, nullptr, nullptr, nullptr};    // compacted t1l, t1r, t2r, t2l
+    int *m_out = nullptr;
+    // ---- geometry buffers (geometry.hip)
+    float *X3 = nullptr;              // triangulated points, 3 floats per point
+    void *pnp_ws = nullptr; size_t pnp_ws_bytes = 0;
+    svo_step_result *d_results = nullptr;
+    // ---- batch-mode pyramid slots: 2 * n_img
+    uint8_t *bslots = nullptr;
+    // ---- online state (svo_add_frame)
+    int online_frames = 0;            // frames fed since reset
+    int online_cur = 0;               // which half of the 2-frame ring holds the latest frame
+    double pose[16];
+    // ---- pinned host scratch
+    void *h_pinned = nullptr; size_t h_pinned_bytes = 0;
+    // ---- timing
+    bool timing = false;
+    std::vector<std::pair<const char *, hipEvent_t>> marks;
+    std::vector<std::pair<const char *, float>> last_times;
+};
+
+#define SVO_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e__);                    \
+            return SVO_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define SVO_ARG(cond, msg)                                                                    \
+    do {                                                                                      \
+        if (!(cond)) { ctx->err = std::string("bad argument: ") + msg; return SVO_ERR_ARG; }   \
+    } while (0)
