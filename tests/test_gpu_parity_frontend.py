@@ -24,7 +24,7 @@ def _ctx(pkg, w, h, **kw):
                                           (1241, 376, 4, 20), (129, 65, 5, 40)])
 def test_fast_parity_random_images(pkg, oracle, torch_cuda, w, h, seed, thr):
     img = rand_image(h, w, seed)
-    ctx = _ctx(pkg, w, h, max_keypoints=32768)
+    ctx = _ctx(pkg, w, h, max_keypoints=1 << 17)
     ref = oracle.fast(img, thr, True)
     # device-resident input (unaligned pitch = w) and host input must both match
     got_d = ctx.fast_detect(torch_cuda.from_numpy(img).cuda(), thr, True)
@@ -33,7 +33,7 @@ def test_fast_parity_random_images(pkg, oracle, torch_cuda, w, h, seed, thr):
     assert got_d.tobytes() == ref.tobytes()
     assert got_h.tobytes() == ref.tobytes()
     ref0 = oracle.fast(img, thr, False)
-    got0 = ctx.fast_detect(img, thr, False, cap=32768)
+    got0 = ctx.fast_detect(img, thr, False)
     assert got0.tobytes() == ref0.tobytes()
     ctx.close()
 
