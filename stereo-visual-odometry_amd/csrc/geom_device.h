@@ -1,0 +1,523 @@
+// geom_device.h -- double-precision device routines of the pose solver: one-sided Jacobi SVD and
+// the solves built on it, EPnP, Rodrigues, the pinhole projection with its Jacobian.
+//
+// These restate the OpenCV 3.4 algorithms behind cv::triangulatePoints / cv::solvePnPRansac /
+// cv::Rodrigues (reference call sites src/tracking.cpp:292-294, 485-488) for per-thread execution
+// on gfx950.  Every floating-point expression keeps the association order of the published
+// algorithms (and of oracle/geom.c, oracle/pnp.c), the library is built with -ffp-contract=off,
+// and f64 +,-,*,/,sqrt are IEEE-exact on CDNA4, so hypotheses, inlier masks and triangulated
+// points are bit-identical to the CPU oracle; only sin/cos/acos/log/pow/atan2 (device libm) may
+// differ in the last ulp, which the Levenberg-Marquardt refit absorbs.
+//
+// Matrices are addressed through (pointer, element stride) so the same code runs on private
+// arrays (stride 1) and on the lane-interleaved LDS image used for the 12x12 EPnP eigenproblem
+// (stride 64: element e of lane t at base[e*64 + t], bank-conflict-free ds_read_b64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+
+namespace svo {
+
+#define SVO_DBL_EPS 2.220446049250313e-16
+#define SVO_DBL_MIN 2.2250738585072014e-308
+
+// JacobiSVDImpl_<double>: At is n rows of length m, element (i,k) at At[(i*m+k)*as].
+// Vt (n x n, element stride vs) may be null; `sort_rows` makes the rows of At follow the
+// descending sort and get normalised even without Vt (what cv::SVD does when U is requested).
+__device__ inline void jacobi_svd_d(double *At, int as, int m, int n, double *W, double *Vt, int vs,
+                                    bool sort_rows)
+{
+    const double eps = SVO_DBL_EPS * 10, minval = SVO_DBL_MIN;
+    const int max_iter = m > 30 ? m : 30;
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) { double t = At[(i * m + k) * as]; sd += t * t; }
+        W[i] = sd;
+        if (Vt) {
+            for (int k = 0; k < n; k++) Vt[(i * n + k) * vs] = 0;
+            Vt[(i * n + i) * vs] = 1;
+        }
+    }
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+        for (int i = 0; i < n - 1; i++)
+            for (int j = i + 1; j < n; j++) {
+                double *Ai = At + (i * m) * as, *Aj = At + (j * m) * as;
+                double a = W[i], p = 0, b = W[j], c, s;
+                for (int k = 0; k < m; k++) p += Ai[k * as] * Aj[k * as];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = sqrt(p * p + beta * beta);
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+                for (int k = 0; k < m; k++) {
+                    double x = Ai[k * as], y = Aj[k * as];
+                    double t0 = c * x + s * y;
+                    double t1 = -s * x + c * y;
+                    Ai[k * as] = t0; Aj[k * as] = t1;
+                    a += t0 * t0; b += t1 * t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = true;
+                if (Vt) {
+                    double *Vi = Vt + (i * n) * vs, *Vj = Vt + (j * n) * vs;
+                    for (int k = 0; k < n; k++) {
+                        double x = Vi[k * vs], y = Vj[k * vs];
+                        double t0 = c * x + s * y;
+                        double t1 = -s * x + c * y;
+                        Vi[k * vs] = t0; Vj[k * vs] = t1;
+                    }
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) { double t = At[(i * m + k) * as]; sd += t * t; }
+        W[i] = sqrt(sd);
+    }
+    for (int i = 0; i < n - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < n; k++) if (W[j] < W[k]) j = k;
+        if (i != j) {
+            double t = W[i]; W[i] = W[j]; W[j] = t;
+            if (Vt || sort_rows)
+                for (int k = 0; k < m; k++) {
+                    t = At[(i * m + k) * as]; At[(i * m + k) * as] = At[(j * m + k) * as]; At[(j * m + k) * as] = t;
+                }
+            if (Vt)
+                for (int k = 0; k < n; k++) {
+                    t = Vt[(i * n + k) * vs]; Vt[(i * n + k) * vs] = Vt[(j * n + k) * vs]; Vt[(j * n + k) * vs] = t;
+                }
+        }
+    }
+    if (!Vt && !sort_rows) return;
+    for (int i = 0; i < n; i++) {
+        double sd = W[i];
+        double s = sd > minval ? 1 / sd : 0.;
+        for (int k = 0; k < m; k++) At[(i * m + k) * as] *= s;
+    }
+}
+
+// cv::solve(A, b, x, DECOMP_SVD), A m x n row-major (m >= n, n <= 6, m <= 6), one right-hand side.
+__device__ inline void svd_solve_d(const double *A, int m, int n, const double *b, double *x)
+{
+    double At[36], W[6], Vt[36];
+    for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) At[j * m + i] = A[i * n + j];
+    jacobi_svd_d(At, 1, m, n, W, Vt, 1, false);
+    double threshold = 0;
+    for (int i = 0; i < n; i++) x[i] = 0;
+    for (int i = 0; i < n; i++) threshold += W[i];
+    threshold *= SVO_DBL_EPS * 2;
+    for (int i = 0; i < n; i++) {
+        double wi = W[i];
+        if (fabs(wi) <= threshold) continue;
+        wi = 1 / wi;
+        double s = 0;
+        for (int j = 0; j < m; j++) s += At[i * m + j] * b[j];
+        s *= wi;
+        for (int j = 0; j < n; j++) x[j] = x[j] + s * Vt[i * n + j];
+    }
+}
+
+// cv::invert(A, Ainv, DECOMP_SVD) for 3x3
+__device__ inline void svd_invert3_d(const double *A, double *Ainv)
+{
+    double At[9], W[3], Vt[9], buffer[3], threshold = 0;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) At[j * 3 + i] = A[i * 3 + j];
+    jacobi_svd_d(At, 1, 3, 3, W, Vt, 1, false);
+    for (int i = 0; i < 9; i++) Ainv[i] = 0;
+    for (int i = 0; i < 3; i++) threshold += W[i];
+    threshold *= SVO_DBL_EPS * 2;
+    for (int i = 0; i < 3; i++) {
+        double wi = W[i];
+        if (fabs(wi) <= threshold) continue;
+        wi = 1 / wi;
+        for (int j = 0; j < 3; j++) buffer[j] = At[i * 3 + j] * wi;
+        for (int j = 0; j < 3; j++)
+            for (int k = 0; k < 3; k++) Ainv[j * 3 + k] = Ainv[j * 3 + k] + Vt[i * 3 + j] * buffer[k];
+    }
+}
+
+__device__ inline double dot3_d(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ inline double dist2_d(const double *a, const double *b)
+{
+    return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
+}
+
+// epnp::qr_solve on the 6x4 Gauss-Newton system (column-max scan quirk of the published code kept)
+__device__ inline void epnp_qr_solve_d(double *A, double *b, double *X)
+{
+    const int nr = 6, nc = 4;
+    double A1[4], A2[4];
+    for (int k = 0; k < nc; k++) {
+        double eta = fabs(A[k * nc + k]);
+        for (int i = k + 1; i < nr; i++) {
+            double elt = fabs(A[(i - 1) * nc + k]);
+            if (eta < elt) eta = elt;
+        }
+        if (eta == 0) return;
+        double sum2 = 0.0, inv_eta = 1. / eta;
+        for (int i = k; i < nr; i++) {
+            A[i * nc + k] *= inv_eta;
+            sum2 += A[i * nc + k] * A[i * nc + k];
+        }
+        double sigma = sqrt(sum2);
+        if (A[k * nc + k] < 0) sigma = -sigma;
+        A[k * nc + k] += sigma;
+        A1[k] = sigma * A[k * nc + k];
+        A2[k] = -eta * sigma;
+        for (int j = k + 1; j < nc; j++) {
+            double sum = 0;
+            for (int i = k; i < nr; i++) sum += A[i * nc + k] * A[i * nc + j];
+            double tau = sum / A1[k];
+            for (int i = k; i < nr; i++) A[i * nc + j] -= tau * A[i * nc + k];
+        }
+    }
+    for (int j = 0; j < nc; j++) {
+        double tau = 0;
+        for (int i = j; i < nr; i++) tau += A[i * nc + j] * b[i];
+        tau /= A1[j];
+        for (int i = j; i < nr; i++) b[i] -= tau * A[i * nc + j];
+    }
+    X[nc - 1] = b[nc - 1] / A2[nc - 1];
+    for (int i = nc - 2; i >= 0; i--) {
+        double sum = 0;
+        for (int j = i + 1; j < nc; j++) sum += A[i * nc + j] * X[j];
+        X[i] = (b[i] - sum) / A2[i];
+    }
+}
+
+struct Epnp5 {
+    double pws[15], us[10], alphas[20], pcs[15];
+    double cws[4][3], ccs[4][3];
+    double fu, fv, uc, vc;
+};
+
+// compute_ccs + compute_pcs + solve_for_sign + estimate_R_and_t + reprojection_error
+__device__ inline double epnp_R_and_t_d(Epnp5 &e, const double *v /* 4 x 12: ut rows 11,10,9,8 */,
+                                        const double *betas, double R[9], double t[3])
+{
+    const int n = 5;
+    for (int i = 0; i < 4; i++) e.ccs[i][0] = e.ccs[i][1] = e.ccs[i][2] = 0.0;
+    for (int i = 0; i < 4; i++) {
+        const double *vi = v + 12 * i;
+        for (int j = 0; j < 4; j++) for (int k = 0; k < 3; k++) e.ccs[j][k] += betas[i] * vi[3 * j + k];
+    }
+    for (int i = 0; i < n; i++) {
+        const double *a = e.alphas + 4 * i;
+        for (int j = 0; j < 3; j++)
+            e.pcs[3 * i + j] = a[0] * e.ccs[0][j] + a[1] * e.ccs[1][j] + a[2] * e.ccs[2][j] + a[3] * e.ccs[3][j];
+    }
+    if (e.pcs[2] < 0.0) {
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 3; j++) e.ccs[i][j] = -e.ccs[i][j];
+        for (int i = 0; i < 3 * n; i++) e.pcs[i] = -e.pcs[i];
+    }
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) { pc0[j] += e.pcs[3 * i + j]; pw0[j] += e.pws[3 * i + j]; }
+    for (int j = 0; j < 3; j++) { pc0[j] /= n; pw0[j] /= n; }
+    double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, abt_d[3], abt_ut[9], abt_vt[9];
+    for (int i = 0; i < n; i++) {
+        const double *pc = e.pcs + 3 * i, *pw = e.pws + 3 * i;
+        for (int j = 0; j < 3; j++) {
+            abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
+            abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
+            abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
+        }
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) abt_ut[j * 3 + i] = abt[i * 3 + j];
+    jacobi_svd_d(abt_ut, 1, 3, 3, abt_d, abt_vt, 1, false);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            R[i * 3 + j] = abt_ut[0 * 3 + i] * abt_vt[0 * 3 + j] + abt_ut[1 * 3 + i] * abt_vt[1 * 3 + j] +
+                           abt_ut[2 * 3 + i] * abt_vt[2 * 3 + j];
+    const double det = R[0] * R[4] * R[8] + R[1] * R[5] * R[6] + R[2] * R[3] * R[7] -
+                       R[2] * R[4] * R[6] - R[1] * R[3] * R[8] - R[0] * R[5] * R[7];
+    if (det < 0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
+    t[0] = pc0[0] - dot3_d(R, pw0);
+    t[1] = pc0[1] - dot3_d(R + 3, pw0);
+    t[2] = pc0[2] - dot3_d(R + 6, pw0);
+    double sum2 = 0.0;
+    for (int i = 0; i < n; i++) {
+        const double *pw = e.pws + 3 * i;
+        double Xc = dot3_d(R, pw) + t[0], Yc = dot3_d(R + 3, pw) + t[1];
+        double inv_Zc = 1.0 / (dot3_d(R + 6, pw) + t[2]);
+        double ue = e.uc + e.fu * Xc * inv_Zc, ve = e.vc + e.fv * Yc * inv_Zc;
+        double u = e.us[2 * i], vv = e.us[2 * i + 1];
+        sum2 += sqrt((u - ue) * (u - ue) + (vv - ve) * (vv - ve));
+    }
+    return sum2 / n;
+}
+
+// epnp::compute_pose for the 5-point minimal sample.  `big` is this lane's 144-double matrix
+// region (element stride `bs`), used for the 12x12 eigenproblem of M^T M.
+__device__ inline void epnp5_d(Epnp5 &e, double *big, int bs, double Rout[9], double tout[3])
+{
+    const int n = 5;
+    // ---- choose_control_points
+    e.cws[0][0] = e.cws[0][1] = e.cws[0][2] = 0;
+    for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) e.cws[0][j] += e.pws[3 * i + j];
+    for (int j = 0; j < 3; j++) e.cws[0][j] /= n;
+    {
+        double PW0[15], c3[9], dc[3], uct[9], vt3[9];
+        for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) PW0[3 * i + j] = e.pws[3 * i + j] - e.cws[0][j];
+        for (int i = 0; i < 3; i++)
+            for (int j = i; j < 3; j++) {
+                double s = 0;
+                for (int k = 0; k < n; k++) s += PW0[k * 3 + i] * PW0[k * 3 + j];
+                c3[i * 3 + j] = s;
+            }
+        for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) c3[i * 3 + j] = c3[j * 3 + i];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) uct[j * 3 + i] = c3[i * 3 + j];
+        jacobi_svd_d(uct, 1, 3, 3, dc, vt3, 1, false);
+        for (int i = 1; i < 4; i++) {
+            double k = sqrt(dc[i - 1] / n);
+            for (int j = 0; j < 3; j++) e.cws[i][j] = e.cws[0][j] + k * uct[3 * (i - 1) + j];
+        }
+    }
+    // ---- compute_barycentric_coordinates
+    {
+        double cc[9], ci[9];
+        for (int i = 0; i < 3; i++) for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = e.cws[j][i] - e.cws[0][i];
+        svd_invert3_d(cc, ci);
+        for (int i = 0; i < n; i++) {
+            const double *pi = e.pws + 3 * i;
+            double *a = e.alphas + 4 * i;
+            for (int j = 0; j < 3; j++)
+                a[1 + j] = ci[3 * j] * (pi[0] - e.cws[0][0]) + ci[3 * j + 1] * (pi[1] - e.cws[0][1]) +
+                           ci[3 * j + 2] * (pi[2] - e.cws[0][2]);
+            a[0] = 1.0 - a[1] - a[2] - a[3];
+        }
+    }
+    // ---- M^T M accumulated row by row (same per-entry summation order as cvMulTransposed),
+    //      directly into the transposed (== itself, symmetric) Jacobi work matrix
+    for (int i = 0; i < 144; i++) big[i * bs] = 0;
+    for (int r = 0; r < 2 * n; r++) {
+        const int p = r >> 1;
+        const double *as = e.alphas + 4 * p;
+        double row[12];
+        for (int j = 0; j < 4; j++) {
+            if ((r & 1) == 0) { row[3 * j] = as[j] * e.fu; row[3 * j + 1] = 0.0; row[3 * j + 2] = as[j] * (e.uc - e.us[2 * p]); }
+            else { row[3 * j] = 0.0; row[3 * j + 1] = as[j] * e.fv; row[3 * j + 2] = as[j] * (e.vc - e.us[2 * p + 1]); }
+        }
+        for (int i = 0; i < 12; i++)
+            for (int j = i; j < 12; j++) big[(i * 12 + j) * bs] += row[i] * row[j];
+    }
+    for (int i = 0; i < 12; i++) for (int j = 0; j < i; j++) big[(i * 12 + j) * bs] = big[(j * 12 + i) * bs];
+    double d12[12];
+    jacobi_svd_d(big, bs, 12, 12, d12, nullptr, 0, true);
+    double v[48];                                   // ut rows 11, 10, 9, 8
+    for (int i = 0; i < 4; i++) for (int k = 0; k < 12; k++) v[i * 12 + k] = big[((11 - i) * 12 + k) * bs];
+
+    // ---- compute_L_6x10, compute_rho
+    double L[60], rho[6];
+    {
+        double dv[4][6][3];
+        for (int i = 0; i < 4; i++) {
+            int a = 0, b = 1;
+            for (int j = 0; j < 6; j++) {
+                dv[i][j][0] = v[i * 12 + 3 * a] - v[i * 12 + 3 * b];
+                dv[i][j][1] = v[i * 12 + 3 * a + 1] - v[i * 12 + 3 * b + 1];
+                dv[i][j][2] = v[i * 12 + 3 * a + 2] - v[i * 12 + 3 * b + 2];
+                b++;
+                if (b > 3) { a++; b = a + 1; }
+            }
+        }
+        for (int i = 0; i < 6; i++) {
+            double *row = L + 10 * i;
+            row[0] = dot3_d(dv[0][i], dv[0][i]);
+            row[1] = 2.0 * dot3_d(dv[0][i], dv[1][i]);
+            row[2] = dot3_d(dv[1][i], dv[1][i]);
+            row[3] = 2.0 * dot3_d(dv[0][i], dv[2][i]);
+            row[4] = 2.0 * dot3_d(dv[1][i], dv[2][i]);
+            row[5] = dot3_d(dv[2][i], dv[2][i]);
+            row[6] = 2.0 * dot3_d(dv[0][i], dv[3][i]);
+            row[7] = 2.0 * dot3_d(dv[1][i], dv[3][i]);
+            row[8] = 2.0 * dot3_d(dv[2][i], dv[3][i]);
+            row[9] = dot3_d(dv[3][i], dv[3][i]);
+        }
+    }
+    rho[0] = dist2_d(e.cws[0], e.cws[1]); rho[1] = dist2_d(e.cws[0], e.cws[2]);
+    rho[2] = dist2_d(e.cws[0], e.cws[3]); rho[3] = dist2_d(e.cws[1], e.cws[2]);
+    rho[4] = dist2_d(e.cws[1], e.cws[3]); rho[5] = dist2_d(e.cws[2], e.cws[3]);
+
+    double best_rep = 0;
+    for (int N = 1; N <= 3; N++) {
+        // ---- find_betas_approx_N
+        double betas[4], Lr[30], bb[5];
+        const int nc = N == 1 ? 4 : (N == 2 ? 3 : 5);
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < nc; j++) {
+                int col = N == 1 ? (j == 0 ? 0 : j == 1 ? 1 : j == 2 ? 3 : 6) : j;
+                Lr[i * nc + j] = L[10 * i + col];
+            }
+        svd_solve_d(Lr, 6, nc, rho, bb);
+        if (N == 1) {
+            if (bb[0] < 0) {
+                betas[0] = sqrt(-bb[0]);
+                betas[1] = -bb[1] / betas[0]; betas[2] = -bb[2] / betas[0]; betas[3] = -bb[3] / betas[0];
+            } else {
+                betas[0] = sqrt(bb[0]);
+                betas[1] = bb[1] / betas[0]; betas[2] = bb[2] / betas[0]; betas[3] = bb[3] / betas[0];
+            }
+        } else {
+            if (bb[0] < 0) {
+                betas[0] = sqrt(-bb[0]);
+                betas[1] = (bb[2] < 0) ? sqrt(-bb[2]) : 0.0;
+            } else {
+                betas[0] = sqrt(bb[0]);
+                betas[1] = (bb[2] > 0) ? sqrt(bb[2]) : 0.0;
+            }
+            if (bb[1] < 0) betas[0] = -betas[0];
+            betas[2] = N == 3 ? bb[3] / betas[0] : 0.0;
+            betas[3] = 0.0;
+        }
+        // ---- gauss_newton: 5 iterations
+        for (int it = 0; it < 5; it++) {
+            double A[24], b[6], x[4] = {0, 0, 0, 0};
+            for (int i = 0; i < 6; i++) {
+                const double *r = L + i * 10;
+                double *ra = A + i * 4;
+                ra[0] = 2 * r[0] * betas[0] + r[1] * betas[1] + r[3] * betas[2] + r[6] * betas[3];
+                ra[1] = r[1] * betas[0] + 2 * r[2] * betas[1] + r[4] * betas[2] + r[7] * betas[3];
+                ra[2] = r[3] * betas[0] + r[4] * betas[1] + 2 * r[5] * betas[2] + r[8] * betas[3];
+                ra[3] = r[6] * betas[0] + r[7] * betas[1] + r[8] * betas[2] + 2 * r[9] * betas[3];
+                b[i] = rho[i] - (r[0] * betas[0] * betas[0] + r[1] * betas[0] * betas[1] +
+                                 r[2] * betas[1] * betas[1] + r[3] * betas[0] * betas[2] +
+                                 r[4] * betas[1] * betas[2] + r[5] * betas[2] * betas[2] +
+                                 r[6] * betas[0] * betas[3] + r[7] * betas[1] * betas[3] +
+                                 r[8] * betas[2] * betas[3] + r[9] * betas[3] * betas[3]);
+            }
+            epnp_qr_solve_d(A, b, x);
+            for (int i = 0; i < 4; i++) betas[i] += x[i];
+        }
+        double Rn[9], tn[3];
+        double rep = epnp_R_and_t_d(e, v, betas, Rn, tn);
+        // "N = 1; if (rep[2] < rep[1]) N = 2; if (rep[3] < rep[N]) N = 3;"
+        if (N == 1 || rep < best_rep) {
+            best_rep = rep;
+            for (int i = 0; i < 9; i++) Rout[i] = Rn[i];
+            for (int i = 0; i < 3; i++) tout[i] = tn[i];
+        }
+    }
+}
+
+// cv::Rodrigues vector -> matrix (+ 3x9 Jacobian)
+__device__ inline void rodrigues_vec2mat_d(const double r[3], double R[9], double *J)
+{
+    double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (theta < SVO_DBL_EPS) {
+        for (int i = 0; i < 9; i++) R[i] = 0;
+        R[0] = R[4] = R[8] = 1;
+        if (J) {
+            for (int i = 0; i < 27; i++) J[i] = 0;
+            J[5] = J[15] = J[19] = -1;
+            J[7] = J[11] = J[21] = 1;
+        }
+        return;
+    }
+    double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = theta ? 1. / theta : 0.;
+    double rx = r[0] * itheta, ry = r[1] * itheta, rz = r[2] * itheta;
+    double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+    double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + s * r_x[k];
+    if (J) {
+        double drrt[27] = {rx + rx, ry, rz, ry, 0, 0, rz, 0, 0,
+                           0, rx, 0, rx, ry + ry, rz, 0, rz, 0,
+                           0, 0, rx, 0, 0, ry, rx, ry, rz + rz};
+        const double d_r_x_[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0,
+                                   0, 0, 1, 0, 0, 0, -1, 0, 0,
+                                   0, -1, 0, 1, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 3; i++) {
+            double ri = i == 0 ? rx : i == 1 ? ry : rz;
+            double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta;
+            double a3 = (c - s * itheta) * ri, a4 = s * itheta;
+            for (int k = 0; k < 9; k++)
+                J[i * 9 + k] = a0 * I[k] + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * r_x[k] + a4 * d_r_x_[i * 9 + k];
+        }
+    }
+}
+
+// cv::Rodrigues matrix -> vector
+__device__ inline void rodrigues_mat2vec_d(const double Rin[9], double r[3])
+{
+    double At[9], W[3], Vt[9], R[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) At[j * 3 + i] = Rin[i * 3 + j];
+    jacobi_svd_d(At, 1, 3, 3, W, Vt, 1, false);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += At[k * 3 + i] * Vt[k * 3 + j];
+            R[i * 3 + j] = s;
+        }
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0) { rx = ry = rz = 0; }
+        else {
+            double t;
+            t = (R[0] + 1) * 0.5; rx = sqrt(t > 0. ? t : 0.);
+            t = (R[4] + 1) * 0.5; ry = sqrt(t > 0. ? t : 0.) * (R[1] < 0 ? -1. : 1.);
+            t = (R[8] + 1) * 0.5; rz = sqrt(t > 0. ? t : 0.) * (R[2] < 0 ? -1. : 1.);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= theta; ry *= theta; rz *= theta;
+        }
+    } else {
+        double vth = 1 / (2 * s);
+        vth *= theta;
+        rx *= vth; ry *= vth; rz *= vth;
+    }
+    r[0] = rx; r[1] = ry; r[2] = rz;
+}
+
+// PnPRansacCallback::computeError for one point (cvProjectPoints2 in double -> float -> float L2^2)
+__device__ inline float reproj_err2_d(const double R[9], const double t[3], double fx, double fy, double cx,
+                                      double cy, float Px, float Py, float Pz, float mx, float my)
+{
+    double X = Px, Y = Py, Z = Pz;
+    double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+    double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+    double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    z = z ? 1. / z : 1;
+    x *= z; y *= z;
+    float px = (float)(x * fx + cx), py = (float)(y * fy + cy);
+    float dx = mx - px, dy = my - py;
+    float s = 0.f;
+    s += dx * dx;
+    s += dy * dy;
+    return s;
+}
+
+// RANSACUpdateNumIters
+__device__ inline int ransac_update_iters_d(double p, double ep, int model_points, int max_iters)
+{
+    p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
+    ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
+    double num = 1. - p > SVO_DBL_MIN ? 1. - p : SVO_DBL_MIN;
+    double denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < SVO_DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+__device__ inline uint32_t rng_next_d(uint64_t &state)
+{
+    state = (uint64_t)(uint32_t)state * 4164903690u + (uint32_t)(state >> 32);
+    return (uint32_t)state;
+}
+
+}  // namespace svo

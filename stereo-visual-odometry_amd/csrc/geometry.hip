@@ -1,13 +1,509 @@
-// geometry.hip -- placeholder until the triangulation / PnP kernels land (next commit).
+// geometry.hip -- triangulation, RANSAC-EPnP + Levenberg-Marquardt pose solver, motion gates and
+// pose chaining for gfx950; replaces cv::triangulatePoints / cv::convertPointsFromHomogeneous
+// (reference src/tracking.cpp:292-294), cv::solvePnPRansac + cv::Rodrigues (:485-488) and the
+// gating / accumulation code (:305-329, 440-463).  "g2o" in the reference is link-only; the live
+// solver is the one restated here.
+//
+// Kernels
+//   triangulate_kernel : one thread per point, 4x4 DLT + one-sided Jacobi SVD in f64.
+//   pnp_ransac_kernel  : one 64-lane workgroup per frame pair.  Hypotheses are evaluated 64 at a
+//       time -- lane h runs the 5-point EPnP of hypothesis base+h (its 12x12 eigenproblem lives in
+//       a lane-interleaved 72 KB LDS image) and scores it against all M points -- then the wave
+//       replays OpenCV's sequential "better model -> shrink niters" rule over the 64 inlier counts,
+//       so the winning hypothesis, the adaptive stop and the inlier mask are exactly those of the
+//       serial algorithm.  The RNG (cv::RNG multiply-with-carry, seed 2^64-1) is stepped by every
+//       lane identically.  The refit on the inliers is LM on 6 parameters with the residual /
+//       J^T J / J^T e reductions done across the wave (butterfly all-reduce, every lane holds
+//       bit-identical sums and takes the same branches).
+//   finalize_kernel    : per pair failure staging, Euler / translation gates, inv([R t;0 1]).
+//   chain_kernel       : frame_pose_ *= T^-1 over the batch, skipping failed steps.
+#include <cstring>
 #include "svo_ctx.h"
+#include "geom_device.h"
+
 namespace svo {
-int geom_workspace_bytes(const svo_config &, int, size_t *bytes) { *bytes = 256; return SVO_OK; }
-int stage_triangulate(svo_ctx *ctx, const double *, const double *, const svo_pt2f *, const svo_pt2f *, int,
-                      svo_pt3f *, int) { ctx->err = "not implemented"; return SVO_ERR_STATE; }
-int stage_pnp_ransac(svo_ctx *ctx, const svo_pt3f *, const svo_pt2f *, int, const double *, int, float, double,
-                     svo_pnp_result *, uint8_t *, int) { ctx->err = "not implemented"; return SVO_ERR_STATE; }
-int pipeline_add_frame(svo_ctx *ctx, const uint8_t *, const uint8_t *, int, int, svo_step_result *)
-{ ctx->err = "not implemented"; return SVO_ERR_STATE; }
-int pipeline_track_batch(svo_ctx *ctx, const uint8_t *, const uint8_t *, int, int64_t, int, const double *,
-                         svo_step_result *, int) { ctx->err = "not implemented"; return SVO_ERR_STATE; }
+
+// ------------------------------------------------------------------------------------------
+struct TriArgs {
+    double P1[12], P2[12];
+    const float2 *x1, *x2; float *out3; int64_t stride;    // item b at + b*stride points
+    const int *n_pts; int n_fixed;
+};
+
+__global__ __launch_bounds__(64) void triangulate_kernel(TriArgs a)
+{
+    const int b = blockIdx.y;
+    const int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t o = (int64_t)b * a.stride + i;
+    const float2 p1 = a.x1[o], p2 = a.x2[o];
+    const double xs[2] = {(double)p1.x, (double)p2.x}, ys[2] = {(double)p1.y, (double)p2.y};
+    double A[16], At[16], W[4], Vt[16];
+    for (int j = 0; j < 2; j++) {
+        const double *P = j == 0 ? a.P1 : a.P2;
+        for (int k = 0; k < 4; k++) {
+            A[(j * 2 + 0) * 4 + k] = xs[j] * P[8 + k] - P[k];
+            A[(j * 2 + 1) * 4 + k] = ys[j] * P[8 + k] - P[4 + k];
+        }
+    }
+    for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) At[k * 4 + j] = A[j * 4 + k];
+    jacobi_svd_d(At, 1, 4, 4, W, Vt, 1, false);
+    // 4 x N CV_32F homogeneous result, then convertPointsFromHomogeneous in float
+    const float X = (float)Vt[12], Y = (float)Vt[13], Z = (float)Vt[14], Wh = (float)Vt[15];
+    const float scale = Wh != 0.f ? 1.f / Wh : 1.f;
+    a.out3[o * 3 + 0] = X * scale; a.out3[o * 3 + 1] = Y * scale; a.out3[o * 3 + 2] = Z * scale;
 }
+
+// ------------------------------------------------------------------------------------------
+struct PnpRecord {                 // device-side record of one solve
+    double rvec[3], tvec[3], R[9];
+    int n_inliers, ransac_iters, best_iter, lm_iters, ok, n;
+};
+
+struct PnpArgs {
+    const float *X3; const float2 *img; int64_t stride;     // points of item b at + b*stride
+    const int *n_pts; int n_fixed;
+    double fx, fy, cx, cy;
+    int iterations; float reproj_err; double confidence;
+    uint8_t *mask;                                          // stride bytes per item
+    PnpRecord *out;
+};
+
+__device__ inline double wave_allsum_f64(double v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
+    return v;
+}
+
+// One LM evaluation over the masked points: err norm^2, optionally J^T J (upper, 21) and J^T e (6).
+__device__ inline double lm_eval(const double param[6], const float *X3, const float2 *img,
+                                 const uint8_t *mask, int n, double fx, double fy, double cx, double cy,
+                                 int lane, double *JtJ, double *JtErr)
+{
+    double R[9], dRdr[27];
+    rodrigues_vec2mat_d(param, R, JtJ ? dRdr : nullptr);
+    const double *t = param + 3;
+    double acc[28];
+    const int nacc = JtJ ? 28 : 1;
+    for (int k = 0; k < nacc; k++) acc[k] = 0;
+    for (int i = lane; i < n; i += 64) {
+        if (!mask[i]) continue;
+        double X = X3[3 * i], Y = X3[3 * i + 1], Z = X3[3 * i + 2];
+        double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+        double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+        double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+        z = z ? 1. / z : 1;
+        x *= z; y *= z;
+        const float2 m = img[i];
+        double ex = (x * fx + cx) - (double)m.x, ey = (y * fy + cy) - (double)m.y;
+        acc[0] += ex * ex + ey * ey;
+        if (JtJ) {
+            double Jx[6], Jy[6];
+            double dxdt[3] = {z, 0, -x * z}, dydt[3] = {0, z, -y * z};
+            double dx0dr[3] = {X * dRdr[0] + Y * dRdr[1] + Z * dRdr[2], X * dRdr[9] + Y * dRdr[10] + Z * dRdr[11],
+                               X * dRdr[18] + Y * dRdr[19] + Z * dRdr[20]};
+            double dy0dr[3] = {X * dRdr[3] + Y * dRdr[4] + Z * dRdr[5], X * dRdr[12] + Y * dRdr[13] + Z * dRdr[14],
+                               X * dRdr[21] + Y * dRdr[22] + Z * dRdr[23]};
+            double dz0dr[3] = {X * dRdr[6] + Y * dRdr[7] + Z * dRdr[8], X * dRdr[15] + Y * dRdr[16] + Z * dRdr[17],
+                               X * dRdr[24] + Y * dRdr[25] + Z * dRdr[26]};
+            for (int j = 0; j < 3; j++) {
+                double dxdr = z * (dx0dr[j] - x * dz0dr[j]);
+                double dydr = z * (dy0dr[j] - y * dz0dr[j]);
+                Jx[j] = fx * dxdr; Jy[j] = fy * dydr;
+                Jx[3 + j] = fx * dxdt[j]; Jy[3 + j] = fy * dydt[j];
+            }
+            int q = 1;
+            for (int r = 0; r < 6; r++)
+                for (int c = r; c < 6; c++) acc[q++] += Jx[r] * Jx[c] + Jy[r] * Jy[c];
+            for (int r = 0; r < 6; r++) acc[q++] += Jx[r] * ex + Jy[r] * ey;
+        }
+    }
+    for (int k = 0; k < nacc; k++) acc[k] = wave_allsum_f64(acc[k]);
+    if (JtJ) {
+        int q = 1;
+        for (int r = 0; r < 6; r++)
+            for (int c = r; c < 6; c++) { JtJ[r * 6 + c] = acc[q]; JtJ[c * 6 + r] = acc[q]; q++; }
+        for (int r = 0; r < 6; r++) JtErr[r] = acc[q++];
+    }
+    return acc[0];
+}
+
+__global__ __launch_bounds__(64) void pnp_ransac_kernel(PnpArgs a)
+{
+    __shared__ double big[144 * 64];          // lane-interleaved 12x12 work matrices (73,728 B)
+    __shared__ double bestRt[12];
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
+    const float *X3 = a.X3 + (int64_t)b * a.stride * 3;
+    const float2 *img = a.img + (int64_t)b * a.stride;
+    uint8_t *mask = a.mask + (int64_t)b * a.stride;
+    PnpRecord *out = a.out + b;
+    const int model_points = 5;
+
+    if (n < model_points) {       // npoints == 4 would take OpenCV's P3P kernel: out of scope, no solution
+        if (lane == 0) {
+            for (int i = 0; i < 3; i++) { out->rvec[i] = 0; out->tvec[i] = 0; }
+            for (int i = 0; i < 9; i++) out->R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+            out->n_inliers = 0; out->ransac_iters = 0; out->best_iter = -1; out->lm_iters = 0; out->ok = 0; out->n = n;
+        }
+        for (int i = lane; i < n; i += 64) mask[i] = 0;
+        return;
+    }
+    const double fx = a.fx, fy = a.fy, cx = a.cx, cy = a.cy;
+    const float thr2 = (float)((double)a.reproj_err * (double)a.reproj_err);
+    int niters = a.iterations > 1 ? a.iterations : 1;
+    int max_good = 0, best_iter = -1, iters_done = 0;
+    uint64_t rng = ~0ull;
+
+    for (int base = 0; base < niters; base += 64) {
+        // ---- RANSACPointSetRegistrator::getSubset for hypotheses base .. base+63
+        int my[5] = {0, 1, 2, 3, 4};
+        if (n > model_points) {
+            for (int h = 0; h < 64; h++) {
+                int idx[5];
+                for (int i = 0; i < model_points;) {
+                    int j, idx_i;
+                    for (;;) {
+                        idx_i = idx[i] = (int)(rng_next_d(rng) % (unsigned)n);
+                        for (j = 0; j < i; j++) if (idx_i == idx[j]) break;
+                        if (j == i) break;
+                    }
+                    i++;
+                }
+                if (h == lane) { my[0] = idx[0]; my[1] = idx[1]; my[2] = idx[2]; my[3] = idx[3]; my[4] = idx[4]; }
+            }
+        }
+        // ---- PnPRansacCallback::runKernel: solvePnP(EPNP) on the 5 samples
+        Epnp5 e;
+        e.fu = fx; e.fv = fy; e.uc = cx; e.vc = cy;
+        for (int i = 0; i < model_points; i++) {
+            const int s = my[i];
+            e.pws[3 * i] = (double)X3[3 * s]; e.pws[3 * i + 1] = (double)X3[3 * s + 1]; e.pws[3 * i + 2] = (double)X3[3 * s + 2];
+            const float2 m = img[s];
+            // undistortPoints (float output, zero distortion), then epnp::init_points' x*fu + uc
+            const float xn = (float)(((double)m.x - cx) * (1. / fx));
+            const float yn = (float)(((double)m.y - cy) * (1. / fy));
+            e.us[2 * i] = (double)xn * fx + cx;
+            e.us[2 * i + 1] = (double)yn * fy + cy;
+        }
+        double R[9], t[3];
+        epnp5_d(e, big + lane, 64, R, t);
+        // ---- findInliers
+        int good = 0;
+        if (n > model_points) {
+            for (int i = 0; i < n; i++) {
+                const float2 m = img[i];
+                good += reproj_err2_d(R, t, fx, fy, cx, cy, X3[3 * i], X3[3 * i + 1], X3[3 * i + 2], m.x, m.y) <= thr2;
+            }
+        } else {
+            good = n;
+        }
+        // ---- replay the serial model-selection rule over this round's hypotheses
+        int owner = -1;
+        for (int h = 0; h < 64; h++) {
+            const int it = base + h;
+            if (it >= niters) break;
+            const int g = __builtin_amdgcn_readlane(good, h);
+            iters_done = it + 1;
+            if (n == model_points || g > (max_good > model_points - 1 ? max_good : model_points - 1)) {
+                max_good = g; best_iter = it; owner = h;
+                if (n == model_points) { niters = it + 1; break; }
+                niters = ransac_update_iters_d(a.confidence, (double)(n - g) / n, model_points, niters);
+            }
+        }
+        if (owner >= 0) {
+            wave_lds_fence();
+            if (lane == owner) {
+                for (int i = 0; i < 9; i++) bestRt[i] = R[i];
+                for (int i = 0; i < 3; i++) bestRt[9 + i] = t[i];
+            }
+            wave_lds_fence();
+        }
+    }
+
+    if (max_good <= 0) {
+        // solvePnPRansac returns false: rvec/tvec stay at the caller's zeros, no inliers
+        if (lane == 0) {
+            for (int i = 0; i < 3; i++) { out->rvec[i] = 0; out->tvec[i] = 0; }
+            for (int i = 0; i < 9; i++) out->R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+            out->n_inliers = 0; out->ransac_iters = iters_done; out->best_iter = -1; out->lm_iters = 0; out->ok = 0; out->n = n;
+        }
+        for (int i = lane; i < n; i += 64) mask[i] = 0;
+        return;
+    }
+    double bR[9], bt[3];
+    for (int i = 0; i < 9; i++) bR[i] = bestRt[i];
+    for (int i = 0; i < 3; i++) bt[i] = bestRt[9 + i];
+    for (int i = lane; i < n; i += 64) {
+        const float2 m = img[i];
+        mask[i] = (n == model_points) ? 1
+                  : (uint8_t)(reproj_err2_d(bR, bt, fx, fy, cx, cy, X3[3 * i], X3[3 * i + 1], X3[3 * i + 2], m.x, m.y) <= thr2);
+    }
+    __threadfence_block();
+    wave_lds_fence();
+
+    // ---- refit on the inliers: solvePnP(ITERATIVE, useExtrinsicGuess) == CvLevMarq on 6 params
+    double param[6], prevParam[6], JtJ[36], JtErr[6];
+    rodrigues_mat2vec_d(bR, param);
+    param[3] = bt[0]; param[4] = bt[1]; param[5] = bt[2];
+    const double POW10[33] = {1e-16, 1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6,
+                              1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8,
+                              1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16};
+    const int max_iter = 20;
+    const double epsilon = 1.1920928955078125e-07;    // FLT_EPSILON
+    double prevErrNorm = 1.7976931348623157e308, errNorm;
+    int lambdaLg10 = -3, iters = 0;
+    for (;;) {
+        double e2 = lm_eval(param, X3, img, mask, n, fx, fy, cx, cy, lane, JtJ, JtErr);
+        for (int i = 0; i < 6; i++) prevParam[i] = param[i];
+        if (iters == 0) prevErrNorm = sqrt(e2);
+        bool done = false;
+        for (;;) {
+            double A[36], x[6];
+            const double lambda = POW10[lambdaLg10 + 16];
+            for (int i = 0; i < 36; i++) A[i] = JtJ[i];
+            for (int i = 0; i < 6; i++) A[i * 6 + i] *= 1. + lambda;
+            svd_solve_d(A, 6, 6, JtErr, x);
+            for (int i = 0; i < 6; i++) param[i] = prevParam[i] - x[i];
+            errNorm = sqrt(lm_eval(param, X3, img, mask, n, fx, fy, cx, cy, lane, nullptr, nullptr));
+            if (errNorm > prevErrNorm) {
+                if (++lambdaLg10 <= 16) continue;
+            }
+            lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
+            double dn = 0, pn = 0;
+            for (int i = 0; i < 6; i++) {
+                dn += (param[i] - prevParam[i]) * (param[i] - prevParam[i]);
+                pn += prevParam[i] * prevParam[i];
+            }
+            if (++iters >= max_iter || sqrt(dn) / sqrt(pn) < epsilon) done = true;
+            prevErrNorm = errNorm;
+            break;
+        }
+        if (done) break;
+    }
+    if (lane == 0) {
+        double Rf[9];
+        rodrigues_vec2mat_d(param, Rf, nullptr);
+        for (int i = 0; i < 3; i++) { out->rvec[i] = param[i]; out->tvec[i] = param[3 + i]; }
+        for (int i = 0; i < 9; i++) out->R[i] = Rf[i];
+        out->n_inliers = max_good; out->ransac_iters = iters_done; out->best_iter = best_iter;
+        out->lm_iters = iters; out->ok = 1; out->n = n;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+struct FinalizeArgs {
+    const PnpRecord *pnp; const int *n_prev, *n_cur, *n_tracked;   // per pair
+    int n_pairs;
+    int num_features_tracking; double inlier_rate, min_move2, max_move2;
+    svo_step_result *res;
+};
+
+__global__ void finalize_kernel(FinalizeArgs a)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_pairs) return;
+    svo_step_result r;
+    const PnpRecord &q = a.pnp[p];
+    r.n_prev_kps = a.n_prev[p]; r.n_cur_kps = a.n_cur[p];
+    r.n_tracked = 0; r.n_inliers = 0; r.ransac_iters = 0; r.lm_iters = 0;
+    for (int i = 0; i < 3; i++) { r.rvec[i] = 0; r.tvec[i] = 0; }
+    for (int i = 0; i < 9; i++) r.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 16; i++) { r.T_rel_inv[i] = (i % 5 == 0) ? 1.0 : 0.0; r.pose[i] = 0; }
+    int fail = 0;
+    if (r.n_cur_kps < 30) fail = SVO_FAIL_FEW_KEYPOINTS;                     // src/tracking.cpp:261
+    else {
+        const int m = a.n_tracked[p];
+        r.n_tracked = m;
+        if (m < a.num_features_tracking) fail = SVO_FAIL_FEW_TRACKS;         // :274
+        else {
+            r.n_inliers = q.n_inliers; r.ransac_iters = q.ransac_iters; r.lm_iters = q.lm_iters;
+            for (int i = 0; i < 3; i++) { r.rvec[i] = q.rvec[i]; r.tvec[i] = q.tvec[i]; }
+            for (int i = 0; i < 9; i++) r.R[i] = q.R[i];
+            if ((double)q.n_inliers / (double)m < a.inlier_rate) fail = SVO_FAIL_INLIER_RATIO;   // :491
+            else {
+                // rotationMatrixToEulerAngles (:440-463): floats holding double expressions
+                const double *R = q.R;
+                const float sy = (float)sqrt(R[0] * R[0] + R[3] * R[3]);
+                const bool singular = (double)sy < 1e-6;
+                float ex, ey, ez;
+                if (!singular) {
+                    ex = (float)atan2(R[7], R[8]); ey = (float)atan2(-R[6], (double)sy); ez = (float)atan2(R[3], R[0]);
+                } else {
+                    ex = (float)atan2(-R[5], R[4]); ey = (float)atan2(-R[6], (double)sy); ez = 0.f;
+                }
+                if (!((double)fabsf(ey) < 0.1 && (double)fabsf(ex) < 0.1 && (double)fabsf(ez) < 0.1))
+                    fail = SVO_FAIL_ROTATION_GATE;                           // :308
+                else {
+                    const double *t = q.tvec;
+                    const double n2 = t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
+                    if (!(n2 < a.max_move2 && n2 > a.min_move2)) fail = SVO_FAIL_TRANSL_GATE;   // :311
+                    else {
+                        double *Ti = r.T_rel_inv;      // inv([R t; 0 1]) in closed form
+                        Ti[0] = R[0]; Ti[1] = R[3]; Ti[2] = R[6];
+                        Ti[4] = R[1]; Ti[5] = R[4]; Ti[6] = R[7];
+                        Ti[8] = R[2]; Ti[9] = R[5]; Ti[10] = R[8];
+                        Ti[3] = -(R[0] * t[0] + R[3] * t[1] + R[6] * t[2]);
+                        Ti[7] = -(R[1] * t[0] + R[4] * t[1] + R[7] * t[2]);
+                        Ti[11] = -(R[2] * t[0] + R[5] * t[1] + R[8] * t[2]);
+                        Ti[12] = 0; Ti[13] = 0; Ti[14] = 0; Ti[15] = 1;
+                    }
+                }
+            }
+        }
+    }
+    r.fail_stage = fail;
+    r.ok = fail == 0;
+    a.res[p] = r;
+}
+
+// frame_pose_ = frame_pose_ * T^-1 over consecutive pairs; failed steps are skipped (:59-68)
+__global__ void chain_kernel(svo_step_result *res, int n_pairs, const double *pose0)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double P[16];
+    for (int i = 0; i < 16; i++) P[i] = pose0[i];
+    for (int p = 0; p < n_pairs; p++) {
+        if (res[p].ok) {
+            double Q[16];
+            const double *T = res[p].T_rel_inv;
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 4; j++) {
+                    double s = 0;
+                    for (int k = 0; k < 4; k++) s += P[i * 4 + k] * T[k * 4 + j];
+                    Q[i * 4 + j] = s;
+                }
+            for (int i = 0; i < 16; i++) P[i] = Q[i];
+        }
+        for (int i = 0; i < 16; i++) res[p].pose[i] = P[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace layout inside ctx->pnp_ws: [PnpRecord x items][mask bytes x items*cap][pose0 16 doubles]
+static size_t ws_off_mask(int n_items) { return ((sizeof(PnpRecord) * (size_t)n_items) + 255) / 256 * 256; }
+static size_t ws_off_pose0(const svo_config &cfg, int n_items)
+{
+    return (ws_off_mask(n_items) + (size_t)n_items * cfg.max_keypoints + 255) / 256 * 256;
+}
+
+int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
+{
+    *bytes = ws_off_pose0(cfg, n_items) + 256;
+    return SVO_OK;
+}
+
+void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const float2 *x1, const float2 *x2,
+                              const int *n_pts, int n_fixed)
+{
+    TriArgs a{};
+    memcpy(a.P1, ctx->cfg.P1, sizeof(a.P1));
+    memcpy(a.P2, ctx->cfg.P2, sizeof(a.P2));
+    a.x1 = x1; a.x2 = x2; a.out3 = ctx->X3; a.stride = ctx->cfg.max_keypoints;
+    a.n_pts = n_pts; a.n_fixed = n_fixed;
+    if (max_pts <= 0) return;
+    hipLaunchKernelGGL(triangulate_kernel, dim3((max_pts + 63) / 64, n_items), dim3(64), 0, ctx->stream, a);
+}
+
+void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n_pts, int n_fixed)
+{
+    PnpArgs a{};
+    a.X3 = ctx->X3; a.img = img; a.stride = ctx->cfg.max_keypoints;
+    a.n_pts = n_pts; a.n_fixed = n_fixed;
+    // K = P1[:, :3] (src/tracking.cpp:476-477)
+    a.fx = ctx->cfg.P1[0]; a.fy = ctx->cfg.P1[5]; a.cx = ctx->cfg.P1[2]; a.cy = ctx->cfg.P1[6];
+    a.iterations = ctx->cfg.iterations; a.reproj_err = ctx->cfg.reproj_err;
+    a.confidence = (double)ctx->cfg.confidence;
+    a.mask = (uint8_t *)ctx->pnp_ws + ws_off_mask(ctx->cfg.max_batch);
+    a.out = (PnpRecord *)ctx->pnp_ws;
+    hipLaunchKernelGGL(pnp_ransac_kernel, dim3(n_items), dim3(64), 0, ctx->stream, a);
+}
+
+void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur, const double *pose0_host)
+{
+    FinalizeArgs f{};
+    f.pnp = (const PnpRecord *)ctx->pnp_ws; f.n_prev = n_prev; f.n_cur = n_cur; f.n_tracked = ctx->m_out;
+    f.n_pairs = n_pairs; f.num_features_tracking = ctx->cfg.num_features_tracking;
+    f.inlier_rate = ctx->cfg.inlier_rate; f.min_move2 = ctx->cfg.min_move2; f.max_move2 = ctx->cfg.max_move2;
+    f.res = ctx->d_results;
+    hipLaunchKernelGGL(finalize_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, f);
+    double *d_pose0 = (double *)((char *)ctx->pnp_ws + ws_off_pose0(ctx->cfg, ctx->cfg.max_batch));
+    // pose0 goes through the pinned scratch so the async copy is valid
+    double *h = (double *)((char *)ctx->h_pinned + 128);
+    for (int i = 0; i < 16; i++) h[i] = pose0_host ? pose0_host[i] : ((i % 5 == 0) ? 1.0 : 0.0);
+    (void)hipMemcpyAsync(d_pose0, h, sizeof(double) * 16, hipMemcpyHostToDevice, ctx->stream);
+    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_results, n_pairs, d_pose0);
+}
+
+// ---- stage API ------------------------------------------------------------------------------
+int stage_triangulate(svo_ctx *ctx, const double P1[12], const double P2[12], const svo_pt2f *x1,
+                      const svo_pt2f *x2, int n, svo_pt3f *out, int mem)
+{
+    SVO_ARG(P1 && P2, "null projection matrix");
+    SVO_ARG(n >= 0 && n <= ctx->cfg.max_keypoints, "n exceeds max_keypoints");
+    SVO_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE, "bad mem");
+    if (n == 0) return SVO_OK;
+    SVO_ARG(x1 && x2 && out, "null pointer");
+    SVO_HIP(hipSetDevice(ctx->device));
+    TriArgs a{};
+    memcpy(a.P1, P1, sizeof(a.P1));
+    memcpy(a.P2, P2, sizeof(a.P2));
+    a.stride = 0; a.n_pts = nullptr; a.n_fixed = n;
+    if (mem == SVO_MEM_HOST) {
+        SVO_HIP(hipMemcpyAsync(ctx->cmp[0], x1, sizeof(float2) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        SVO_HIP(hipMemcpyAsync(ctx->cmp[1], x2, sizeof(float2) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        a.x1 = ctx->cmp[0]; a.x2 = ctx->cmp[1]; a.out3 = ctx->X3;
+    } else {
+        a.x1 = (const float2 *)x1; a.x2 = (const float2 *)x2; a.out3 = (float *)out;
+    }
+    hipLaunchKernelGGL(triangulate_kernel, dim3((n + 63) / 64, 1), dim3(64), 0, ctx->stream, a);
+    SVO_HIP(hipGetLastError());
+    if (mem == SVO_MEM_HOST) {
+        SVO_HIP(hipMemcpyAsync(out, ctx->X3, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        SVO_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return SVO_OK;
+}
+
+int stage_pnp_ransac(svo_ctx *ctx, const svo_pt3f *obj, const svo_pt2f *img, int n, const double K[9],
+                     int iterations, float reproj_err, double confidence, svo_pnp_result *res,
+                     uint8_t *inlier_mask, int mem)
+{
+    SVO_ARG(K && res, "null pointer");
+    SVO_ARG(n >= 0 && n <= ctx->cfg.max_keypoints, "n exceeds max_keypoints");
+    SVO_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE, "bad mem");
+    SVO_ARG(n == 0 || (obj && img), "null pointer");
+    SVO_HIP(hipSetDevice(ctx->device));
+    PnpArgs a{};
+    a.stride = 0; a.n_pts = nullptr; a.n_fixed = n;
+    a.fx = K[0]; a.fy = K[4]; a.cx = K[2]; a.cy = K[5];
+    a.iterations = iterations; a.reproj_err = reproj_err; a.confidence = confidence;
+    uint8_t *ws_mask = (uint8_t *)ctx->pnp_ws + ws_off_mask(ctx->cfg.max_batch);
+    a.out = (PnpRecord *)ctx->pnp_ws;
+    if (mem == SVO_MEM_HOST) {
+        if (n > 0) {
+            SVO_HIP(hipMemcpyAsync(ctx->X3, obj, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+            SVO_HIP(hipMemcpyAsync(ctx->cmp[3], img, sizeof(float2) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        }
+        a.X3 = ctx->X3; a.img = ctx->cmp[3]; a.mask = ws_mask;
+    } else {
+        a.X3 = (const float *)obj; a.img = (const float2 *)img; a.mask = inlier_mask ? inlier_mask : ws_mask;
+    }
+    hipLaunchKernelGGL(pnp_ransac_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
+    SVO_HIP(hipGetLastError());
+    PnpRecord *h = (PnpRecord *)((char *)ctx->h_pinned + 256);
+    SVO_HIP(hipMemcpyAsync(h, ctx->pnp_ws, sizeof(PnpRecord), hipMemcpyDeviceToHost, ctx->stream));
+    if (mem == SVO_MEM_HOST && inlier_mask && n > 0)
+        SVO_HIP(hipMemcpyAsync(inlier_mask, ws_mask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(res->rvec, h->rvec, sizeof(res->rvec));
+    memcpy(res->tvec, h->tvec, sizeof(res->tvec));
+    memcpy(res->R, h->R, sizeof(res->R));
+    res->n_inliers = h->n_inliers; res->ransac_iters = h->ransac_iters; res->best_iter = h->best_iter;
+    res->lm_iters = h->lm_iters; res->ok = h->ok; res->_pad = 0;
+    return SVO_OK;
+}
+
+}  // namespace svo

@@ -1,0 +1,197 @@
+// pipeline.hip -- the fused LK-mode frame step (Tracking::AddFrame -> LK_StereoF2F_PnP_Track,
+// reference src/tracking.cpp:49-77, 258-344) as a fixed sequence of batched launches:
+//
+//   pyramids (L,R of every new frame) -> FAST on every left image -> circular LK chain per point
+//   -> stable compaction -> triangulation -> RANSAC-EPnP + LM -> gates -> pose chain
+//
+// Every consecutive frame pair is independent, so a batch of F frames is
+// F-1 pairs processed by ONE launch of each kernel (grid.y / grid.x = pair), with frame f's
+// pyramids at bslots[2f], bslots[2f+1] and its keypoints at kp[f]; only the 4x4 pose product is
+// sequential.  The online entry point (svo_add_frame) runs the same kernels with one pair on a
+// two-frame ring.
+#include <cstring>
+#include "svo_ctx.h"
+
+namespace svo {
+
+static void mark(svo_ctx *ctx, const char *name)
+{
+    if (!ctx->timing) return;
+    hipEvent_t ev = nullptr;
+    for (auto &m : ctx->marks)
+        if (m.first == name) { ev = m.second; break; }
+    if (!ev) {
+        if (hipEventCreate(&ev) != hipSuccess) return;
+        ctx->marks.emplace_back(name, ev);
+    }
+    (void)hipEventRecord(ev, ctx->stream);
+}
+
+static void collect_times(svo_ctx *ctx, const std::vector<const char *> &order)
+{
+    ctx->last_times.clear();
+    if (!ctx->timing) return;
+    hipEvent_t prev = nullptr;
+    for (const char *nm : order) {
+        hipEvent_t ev = nullptr;
+        for (auto &m : ctx->marks) if (m.first == nm) ev = m.second;
+        if (!ev) continue;
+        if (prev) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, prev, ev) == hipSuccess) ctx->last_times.emplace_back(nm, ms);
+        }
+        prev = ev;
+    }
+}
+
+static const char *kT0 = "start", *kTPyr = "pyramid", *kTFast = "fast", *kTLk = "lk", *kTCompact = "compact",
+                  *kTTri = "triangulate", *kTPnp = "pnp", *kTFin = "finalize";
+
+// Builds pyramids of `n_new` frames into frame slots [f0, f0+n_new) and runs FAST on their left
+// images.  L/R: device pointers to the first new frame.
+static int ingest_frames(svo_ctx *ctx, const uint8_t *L, const uint8_t *R, int pitch, int64_t frame_stride,
+                         int f0, int n_new)
+{
+    const PyrGeom &g = ctx->geom;
+    PyrArgs p{};
+    p.g = g; p.pitch = pitch; p.img_stride = frame_stride; p.slot_stride = 2 * g.slot_bytes;
+    p.img = L; p.slots = ctx->bslots + (size_t)(2 * f0) * g.slot_bytes;
+    launch_pyramid(p, n_new, ctx->stream);
+    p.img = R; p.slots = ctx->bslots + (size_t)(2 * f0 + 1) * g.slot_bytes;
+    launch_pyramid(p, n_new, ctx->stream);
+    mark(ctx, kTPyr);
+    FastArgs a{};
+    a.img = L; a.pitch = pitch; a.img_stride = frame_stride;
+    a.w = ctx->cfg.width; a.h = ctx->cfg.height; a.thr = ctx->cfg.fast_threshold; a.nms = 1;
+    a.score = ctx->score + (size_t)f0 * ctx->score_stride; a.spitch = ctx->spitch; a.score_stride = ctx->score_stride;
+    a.rowcount = ctx->rowcount + (size_t)f0 * ctx->rowcount_stride; a.rowcount_stride = ctx->rowcount_stride;
+    a.kp_xy = ctx->kp_xy + (size_t)f0 * ctx->cfg.max_keypoints;
+    a.kp_resp = ctx->kp_resp + (size_t)f0 * ctx->cfg.max_keypoints;
+    a.kp_stride = ctx->cfg.max_keypoints;
+    a.n_out = ctx->kp_n + f0; a.cap = ctx->cfg.max_keypoints;
+    launch_fast(a, n_new, ctx->stream);
+    mark(ctx, kTFast);
+    return SVO_OK;
+}
+
+// Tracks `n_pairs` pairs; pair p = (frame slot fp0 + p*fstep, frame slot fc0 + p*fstep).
+static int run_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, const double *pose0_host)
+{
+    const PyrGeom &g = ctx->geom;
+    const int cap = ctx->cfg.max_keypoints;
+    auto S = [&](int slot) { return ctx->bslots + (size_t)slot * g.slot_bytes; };
+    LkArgs a{};
+    a.g = g; a.ncalls = 4;
+    a.slot_stride = (int64_t)fstep * 2 * g.slot_bytes;
+    // L1 -> R1 -> R2 -> L2 -> L1'  (src/tracking.cpp:593-618)
+    a.prev[0] = S(2 * fp0);     a.next[0] = S(2 * fp0 + 1);
+    a.prev[1] = S(2 * fp0 + 1); a.next[1] = S(2 * fc0 + 1);
+    a.prev[2] = S(2 * fc0 + 1); a.next[2] = S(2 * fc0);
+    a.prev[3] = S(2 * fc0);     a.next[3] = S(2 * fp0);
+    // matched_t1_left = the previous frame's FAST keypoints (:268-271), read in place
+    a.pts_in = ctx->kp_xy + (size_t)fp0 * cap; a.pts_stride = (int64_t)fstep * cap;
+    a.n_pts = ctx->kp_n + fp0;
+    // NOTE: n_pts is indexed by batch item b, so fstep must be 1 when n_pairs > 1
+    a.n_fixed = 0; a.cap = cap;
+    for (int i = 0; i < 4; i++) { a.pts_out[i] = ctx->pts_out[i]; a.status[i] = ctx->status[i]; }
+    a.keep = ctx->keep;
+    a.match_err = ctx->cfg.feature_match_error; a.match_err_f = (float)ctx->cfg.feature_match_error;
+    // LK writes its outputs with the INPUT stride (pts_stride); keep outputs dense per item:
+    // outputs are addressed with the same po = b*pts_stride + idx, so give them the same stride
+    launch_lk(a, n_pairs, cap, ctx->stream);
+    mark(ctx, kTLk);
+    CompactArgs c{};
+    c.keep = ctx->keep; c.n_pts = ctx->kp_n + fp0; c.n_fixed = 0; c.pts_stride = (int64_t)fstep * cap; c.cap = cap;
+    c.in[0] = a.pts_in; c.in[1] = ctx->pts_out[0]; c.in[2] = ctx->pts_out[1]; c.in[3] = ctx->pts_out[2];
+    for (int i = 0; i < 4; i++) c.out[i] = ctx->cmp[i];
+    c.m_out = ctx->m_out;
+    launch_compact(c, n_pairs, ctx->stream);
+    mark(ctx, kTCompact);
+    // triangulatePoints(P1, P2, t1_left, t1_right) (:292-294); solvePnPRansac(X, t2_left) (:299)
+    launch_triangulate_batch(ctx, n_pairs, cap, ctx->cmp[0], ctx->cmp[1], ctx->m_out, 0);
+    mark(ctx, kTTri);
+    launch_pnp_batch(ctx, n_pairs, ctx->cmp[3], ctx->m_out, 0);
+    mark(ctx, kTPnp);
+    launch_finalize_chain(ctx, n_pairs, ctx->kp_n + fp0, ctx->kp_n + fc0, pose0_host);
+    mark(ctx, kTFin);
+    return SVO_OK;
+}
+
+int pipeline_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t *right_frames, int pitch,
+                         int64_t frame_stride, int n_frames, const double *pose0,
+                         svo_step_result *results, int results_mem)
+{
+    SVO_ARG(left_frames && right_frames && results, "null pointer");
+    SVO_ARG(n_frames >= 2 && n_frames - 1 <= ctx->cfg.max_batch, "n_frames - 1 must be in [1, max_batch]");
+    SVO_ARG(pitch >= ctx->cfg.width && frame_stride >= (int64_t)pitch * ctx->cfg.height, "bad pitch / frame_stride");
+    SVO_ARG(results_mem == SVO_MEM_HOST || results_mem == SVO_MEM_DEVICE, "bad results_mem");
+    SVO_HIP(hipSetDevice(ctx->device));
+    const int n_pairs = n_frames - 1;
+    mark(ctx, kT0);
+    int rc = ingest_frames(ctx, left_frames, right_frames, pitch, frame_stride, 0, n_frames);
+    if (rc) return rc;
+    // the LK outputs use the keypoint stride (cap) per item: frame slots are consecutive (fstep 1)
+    rc = run_pairs(ctx, n_pairs, 0, 1, 1, pose0);
+    if (rc) return rc;
+    SVO_HIP(hipGetLastError());
+    if (results_mem == SVO_MEM_DEVICE) {
+        SVO_HIP(hipMemcpyAsync(results, ctx->d_results, sizeof(svo_step_result) * (size_t)n_pairs,
+                               hipMemcpyDeviceToDevice, ctx->stream));
+        if (ctx->timing) { SVO_HIP(hipStreamSynchronize(ctx->stream)); collect_times(ctx, {kT0, kTPyr, kTFast, kTLk, kTCompact, kTTri, kTPnp, kTFin}); }
+        return SVO_OK;
+    }
+    svo_step_result *h = (svo_step_result *)((char *)ctx->h_pinned + 4096);
+    SVO_HIP(hipMemcpyAsync(h, ctx->d_results, sizeof(svo_step_result) * (size_t)n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(results, h, sizeof(svo_step_result) * (size_t)n_pairs);
+    collect_times(ctx, {kT0, kTPyr, kTFast, kTLk, kTCompact, kTTri, kTPnp, kTFin});
+    return SVO_OK;
+}
+
+int pipeline_add_frame(svo_ctx *ctx, const uint8_t *left, const uint8_t *right, int pitch, int mem,
+                       svo_step_result *res)
+{
+    SVO_ARG(left && right && res, "null pointer");
+    SVO_ARG(pitch >= ctx->cfg.width, "pitch < width");
+    SVO_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE, "bad mem");
+    SVO_HIP(hipSetDevice(ctx->device));
+    const uint8_t *dL = left, *dR = right;
+    int dp = pitch;
+    if (mem == SVO_MEM_HOST) {
+        uint8_t *sL = ctx->stage_img, *sR = ctx->stage_img + (size_t)ctx->stage_pitch * ctx->cfg.height;
+        SVO_HIP(hipMemcpy2DAsync(sL, ctx->stage_pitch, left, pitch, ctx->cfg.width, ctx->cfg.height, hipMemcpyHostToDevice, ctx->stream));
+        SVO_HIP(hipMemcpy2DAsync(sR, ctx->stage_pitch, right, pitch, ctx->cfg.width, ctx->cfg.height, hipMemcpyHostToDevice, ctx->stream));
+        dL = sL; dR = sR; dp = ctx->stage_pitch;
+    }
+    // two-frame ring in frame slots 0 / 1
+    const int cur = ctx->online_frames == 0 ? 0 : (ctx->online_cur ^ 1);
+    const int prev = cur ^ 1;
+    mark(ctx, kT0);
+    int rc = ingest_frames(ctx, dL, dR, dp, 0, cur, 1);
+    if (rc) return rc;
+    memset(res, 0, sizeof(*res));
+    if (ctx->online_frames == 0) {
+        // StereoInit_f2f (:78-92): detect only
+        int *h_n = (int *)ctx->h_pinned;
+        SVO_HIP(hipMemcpyAsync(h_n, ctx->kp_n + cur, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SVO_HIP(hipStreamSynchronize(ctx->stream));
+        res->ok = 1; res->n_cur_kps = *h_n;
+        for (int i = 0; i < 9; i++) res->R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        for (int i = 0; i < 16; i++) { res->T_rel_inv[i] = (i % 5 == 0) ? 1.0 : 0.0; res->pose[i] = ctx->pose[i]; }
+        ctx->online_frames = 1; ctx->online_cur = cur;
+        return SVO_OK;
+    }
+    rc = run_pairs(ctx, 1, prev, cur, 0, ctx->pose);
+    if (rc) return rc;
+    SVO_HIP(hipGetLastError());
+    svo_step_result *h = (svo_step_result *)((char *)ctx->h_pinned + 4096);
+    SVO_HIP(hipMemcpyAsync(h, ctx->d_results, sizeof(svo_step_result), hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    *res = *h;
+    collect_times(ctx, {kT0, kTPyr, kTFast, kTLk, kTCompact, kTTri, kTPnp, kTFin});
+    memcpy(ctx->pose, res->pose, sizeof(ctx->pose));
+    ctx->online_frames++; ctx->online_cur = cur;       // last_frame_ = current_frame_ on both outcomes (:59-68)
+    return res->ok ? SVO_OK : res->fail_stage;
+}
+
+}  // namespace svo

@@ -61,3 +61,13 @@ struct svo_ctx {
     do {                                                                                      \
         if (!(cond)) { ctx->err = std::string("bad argument: ") + msg; return SVO_ERR_ARG; }   \
     } while (0)
+
+namespace svo {
+// geometry.hip
+int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes);
+void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const float2 *x1, const float2 *x2,
+                              const int *n_pts, int n_fixed);
+void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n_pts, int n_fixed);
+void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur,
+                           const double *pose0_host);
+}  // namespace svo
