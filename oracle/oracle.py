@@ -38,7 +38,8 @@ class TrackParams(C.Structure):
     _fields_ = [("P1", C.c_double * 12), ("P2", C.c_double * 12),
                 ("feature_match_error", C.c_double), ("num_features_tracking", C.c_int),
                 ("inlier_rate", C.c_double), ("iterations", C.c_int), ("reproj_err", C.c_float),
-                ("confidence", C.c_float), ("fast_thr", C.c_int)]
+                ("confidence", C.c_float), ("fast_thr", C.c_int),
+                ("min_t2", C.c_double), ("max_t2", C.c_double)]
 
 
 def build(force=False):
@@ -221,7 +222,8 @@ def gate_and_accumulate(R, t, pose, min_t2=0.0005 ** 2, max_t2=100.0):
 
 
 def make_params(P1, P2, feature_match_error=3.0, num_features_tracking=5, inlier_rate=0.01,
-                iterations=500, reproj_err=0.5, confidence=0.99, fast_thr=20):
+                iterations=500, reproj_err=0.5, confidence=0.99, fast_thr=20,
+                min_t2=0.0005 * 0.0005, max_t2=100.0):
     p = TrackParams()
     for i, v in enumerate(np.asarray(P1, np.float64).reshape(12)):
         p.P1[i] = v
@@ -234,6 +236,8 @@ def make_params(P1, P2, feature_match_error=3.0, num_features_tracking=5, inlier
     p.reproj_err = reproj_err
     p.confidence = confidence
     p.fast_thr = fast_thr
+    p.min_t2 = min_t2
+    p.max_t2 = max_t2
     return p
 
 

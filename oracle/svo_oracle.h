@@ -132,6 +132,7 @@ typedef struct {
     float  reproj_err;
     float  confidence;
     int    fast_thr;
+    double min_t2, max_t2;   /* squared translation gate; LK mode hard-codes 0.0005^2, 100 (:311) */
 } orc_track_params;
 
 /* threads: OpenMP threads for the LK point loop (1 = scalar port). */

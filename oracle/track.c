@@ -80,8 +80,8 @@ int orc_lk_track_step(const orc_track_params *prm, const uint8_t *prevL, const u
     if ((double)pr.n_inliers / (double)m < prm->inlier_rate) { res->fail_stage = 3; goto done; }
 
     /* (6,7) Euler + translation gates, frame_pose_ *= T^-1 (:305-329); LK mode hard-codes the
-     * translation window 0.0005^2 < |t|^2 < 100 (:311) */
-    int g = orc_gate_and_accumulate(pr.R, pr.tvec, 0.0005 * 0.0005, 100.0, pose, res->T_rel_inv);
+     * translation window 0.0005^2 < |t|^2 < 100 (:311); the caller passes it in prm */
+    int g = orc_gate_and_accumulate(pr.R, pr.tvec, prm->min_t2, prm->max_t2, pose, res->T_rel_inv);
     if (g < 0) { res->fail_stage = -g; goto done; }
     ok = 1;
 done:

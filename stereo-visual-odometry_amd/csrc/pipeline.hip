@@ -17,31 +17,15 @@ namespace svo {
 static void mark(svo_ctx *ctx, const char *name)
 {
     if (!ctx->timing) return;
-    hipEvent_t ev = nullptr;
-    for (auto &m : ctx->marks)
-        if (m.first == name) { ev = m.second; break; }
-    if (!ev) {
-        if (hipEventCreate(&ev) != hipSuccess) return;
-        ctx->marks.emplace_back(name, ev);
-    }
-    (void)hipEventRecord(ev, ctx->stream);
-}
-
-static void collect_times(svo_ctx *ctx, const std::vector<const char *> &order)
-{
-    ctx->last_times.clear();
-    if (!ctx->timing) return;
-    hipEvent_t prev = nullptr;
-    for (const char *nm : order) {
+    if (ctx->ev_used >= 16384) return;                 // bounded log
+    if (ctx->ev_used == ctx->ev_pool.size()) {
         hipEvent_t ev = nullptr;
-        for (auto &m : ctx->marks) if (m.first == nm) ev = m.second;
-        if (!ev) continue;
-        if (prev) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, prev, ev) == hipSuccess) ctx->last_times.emplace_back(nm, ms);
-        }
-        prev = ev;
+        if (hipEventCreate(&ev) != hipSuccess) return;
+        ctx->ev_pool.push_back(ev);
     }
+    hipEvent_t ev = ctx->ev_pool[ctx->ev_used++];
+    (void)hipEventRecord(ev, ctx->stream);
+    ctx->marks.emplace_back(name, ev);
 }
 
 static const char *kT0 = "start", *kTPyr = "pyramid", *kTFast = "fast", *kTLk = "lk", *kTCompact = "compact",
@@ -137,14 +121,12 @@ int pipeline_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t
     if (results_mem == SVO_MEM_DEVICE) {
         SVO_HIP(hipMemcpyAsync(results, ctx->d_results, sizeof(svo_step_result) * (size_t)n_pairs,
                                hipMemcpyDeviceToDevice, ctx->stream));
-        if (ctx->timing) { SVO_HIP(hipStreamSynchronize(ctx->stream)); collect_times(ctx, {kT0, kTPyr, kTFast, kTLk, kTCompact, kTTri, kTPnp, kTFin}); }
         return SVO_OK;
     }
     svo_step_result *h = (svo_step_result *)((char *)ctx->h_pinned + 4096);
     SVO_HIP(hipMemcpyAsync(h, ctx->d_results, sizeof(svo_step_result) * (size_t)n_pairs, hipMemcpyDeviceToHost, ctx->stream));
     SVO_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(results, h, sizeof(svo_step_result) * (size_t)n_pairs);
-    collect_times(ctx, {kT0, kTPyr, kTFast, kTLk, kTCompact, kTTri, kTPnp, kTFin});
     return SVO_OK;
 }
 
@@ -188,7 +170,6 @@ int pipeline_add_frame(svo_ctx *ctx, const uint8_t *left, const uint8_t *right, 
     SVO_HIP(hipMemcpyAsync(h, ctx->d_results, sizeof(svo_step_result), hipMemcpyDeviceToHost, ctx->stream));
     SVO_HIP(hipStreamSynchronize(ctx->stream));
     *res = *h;
-    collect_times(ctx, {kT0, kTPyr, kTFast, kTLk, kTCompact, kTTri, kTPnp, kTFin});
     memcpy(ctx->pose, res->pose, sizeof(ctx->pose));
     ctx->online_frames++; ctx->online_cur = cur;       // last_frame_ = current_frame_ on both outcomes (:59-68)
     return res->ok ? SVO_OK : res->fail_stage;

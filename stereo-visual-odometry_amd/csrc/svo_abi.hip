@@ -82,7 +82,7 @@ static void free_all(svo_ctx *c)
     for (int i = 0; i < 4; i++) { F(c->pts_out[i]); F(c->status[i]); F(c->cmp[i]); }
     F(c->keep); F(c->m_out); F(c->X3); F(c->pnp_ws); F(c->d_results); F(c->bslots);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-    for (auto &m : c->marks) (void)hipEventDestroy(m.second);
+    for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
 }
 
@@ -184,9 +184,28 @@ extern "C" int svo_enable_timing(svo_ctx *ctx, int on)
     return SVO_OK;
 }
 
+// Resolves the stage marks logged since the last query: synchronises the stream, averages the
+// elapsed time of each stage over the logged steps ("start" opens a step), clears the log.
 extern "C" int svo_get_timing(svo_ctx *ctx, const char **names, float *ms, int cap)
 {
     if (!ctx) return SVO_ERR_ARG;
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<std::pair<const char *, double>> acc;
+    std::vector<int> cnt;
+    for (size_t i = 1; i < ctx->marks.size(); i++) {
+        const char *nm = ctx->marks[i].first;
+        if (strcmp(nm, "start") == 0) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, ctx->marks[i - 1].second, ctx->marks[i].second) != hipSuccess) continue;
+        size_t k = 0;
+        for (; k < acc.size(); k++) if (acc[k].first == nm) break;
+        if (k == acc.size()) { acc.emplace_back(nm, 0.0); cnt.push_back(0); }
+        acc[k].second += t; cnt[k]++;
+    }
+    ctx->marks.clear();
+    ctx->ev_used = 0;
+    ctx->last_times.clear();
+    for (size_t k = 0; k < acc.size(); k++) ctx->last_times.emplace_back(acc[k].first, (float)(acc[k].second / cnt[k]));
     int n = 0;
     for (auto &t : ctx->last_times) {
         if (n >= cap) break;

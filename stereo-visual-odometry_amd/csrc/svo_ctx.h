@@ -43,8 +43,12 @@ struct svo_ctx {
     // ---- pinned host scratch
     void *h_pinned = nullptr; size_t h_pinned_bytes = 0;
     // ---- timing
+    // stage marks are HIP events recorded on the context's stream; they are resolved (elapsed
+    // times averaged per stage over all steps since the last query) in svo_get_timing
     bool timing = false;
-    std::vector<std::pair<const char *, hipEvent_t>> marks;
+    std::vector<hipEvent_t> ev_pool;                               // every event ever created
+    size_t ev_used = 0;
+    std::vector<std::pair<const char *, hipEvent_t>> marks;        // log since the last query
     std::vector<std::pair<const char *, float>> last_times;
 };
 

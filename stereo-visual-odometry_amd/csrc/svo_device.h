@@ -55,6 +55,57 @@ __device__ inline long long wave_sum_i32_wide(int p)
     return ((long long)hi << 16) + (long long)lo;
 }
 
+// ---- several sums at once ---------------------------------------------------------------------
+// Reducing k values with k independent butterflies costs k*log2(64) cross-lane adds.  Instead the
+// first log2(k) steps exchange HALF of the values with the partner lane (each lane keeps one class
+// of values and gives the other away), so afterwards every lane carries ONE value whose class is
+// lane % k; the remaining steps use class-preserving moves: row_ror:4/8 inside a row of 16 and the
+// CDNA4 v_permlane16_swap / v_permlane32_swap across rows.
+__device__ inline int dpp_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
+__device__ inline int dpp_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); }
+__device__ inline int dpp_ror4(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true); }
+__device__ inline int dpp_ror8(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true); }
+
+// every lane ends with the sum over all lanes congruent to it mod 4
+__device__ inline int allsum_mod4(int v)
+{
+    v += dpp_ror4(v);
+    v += dpp_ror8(v);
+    auto a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = (int)(a[0] + a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)(b[0] + b[1]);
+}
+
+// four wave-wide int32 sums (each must fit in int32); results are wave-uniform
+__device__ inline void wave_sum4_i32(int lane, int v0, int v1, int v2, int v3, int &s0, int &s1, int &s2, int &s3)
+{
+    const bool odd = lane & 1, b1 = lane & 2;
+    int k0 = odd ? v2 : v0, g0 = odd ? v0 : v2;
+    int k1 = odd ? v3 : v1, g1 = odd ? v1 : v3;
+    k0 += dpp_xor1(g0);
+    k1 += dpp_xor1(g1);
+    int k = b1 ? k1 : k0, g = b1 ? k0 : k1;
+    k += dpp_xor2(g);
+    k = allsum_mod4(k);                     // lane % 4: 0 -> v0, 1 -> v2, 2 -> v1, 3 -> v3
+    s0 = __builtin_amdgcn_readlane(k, 0);
+    s2 = __builtin_amdgcn_readlane(k, 1);
+    s1 = __builtin_amdgcn_readlane(k, 2);
+    s3 = __builtin_amdgcn_readlane(k, 3);
+}
+
+// two wave-wide int32 sums
+__device__ inline void wave_sum2_i32(int lane, int v0, int v1, int &s0, int &s1)
+{
+    const bool odd = lane & 1;
+    int k = odd ? v1 : v0, g = odd ? v0 : v1;
+    k += dpp_xor1(g);
+    k += dpp_xor2(k);                       // parity-preserving
+    k = allsum_mod4(k);
+    s0 = __builtin_amdgcn_readlane(k, 0);
+    s1 = __builtin_amdgcn_readlane(k, 1);
+}
+
 // LDS traffic of ONE wave is ordered by the hardware queue; this only stops the compiler from
 // moving LDS accesses across the hand-off between lanes of the same wave.
 __device__ inline void wave_lds_fence()
