@@ -45,10 +45,22 @@ __device__ __forceinline__ bool has_arc9(unsigned m16)
 }
 
 // Returns 0 for a non-corner, else cornerScore<16> (>= thr) -- or 1 when scores are not needed.
-__device__ __forceinline__ int fast_score_at(const uint8_t *c, int thr, bool want_score)
+// Any 9-arc of the 16-circle contains at least one pixel of every opposite pair (k, k+8), so a
+// pixel whose pairs (0,8) and (4,12) cannot both be "brighter" or both be "darker" is rejected
+// after 4 loads (the same high-speed test cv::FAST performs); the wave only pays for the full
+// test when one of its lanes survives.
+__device__ __forceinline__ int fast_score_at(const uint8_t *c, int thr, bool want_score, bool valid)
 {
-    int v = c[0];
-    // high-speed rejection on the compass points first (same outcome as the full test)
+    constexpr int P = kRawW;
+    const int v = c[0];
+    bool alive = valid;
+    {
+        const int d0 = v - c[3 * P], d8 = v - c[-3 * P], d4 = v - c[3], d12 = v - c[-3];
+        const bool dk = (d0 > thr || d8 > thr) && (d4 > thr || d12 > thr);
+        const bool br = (d0 < -thr || d8 < -thr) && (d4 < -thr || d12 < -thr);
+        alive = alive && (dk || br);
+    }
+    if (!__any(alive)) return 0;
     int d[16];
     load_circle(c, d, v);
     unsigned dark = 0, bright = 0;          // d > thr: pixel darker than centre; d < -thr: brighter
@@ -57,8 +69,9 @@ __device__ __forceinline__ int fast_score_at(const uint8_t *c, int thr, bool wan
         dark |= (unsigned)(d[k] > thr) << k;
         bright |= (unsigned)(d[k] < -thr) << k;
     }
-    if (!(has_arc9(dark) || has_arc9(bright))) return 0;
-    if (!want_score) return 1;
+    const bool corner = alive && (has_arc9(dark) || has_arc9(bright));
+    if (!want_score) return corner ? 1 : 0;
+    if (!__any(corner)) return 0;
     // min / max over every 9-arc d[s..s+8] by doubling
     int mn[16], mx[16], t1[16], t2[16];
 #pragma unroll
@@ -74,12 +87,12 @@ __device__ __forceinline__ int fast_score_at(const uint8_t *c, int thr, bool wan
         bmin = min(bmin, max(t2[i], d[(i + 8) & 15]));
     }
     int b0 = min(-a0, bmin);
-    return -b0 - 1;
+    return corner ? -b0 - 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void fast_score_kernel(FastArgs a)
 {
-    __shared__ uint8_t raw[kRawH * kRawW];
+    __shared__ __attribute__((aligned(16))) uint8_t raw[kRawH * kRawW];
     __shared__ uint8_t sc[kScH * kScW];
     const int b = blockIdx.z;
     const uint8_t *img = a.img + (int64_t)b * a.img_stride;
@@ -88,24 +101,42 @@ __global__ __launch_bounds__(256) void fast_score_kernel(FastArgs a)
     const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
     const int tid = threadIdx.y * 64 + threadIdx.x;
 
-    // stage raw tile + halo; out-of-image bytes are never used by a valid centre
-    for (int i = tid; i < kRawH * kRawW; i += 256) {
-        int ry = i / kRawW, rx = i - ry * kRawW;
-        int gx = x0 - kHalo + rx, gy = y0 - kHalo + ry;
-        uint8_t v = 0;
-        if (gx >= 0 && gx < a.w && gy >= 0 && gy < a.h) v = img[(int64_t)gy * a.pitch + gx];
-        raw[i] = v;
+    // stage raw tile + halo (72 x 24 bytes); out-of-image bytes are never used by a valid centre.
+    // x0 - 4 is a multiple of 4, so with a 4-byte aligned image the tile is 18 dwords per row.
+    if ((((uintptr_t)img | (uintptr_t)a.pitch) & 3) == 0) {
+        uint32_t *raw32 = (uint32_t *)raw;
+        for (int i = tid; i < kRawH * (kRawW / 4); i += 256) {
+            int ry = i / (kRawW / 4), rx4 = i - ry * (kRawW / 4);
+            int gx = x0 - kHalo + rx4 * 4, gy = y0 - kHalo + ry;
+            uint32_t v = 0;
+            if (gy >= 0 && gy < a.h && gx >= 0) {
+                const uint8_t *src = img + (int64_t)gy * a.pitch + gx;
+                if (gx + 3 < a.w) v = *(const uint32_t *)src;
+                else for (int q = 0; q < 4; q++) if (gx + q < a.w) v |= (uint32_t)src[q] << (8 * q);
+            }
+            raw32[i] = v;
+        }
+    } else {
+        for (int i = tid; i < kRawH * kRawW; i += 256) {
+            int ry = i / kRawW, rx = i - ry * kRawW;
+            int gx = x0 - kHalo + rx, gy = y0 - kHalo + ry;
+            uint8_t v = 0;
+            if (gx >= 0 && gx < a.w && gy >= 0 && gy < a.h) v = img[(int64_t)gy * a.pitch + gx];
+            raw[i] = v;
+        }
     }
     __syncthreads();
 
-    // scores for the tile and its 1-pixel ring
-    for (int i = tid; i < kScH * kScW; i += 256) {
-        int sy = i / kScW, sx = i - sy * kScW;
+    // scores for the tile and its 1-pixel ring (every lane takes part: wave votes inside)
+    for (int i0 = 0; i0 < kScH * kScW; i0 += 256) {
+        const int i = i0 + tid;
+        const bool in = i < kScH * kScW;
+        const int ii = in ? i : 0;
+        int sy = ii / kScW, sx = ii - sy * kScW;
         int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
-        int s = 0;
-        if (gx >= 3 && gx < a.w - 3 && gy >= 3 && gy < a.h - 3)
-            s = fast_score_at(&raw[(sy + kHalo - 1) * kRawW + sx + kHalo - 1], a.thr, a.nms != 0);
-        sc[i] = (uint8_t)s;
+        const bool valid = in && gx >= 3 && gx < a.w - 3 && gy >= 3 && gy < a.h - 3;
+        int s = fast_score_at(&raw[(sy + kHalo - 1) * kRawW + sx + kHalo - 1], a.thr, a.nms != 0, valid);
+        if (in) sc[i] = (uint8_t)s;
     }
     __syncthreads();
 

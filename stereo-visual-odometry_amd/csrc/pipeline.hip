@@ -38,11 +38,10 @@ static int ingest_frames(svo_ctx *ctx, const uint8_t *L, const uint8_t *R, int p
 {
     const PyrGeom &g = ctx->geom;
     PyrArgs p{};
-    p.g = g; p.pitch = pitch; p.img_stride = frame_stride; p.slot_stride = 2 * g.slot_bytes;
-    p.img = L; p.slots = ctx->bslots + (size_t)(2 * f0) * g.slot_bytes;
-    launch_pyramid(p, n_new, ctx->stream);
-    p.img = R; p.slots = ctx->bslots + (size_t)(2 * f0 + 1) * g.slot_bytes;
-    launch_pyramid(p, n_new, ctx->stream);
+    // left and right images interleave into consecutive slots 2f, 2f+1: one launch set for both
+    p.g = g; p.pitch = pitch; p.img_stride = frame_stride; p.slot_stride = g.slot_bytes;
+    p.img = L; p.img2 = R; p.slots = ctx->bslots + (size_t)(2 * f0) * g.slot_bytes;
+    launch_pyramid(p, 2 * n_new, ctx->stream);
     mark(ctx, kTPyr);
     FastArgs a{};
     a.img = L; a.pitch = pitch; a.img_stride = frame_stride;

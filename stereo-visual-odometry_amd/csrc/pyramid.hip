@@ -5,54 +5,100 @@
 // BORDER_REFLECT_101 frame (upstream keeps a winSize = 21 frame the same way) and a 64-byte
 // aligned row pitch, so the LK kernel gathers 4-byte aligned tiles with no bounds logic.
 // Level l+1 = pyrDown(level l): separable [1 4 6 4 1], (sum + 128) >> 8, reflect-101 at the
-// level's own edges.  Border pixels are produced by evaluating the same expression at the
-// reflected interior coordinate, so every output byte is written exactly once and no second
-// border-fill pass (and no inter-workgroup dependency) is needed.
+// level's own edges -- which is exactly what reading the previous level's stored frame gives.
+//
+// Launch sequence per batch (all images of the batch in one grid):
+//   copy0   : source image -> level-0 interior, 16 bytes per lane when alignment allows
+//   border  : frame of level l from its own interior (1 load + 1 store per frame byte)
+//   down    : level l interior from level l-1 (+ its frame): 4 output pixels per lane, the 5x11
+//             source bytes fetched as aligned dwords, horizontal pass in registers
+// Algorithmic HBM bytes per image: W*H read, 1.33*W*H written (+ frames).
 // Integer-exact against oracle/lk.c (orc_pyramid_build).
 #include "svo_device.h"
 #include "svo_kernels.h"
 
 namespace svo {
 
-// level 0: padded copy of the source image
-__global__ __launch_bounds__(256) void pyr_level0_kernel(PyrArgs a)
+__device__ __forceinline__ const uint8_t *src_image(const PyrArgs &a, int b)
 {
-    const int b = blockIdx.z;
-    const int w = a.g.w[0], h = a.g.h[0];
-    const int px = blockIdx.x * 256 + threadIdx.x;       // padded x
-    const int py = blockIdx.y;                           // padded y
-    if (px >= w + 2 * kPad) return;
-    const uint8_t *img = a.img + (int64_t)b * a.img_stride;
-    uint8_t *dst = a.slots + (int64_t)b * a.slot_stride + a.g.origin[0];
-    int x = refl101(px - kPad, w), y = refl101(py - kPad, h);
-    dst[(int64_t)(py - kPad) * a.g.pitch[0] + (px - kPad)] = img[(int64_t)y * a.pitch + x];
+    // image b of the batch: even/odd images may come from two arrays (left / right frames)
+    if (a.img2) return ((b & 1) ? a.img2 : a.img) + (int64_t)(b >> 1) * a.img_stride;
+    return a.img + (int64_t)b * a.img_stride;
 }
 
-// level l (>= 1) from level l-1, including the border ring
-__global__ __launch_bounds__(256) void pyr_down_kernel(PyrArgs a, int l)
+__global__ __launch_bounds__(256) void pyr_copy0_kernel(PyrArgs a)
+{
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int w = a.g.w[0];
+    const uint8_t *src = src_image(a, b) + (int64_t)y * a.pitch;
+    uint8_t *dst = a.slots + (int64_t)b * a.slot_stride + a.g.origin[0] + (int64_t)y * a.g.pitch[0];
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 16;
+    if (x >= w) return;
+    if (x + 16 <= w && ((uintptr_t)(src + x) & 15) == 0) {
+        *(uint4 *)(dst + x) = *(const uint4 *)(src + x);          // dst rows are 32-byte aligned
+    } else {
+        for (int q = 0; q < 16 && x + q < w; q++) dst[x + q] = src[x + q];
+    }
+}
+
+// frame of level l: every padded position outside the interior copies its reflect-101 source
+__global__ __launch_bounds__(256) void pyr_border_kernel(PyrArgs a, int l)
 {
     const int b = blockIdx.z;
-    const int w = a.g.w[l], h = a.g.h[l];
-    const int sw = a.g.w[l - 1], sh = a.g.h[l - 1], sp = a.g.pitch[l - 1];
-    const int px = blockIdx.x * 256 + threadIdx.x;
-    const int py = blockIdx.y;
-    if (px >= w + 2 * kPad) return;
+    const int w = a.g.w[l], h = a.g.h[l], pitch = a.g.pitch[l];
+    uint8_t *lvl = a.slots + (int64_t)b * a.slot_stride + a.g.origin[l];
+    const int py = blockIdx.y - kPad;                      // padded row
+    int px = blockIdx.x * 256 + threadIdx.x;               // index into the row's frame bytes
+    if (py >= 0 && py < h) {
+        // interior row: only the 2 * kPad side bytes
+        if (px >= 2 * kPad) return;
+        px = px < kPad ? px - kPad : w + (px - kPad);
+    } else {
+        if (px >= w + 2 * kPad) return;
+        px -= kPad;
+    }
+    lvl[(int64_t)py * pitch + px] = lvl[(int64_t)refl101(py, h) * pitch + refl101(px, w)];
+}
+
+// level l (>= 1) interior from level l-1: thread -> 4 consecutive output pixels
+__global__ __launch_bounds__(256) void pyr_down_kernel(PyrArgs a, int l)
+{
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int w = a.g.w[l];
+    const int sp = a.g.pitch[l - 1];
     uint8_t *slot = a.slots + (int64_t)b * a.slot_stride;
     const uint8_t *src = slot + a.g.origin[l - 1];
-    uint8_t *dst = slot + a.g.origin[l];
-    const int x = refl101(px - kPad, w), y = refl101(py - kPad, h);
-    // columns 2x-2..2x+2 / rows 2y-2..2y+2 of the source level, reflect-101 on ITS size
-    int cx[5], acc = 0;
-#pragma unroll
-    for (int k = 0; k < 5; k++) cx[k] = refl101(2 * x + k - 2, sw);
+    uint8_t *dst = slot + a.g.origin[l] + (int64_t)y * a.g.pitch[l];
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= w) return;
+    // source columns 2*x0-2 .. 2*x0+8, fetched as the 4 aligned dwords starting at 2*x0-4
+    // (x0 % 4 == 0 and the level origin is 32-byte aligned, so 2*x0-4 is 4-byte aligned; the
+    //  stored reflect-101 frame supplies columns < 0 and >= w_src, rows likewise)
+    int acc[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 5; r++) {
-        const uint8_t *row = src + (int64_t)refl101(2 * y + r - 2, sh) * sp;
-        int hs = row[cx[2]] * 6 + (row[cx[1]] + row[cx[3]]) * 4 + row[cx[0]] + row[cx[4]];
+        const uint32_t *row = (const uint32_t *)(src + (int64_t)(2 * y + r - 2) * sp + 2 * x0 - 4);
+        const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3];
+        // bytes s[j] = source column 2*x0 - 4 + j, j = 0..15
+        int s[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            s[j] = (d0 >> (8 * j)) & 255; s[4 + j] = (d1 >> (8 * j)) & 255;
+            s[8 + j] = (d2 >> (8 * j)) & 255; s[12 + j] = (d3 >> (8 * j)) & 255;
+        }
         const int wv = (r == 2) ? 6 : ((r == 1 || r == 3) ? 4 : 1);
-        acc += hs * wv;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = 4 + 2 * q;                       // centre column 2*(x0+q)
+            const int hs = s[c] * 6 + (s[c - 1] + s[c + 1]) * 4 + s[c - 2] + s[c + 2];
+            acc[q] += hs * wv;
+        }
     }
-    dst[(int64_t)(py - kPad) * a.g.pitch[l] + (px - kPad)] = (uint8_t)((acc + 128) >> 8);
+    uint32_t out = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) out |= (uint32_t)((acc[q] + 128) >> 8) << (8 * q);
+    if (x0 + 4 <= w) *(uint32_t *)(dst + x0) = out;
+    else for (int q = 0; x0 + q < w; q++) dst[x0 + q] = (uint8_t)(out >> (8 * q));
 }
 
 __global__ __launch_bounds__(256) void pyr_read_level_kernel(PyrGeom g, const uint8_t *slot, int l,
@@ -67,12 +113,16 @@ void launch_pyramid(const PyrArgs &a, int batch, hipStream_t st)
 {
     dim3 blk(256, 1, 1);
     {
-        dim3 g((a.g.w[0] + 2 * kPad + 255) / 256, a.g.h[0] + 2 * kPad, batch);
-        hipLaunchKernelGGL(pyr_level0_kernel, g, blk, 0, st, a);
+        dim3 g((a.g.w[0] + 4095) / 4096, a.g.h[0], batch);
+        hipLaunchKernelGGL(pyr_copy0_kernel, g, blk, 0, st, a);
     }
-    for (int l = 1; l < a.g.nlevels; l++) {
-        dim3 g((a.g.w[l] + 2 * kPad + 255) / 256, a.g.h[l] + 2 * kPad, batch);
-        hipLaunchKernelGGL(pyr_down_kernel, g, blk, 0, st, a, l);
+    for (int l = 0; l < a.g.nlevels; l++) {
+        if (l > 0) {
+            dim3 g((a.g.w[l] + 1023) / 1024, a.g.h[l], batch);
+            hipLaunchKernelGGL(pyr_down_kernel, g, blk, 0, st, a, l);
+        }
+        dim3 gb((a.g.w[l] + 2 * kPad + 255) / 256, a.g.h[l] + 2 * kPad, batch);
+        hipLaunchKernelGGL(pyr_border_kernel, gb, blk, 0, st, a, l);
     }
 }
 

@@ -22,6 +22,7 @@ void launch_fast(const FastArgs &a, int batch, hipStream_t st);
 struct PyrArgs {
     PyrGeom g;
     const uint8_t *img; int pitch; int64_t img_stride;     // source images
+    const uint8_t *img2;                                   // non-null: image b comes from (b odd ? img2 : img) + (b/2)*img_stride
     uint8_t *slots; int64_t slot_stride;                   // destination slots (b-th image -> slots + b*slot_stride)
 };
 void launch_pyramid(const PyrArgs &a, int batch, hipStream_t st);

@@ -1,0 +1,49 @@
+// System.h -- facade + KITTI reader (reference include/lzb_vio/System.h:19-47).  Same public
+// surface: System(std::string&), Run(), Step(), Step_ros(Frame::Ptr).  Additive: SetPoseFile().
+#pragma once
+#ifndef lzb_vio_System_H
+#define lzb_vio_System_H
+
+#include "lzb_vio/common_include.h"
+#include "lzb_vio/frame.h"
+#include "lzb_vio/parameter.h"
+#include "lzb_vio/tracking.h"
+
+namespace lzb_vio {
+
+class System {
+public:
+    explicit System(std::string &config_path);
+    ~System();
+    void Run();
+    bool Step();
+    bool Step_ros(Frame::Ptr new_frame);
+
+    // additive: write one KITTI-format pose row (12 numbers of [R|t]) per frame
+    bool SetPoseFile(const std::string &path);
+    Tracking::Ptr GetTracking() { return tracking_; }
+    int FramesProcessed() const { return current_image_index_; }
+
+private:
+    TrackingStatus GetFrontendStatus() const { return tracking_->GetStatus(); }
+    Frame::Ptr NextFrame_kitti();
+    void Shutdown();
+    void Reset();
+    void WritePose();
+
+    std::string config_file_path_;
+    Parameter::Ptr init_parameter_ = nullptr;
+    Sensors::Ptr sensors_ = nullptr;
+    Tracking::Ptr tracking_ = nullptr;
+    int current_image_index_ = 0;
+    bool inited_ = false;
+    std::string dataset_path_;
+    FILE *pose_file_ = nullptr;
+};
+
+// 8-bit grayscale image readers used by NextFrame_kitti: binary PGM (P5) and PNG (8-bit gray or
+// RGB/RGBA converted with the BT.601 weights cv::imread(IMREAD_GRAYSCALE) uses; zlib inflate).
+bool ReadImageGray(const std::string &path, cv::Mat &out);
+
+}  // namespace lzb_vio
+#endif

@@ -1,0 +1,69 @@
+// tracking.h -- host-side mirror of lzb_vio::Tracking (reference include/lzb_vio/tracking.h:29-154).
+// The public surface is the reference's: Tracking(System*, Parameter::Ptr, Sensors::Ptr),
+// AddFrame(Frame::Ptr), GetStatus(), Set_vo(System*).  The private OpenCV stages are replaced by
+// ONE call into the HIP library per frame (svo_add_frame, include/svo_abi.h); there is no CPU
+// implementation behind this class.  Additive API: GetPose(), LastResult().
+#pragma once
+#ifndef lzb_vio_TRACKING_H
+#define lzb_vio_TRACKING_H
+
+#include "lzb_vio/feature.h"
+#include "lzb_vio/frame.h"
+#include "lzb_vio/parameter.h"
+#include "lzb_vio/sensors.h"
+#include "svo_abi.h"
+
+namespace lzb_vio {
+class System;
+
+enum class TrackingStatus { INITING, TRACKING_GOOD, LOST };
+
+class Tracking {
+public:
+    typedef std::shared_ptr<Tracking> Ptr;
+    Tracking(System *system, Parameter::Ptr parameter, Sensors::Ptr sensors);
+    ~Tracking();
+    void Set_vo(System *vo);
+    bool AddFrame(Frame::Ptr frame);
+    TrackingStatus GetStatus() const { return status_; }
+
+    // additive (the reference has no getter for frame_pose_)
+    Pose4x4 GetPose() const { return frame_pose_; }
+    const svo_step_result &LastResult() const { return last_; }
+    void SetFillFeatures(bool on) { fill_features_ = on; }   // populate Frame::features_left_ (costs a D2H)
+
+private:
+    bool StereoInit_f2f();
+    bool Track();
+    bool LK_StereoF2F_PnP_Track();
+    bool ORB_StereoF2F_PnP_Track();
+    void Readparameter();
+    bool EnsureContext(int width, int height);
+
+    TrackingStatus status_ = TrackingStatus::INITING;
+    Frame::Ptr current_frame_ = nullptr, last_frame_ = nullptr;
+    Sensors::Ptr sensors_ = nullptr;
+    System *system_ = nullptr;
+    Parameter::Ptr parameter_ = nullptr;
+    Pose4x4 frame_pose_;
+    double Px_ = 0, Py_ = 0, Pz_ = 0;
+
+    svo_ctx *ctx_ = nullptr;
+    int ctx_w_ = 0, ctx_h_ = 0;
+    svo_step_result last_;
+    bool fill_features_ = false;
+
+    // Readparameter()
+    int num_features_ = 200, num_features_init_ = 100, num_features_tracking_ = 50;
+    int num_features_tracking_bad_ = 20, num_features_needed_for_keyframe_ = 80, init_landmarks_ = 5;
+    double feature_match_error_ = 10, inlier_rate_ = 0.5;
+    int iterationsCount_ = 500;
+    float reprojectionError_ = 0.5f, confidence_ = 0.999f;
+    double minmove_ = 0.01, maxmove_ = 0.01;
+    std::string track_mode_ = "stereoicp_f2f";
+    int nFeatures_ = 0, nLevels_ = 0, fIniThFAST_ = 0, fMinThFAST_ = 0;
+    float fScaleFactor_ = 0;
+};
+
+}  // namespace lzb_vio
+#endif

@@ -1,0 +1,199 @@
+// System.cpp -- facade + KITTI dataset reader (reference src/System.cpp).  The reference's dead
+// 0.5x resize (:93-97) is dropped; PNG decode replaces cv::imread.
+#include "lzb_vio/System.h"
+#include <chrono>
+#include <cstdlib>
+#include <zlib.h>
+
+namespace lzb_vio {
+
+// ---- image readers ---------------------------------------------------------------------------
+static bool read_file(const std::string &path, std::vector<uint8_t> &buf)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    buf.resize(n > 0 ? (size_t)n : 0);
+    bool ok = n > 0 && fread(buf.data(), 1, (size_t)n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+
+static bool read_pgm(const std::vector<uint8_t> &b, cv::Mat &out)
+{
+    size_t p = 2;
+    int vals[3], nv = 0;
+    while (nv < 3 && p < b.size()) {
+        while (p < b.size() && (b[p] == ' ' || b[p] == '\n' || b[p] == '\r' || b[p] == '\t')) p++;
+        if (p < b.size() && b[p] == '#') { while (p < b.size() && b[p] != '\n') p++; continue; }
+        int v = 0; bool any = false;
+        while (p < b.size() && b[p] >= '0' && b[p] <= '9') { v = v * 10 + (b[p] - '0'); p++; any = true; }
+        if (!any) return false;
+        vals[nv++] = v;
+    }
+    p++;                                                    // single whitespace after maxval
+    if (nv != 3 || vals[2] != 255 || b.size() < p + (size_t)vals[0] * vals[1]) return false;
+    out.create(vals[1], vals[0]);
+    for (int y = 0; y < vals[1]; y++) memcpy(out.ptr(y), &b[p + (size_t)y * vals[0]], vals[0]);
+    return true;
+}
+
+static uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
+
+// 8-bit, non-interlaced PNG: gray (type 0), gray+alpha (4), RGB (2), RGBA (6)
+static bool read_png(const std::vector<uint8_t> &b, cv::Mat &out)
+{
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (b.size() < 33 || memcmp(b.data(), sig, 8) != 0) return false;
+    size_t p = 8;
+    int w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat;
+    while (p + 12 <= b.size()) {
+        uint32_t len = be32(&b[p]);
+        const uint8_t *type = &b[p + 4];
+        if (p + 12 + len > b.size()) return false;
+        if (!memcmp(type, "IHDR", 4)) {
+            w = (int)be32(&b[p + 8]); h = (int)be32(&b[p + 12]);
+            depth = b[p + 16]; ctype = b[p + 17]; interlace = b[p + 20];
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), &b[p + 8], &b[p + 8 + len]);
+        } else if (!memcmp(type, "IEND", 4)) break;
+        p += 12 + len;
+    }
+    if (w <= 0 || h <= 0 || depth != 8 || interlace != 0) return false;
+    int ch = ctype == 0 ? 1 : ctype == 4 ? 2 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
+    if (!ch) return false;
+    const size_t stride = (size_t)w * ch;
+    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    uLongf rawlen = (uLongf)raw.size();
+    if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return false;
+    std::vector<uint8_t> prev(stride, 0), cur(stride);
+    out.create(h, w);
+    for (int y = 0; y < h; y++) {
+        const uint8_t *src = &raw[(stride + 1) * (size_t)y];
+        const int ft = src[0];
+        for (size_t i = 0; i < stride; i++) {
+            int a = i >= (size_t)ch ? cur[i - ch] : 0, bb = prev[i], c = i >= (size_t)ch ? prev[i - ch] : 0, x = src[1 + i];
+            int pr;
+            switch (ft) {
+            case 0: pr = 0; break;
+            case 1: pr = a; break;
+            case 2: pr = bb; break;
+            case 3: pr = (a + bb) >> 1; break;
+            case 4: { int pp = a + bb - c, pa = abs(pp - a), pb = abs(pp - bb), pc = abs(pp - c);
+                      pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c); break; }
+            default: return false;
+            }
+            cur[i] = (uint8_t)(x + pr);
+        }
+        uint8_t *d = out.ptr(y);
+        if (ch <= 2) for (int x = 0; x < w; x++) d[x] = cur[(size_t)x * ch];
+        else for (int x = 0; x < w; x++) {
+            // cv::imread(IMREAD_GRAYSCALE) colour conversion: (R*4899 + G*9617 + B*1868 + 8192) >> 14
+            const uint8_t *q = &cur[(size_t)x * ch];
+            d[x] = (uint8_t)((q[0] * 4899 + q[1] * 9617 + q[2] * 1868 + 8192) >> 14);
+        }
+        prev.swap(cur);
+    }
+    return true;
+}
+
+bool ReadImageGray(const std::string &path, cv::Mat &out)
+{
+    std::vector<uint8_t> b;
+    if (!read_file(path, b) || b.size() < 8) return false;
+    if (b[0] == 'P' && b[1] == '5') return read_pgm(b, out);
+    return read_png(b, out);
+}
+
+// ---- System ------------------------------------------------------------------------------------
+System::System(std::string &config_path) : config_file_path_(config_path)
+{
+    if (Config::SetParameterFile(config_file_path_) == false) {
+        fprintf(stderr, "unable to open %s\n", config_file_path_.c_str());
+        exit(-1);                                          // as the reference does (src/System.cpp:15-19)
+    }
+    init_parameter_ = Parameter::Ptr(new Parameter);
+    sensors_ = Sensors::Ptr(new Sensors(init_parameter_));
+    tracking_ = Tracking::Ptr(new Tracking(this, init_parameter_, sensors_));
+    dataset_path_ = init_parameter_->dataset_path_;
+    if (Config::Has("pose_file")) SetPoseFile(Config::Get<std::string>("pose_file"));   // additive key
+}
+
+System::~System()
+{
+    if (pose_file_) fclose(pose_file_);
+}
+
+bool System::SetPoseFile(const std::string &path)
+{
+    if (pose_file_) fclose(pose_file_);
+    pose_file_ = fopen(path.c_str(), "w");
+    return pose_file_ != nullptr;
+}
+
+void System::WritePose()
+{
+    if (!pose_file_) return;
+    Pose4x4 P = tracking_->GetPose();
+    for (int i = 0; i < 12; i++) fprintf(pose_file_, "%.9e%c", P.m[i], i == 11 ? '\n' : ' ');
+}
+
+void System::Run()
+{
+    while (1) {
+        if (Step() == false) break;
+    }
+    Shutdown();
+}
+
+bool System::Step()
+{
+    Frame::Ptr new_frame = NextFrame_kitti();
+    if (new_frame == nullptr) return false;
+    auto t1 = std::chrono::steady_clock::now();
+    bool success = tracking_->AddFrame(new_frame);
+    auto t2 = std::chrono::steady_clock::now();
+    double dt = std::chrono::duration_cast<std::chrono::duration<double>>(t2 - t1).count();
+    if (getenv("LZB_VIO_VERBOSE")) LZB_LOG("INFO", "VO cost time: %f seconds (%s)", dt, success ? "ok" : "skipped");
+    WritePose();
+    return true;                                           // the reference ignores AddFrame's result here (:53,58)
+}
+
+bool System::Step_ros(Frame::Ptr new_frame)
+{
+    if (new_frame == nullptr) return false;
+    bool success = tracking_->AddFrame(new_frame);
+    WritePose();
+    return success;
+}
+
+Frame::Ptr System::NextFrame_kitti()
+{
+    char name[32];
+    cv::Mat image_left, image_right;
+    const char *ext[2] = {"png", "pgm"};
+    for (int cam = 0; cam < 2; cam++) {
+        bool ok = false;
+        for (int e = 0; e < 2 && !ok; e++) {
+            snprintf(name, sizeof(name), "/image_%d/%06d.%s", cam, current_image_index_, ext[e]);
+            ok = ReadImageGray(dataset_path_ + name, cam == 0 ? image_left : image_right);
+        }
+        if (!ok) {
+            LZB_LOG("WARNING", "cannot find images at index %d", current_image_index_);
+            return nullptr;
+        }
+    }
+    auto new_frame = Frame::CreateFrame();
+    new_frame->left_img_ = image_left;
+    new_frame->right_img_ = image_right;
+    current_image_index_++;
+    return new_frame;
+}
+
+void System::Shutdown() {}
+void System::Reset() {}
+
+}  // namespace lzb_vio

@@ -1,0 +1,148 @@
+// tracking.cpp -- lzb_vio::Tracking on top of the HIP library (reference src/tracking.cpp).
+// The state machine is the reference's (AddFrame :49-77, StereoInit_f2f :78-92, Track :115-128);
+// everything below it is ONE svo_add_frame call: FAST -> 4x LK -> filter -> triangulate ->
+// solvePnPRansac -> gates -> frame_pose_ update all happen on the GPU.
+#include "lzb_vio/tracking.h"
+
+namespace lzb_vio {
+
+Tracking::Tracking(System *system, Parameter::Ptr parameter, Sensors::Ptr sensors)
+{
+    sensors_ = sensors;
+    system_ = system;
+    parameter_ = parameter;
+    memset(&last_, 0, sizeof(last_));
+    Readparameter();
+}
+
+Tracking::~Tracking()
+{
+    if (ctx_) svo_destroy(ctx_);
+}
+
+void Tracking::Readparameter()
+{
+    num_features_init_ = parameter_->num_features_init_;
+    num_features_ = parameter_->num_features_;
+    num_features_tracking_bad_ = parameter_->num_features_tracking_bad_;
+    num_features_needed_for_keyframe_ = parameter_->num_features_needed_for_keyframe_;
+    init_landmarks_ = parameter_->init_landmarks_;
+    feature_match_error_ = parameter_->feature_match_error_;
+    track_mode_ = parameter_->track_mode_;
+    num_features_tracking_ = parameter_->num_features_tracking_;
+    inlier_rate_ = parameter_->inlier_rate_;
+    iterationsCount_ = parameter_->iterationsCount_;
+    reprojectionError_ = parameter_->reprojectionError_;
+    confidence_ = parameter_->confidence_;
+    maxmove_ = parameter_->maxmove_;
+    minmove_ = parameter_->minmove_;
+    nFeatures_ = parameter_->nFeatures_;
+    fScaleFactor_ = parameter_->fScaleFactor_;
+    nLevels_ = parameter_->nLevels_;
+    fIniThFAST_ = parameter_->fIniThFAST_;
+    fMinThFAST_ = parameter_->fMinThFAST_;
+}
+
+void Tracking::Set_vo(System *slam) { system_ = slam; }
+
+// The HIP context is sized by the first frame (the reference learns the size from cv::imread too).
+bool Tracking::EnsureContext(int width, int height)
+{
+    if (ctx_ && width == ctx_w_ && height == ctx_h_) return true;
+    if (ctx_) { svo_destroy(ctx_); ctx_ = nullptr; }
+    svo_config cfg;
+    svo_default_config(&cfg, width, height);
+    cfg.fast_threshold = 20;                                     // hard-coded, src/tracking.cpp:99
+    cfg.num_features_tracking = num_features_tracking_;
+    cfg.iterations = iterationsCount_;
+    cfg.reproj_err = reprojectionError_;
+    cfg.confidence = confidence_;
+    cfg.feature_match_error = feature_match_error_;
+    cfg.inlier_rate = inlier_rate_;
+    cfg.min_move2 = 0.0005 * 0.0005;                             // LK mode, src/tracking.cpp:311
+    cfg.max_move2 = 100.0;
+    memcpy(cfg.P1, sensors_->projMatr1_, sizeof(cfg.P1));
+    memcpy(cfg.P2, sensors_->projMatr2_, sizeof(cfg.P2));
+    int rc = svo_create(&cfg, 0, &ctx_);
+    if (rc != SVO_OK) {
+        LZB_LOG("ERROR", "svo_create failed (%d): a HIP device is required, there is no CPU path", rc);
+        ctx_ = nullptr;
+        return false;
+    }
+    ctx_w_ = width; ctx_h_ = height;
+    return true;
+}
+
+bool Tracking::AddFrame(Frame::Ptr frame)
+{
+    current_frame_ = frame;
+    bool ok = true;
+    switch (status_) {
+    case TrackingStatus::INITING:
+        StereoInit_f2f();
+        break;
+    case TrackingStatus::TRACKING_GOOD:
+        ok = Track();
+        last_frame_ = current_frame_;          // on success AND failure (src/tracking.cpp:59-68)
+        return ok;
+    case TrackingStatus::LOST:
+        break;
+    }
+    return true;
+}
+
+static bool feed(svo_ctx *ctx, Frame::Ptr f, svo_step_result *res, int *rc_out)
+{
+    const cv::Mat &L = f->left_img_, &R = f->right_img_;
+    if (L.empty() || R.empty() || L.rows != R.rows || L.cols != R.cols || L.step != R.step) {
+        LZB_LOG("ERROR", "stereo frame %lu has missing or mismatched images", f->id_);
+        *rc_out = SVO_ERR_ARG;
+        return false;
+    }
+    *rc_out = svo_add_frame(ctx, L.data, R.data, (int)L.step, SVO_MEM_HOST, res);
+    if (*rc_out < 0) LZB_LOG("ERROR", "svo_add_frame: %s", svo_last_error(ctx));
+    return *rc_out == SVO_OK;
+}
+
+bool Tracking::StereoInit_f2f()
+{
+    if (track_mode_ == "ORB_stereof2f_pnp")
+        LZB_LOG("WARNING", "track_mode ORB_stereof2f_pnp is not built yet; initialising the FAST+LK path");
+    if (!EnsureContext(current_frame_->left_img_.cols, current_frame_->left_img_.rows)) return false;
+    svo_reset(ctx_);
+    int rc;
+    feed(ctx_, current_frame_, &last_, &rc);
+    last_frame_ = current_frame_;
+    status_ = TrackingStatus::TRACKING_GOOD;
+    return rc >= 0;
+}
+
+bool Tracking::Track()
+{
+    if (track_mode_ == "LK_stereof2f_pnp") return LK_StereoF2F_PnP_Track();
+    if (track_mode_ == "ORB_stereof2f_pnp") return ORB_StereoF2F_PnP_Track();
+    return false;                               // any other string: Track() is always false (:127)
+}
+
+bool Tracking::LK_StereoF2F_PnP_Track()
+{
+    if (!EnsureContext(current_frame_->left_img_.cols, current_frame_->left_img_.rows)) return false;
+    int rc;
+    bool ok = feed(ctx_, current_frame_, &last_, &rc);
+    if (rc < 0) return false;
+    if (ok) {
+        memcpy(frame_pose_.m, last_.pose, sizeof(frame_pose_.m));
+        Px_ = frame_pose_.m[3]; Py_ = frame_pose_.m[7]; Pz_ = frame_pose_.m[11];
+    }
+    return ok;
+}
+
+bool Tracking::ORB_StereoF2F_PnP_Track()
+{
+    // SURVEY.md section 8 rows a8-a14 (BASELINE config #3): next to be built; fail loudly rather than
+    // silently running something else
+    LZB_LOG("ERROR", "track_mode ORB_stereof2f_pnp: the ORB path is not built yet (use LK_stereof2f_pnp)");
+    return false;
+}
+
+}  // namespace lzb_vio

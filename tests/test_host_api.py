@@ -1,0 +1,157 @@
+"""Host-side C++ mirror of the reference's lzb_vio API (stereo-visual-odometry_amd/host/).
+
+CPU: the YAML surface parses the reference's config/default.yaml layout and the PGM/PNG readers
+decode what cv::imread(IMREAD_GRAYSCALE) would.  GPU (-m gpu): run_kitti_stereo <yaml> is a drop-in:
+it walks a KITTI-layout dataset directory and its pose chain equals the C-ABI's online path."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import conftest
+
+HOST = os.path.join(conftest.ROOT, "stereo-visual-odometry_amd", "host")
+
+YAML = """%YAML:1.0
+# data
+dataset_path: {dataset}
+
+# don't care，it doesn't effect others.(this param is diacard)
+ros_data_IaE_dir: /
+camera_l.fx: {fx}
+camera_l.fy: {fy}
+camera_l.cx: {cx}
+camera_l.cy: {cy}
+camera_r.fx: {fx}
+camera_r.fy: {fy}
+camera_r.cx: {cx}
+camera_r.cy: {cy}
+t_lr0: -0.537
+t_lr1: 0.00
+t_lr2: 0.00
+R_lr0: 1.0
+R_lr1: 0.0
+R_lr2: 0.0
+R_lr3: 0.0
+R_lr4: 1.0
+R_lr5: 0.0
+R_lr6: 0.0
+R_lr7: 0.0
+R_lr8: 1.0
+num_features: 500
+num_features_init: 20
+init_landmarks: 5
+feature_match_error: 3
+num_features_tracking: 5
+num_features_tracking_bad: 10
+num_features_needed_for_keyframe: 60
+#you can choose LK_stereof2f_pnp, ORB_stereof2f_pnp
+track_mode: {mode}
+inlier_rate: 0.01
+iterationsCount: 500
+reprojectionError: 0.5
+confidence: 0.99
+display_scale: 1
+display_x: 400
+display_y: 200
+minmove: 0.05
+maxmove: 10
+fMinThFAST: 7
+fIniThFAST: 20
+nLevels: 8
+fScaleFactor: 1.2
+nFeatures: 2000
+"""
+
+
+@pytest.fixture(scope="module")
+def host_built(pkg):
+    pkg.build_library()
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    return HOST
+
+
+def _write_yaml(path, dataset, fx=718.856, fy=718.856, cx=607.193, cy=185.216, mode="LK_stereof2f_pnp"):
+    with open(path, "w", encoding="utf-8") as f:
+        f.write(YAML.format(dataset=dataset, fx=fx, fy=fy, cx=cx, cy=cy, mode=mode))
+
+
+def _write_pgm(path, img):
+    with open(path, "wb") as f:
+        f.write(b"P5\n# synthetic\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(np.ascontiguousarray(img).tobytes())
+
+
+def _hash(img):
+    s = 0
+    for v in img.reshape(-1).tolist():
+        s = (s * 31 + v) % (1 << 64)
+    return s
+
+
+def test_yaml_surface_and_image_readers(host_built, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    gray = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    rgb = rng.integers(0, 256, (21, 34, 3), dtype=np.uint8)
+    Image.fromarray(gray).save(tmp_path / "g.png")
+    Image.fromarray(rgb).save(tmp_path / "c.png")
+    _write_pgm(tmp_path / "g.pgm", gray)
+    (tmp_path / "bad.png").write_bytes(b"not a png at all")
+    _write_yaml(tmp_path / "cfg.yaml", "/data/kitti/00", mode="ORB_stereof2f_pnp")
+    out = subprocess.check_output([os.path.join(host_built, "host_selftest"), str(tmp_path / "cfg.yaml"),
+                                   str(tmp_path / "g.png"), str(tmp_path / "g.pgm"), str(tmp_path / "c.png"),
+                                   str(tmp_path / "bad.png")], stderr=subprocess.DEVNULL).decode()
+    lines = dict(l.split("=", 1) if l.count("=") == 1 else (l.split(" ", 1)[0], l) for l in out.strip().split("\n"))
+    assert lines["track_mode"] == "ORB_stereof2f_pnp" and lines["dataset_path"] == "/data/kitti/00"
+    assert "fx=718.856000 cx=607.193000 cy=185.216000" in out
+    assert "P2_03=%.9f" % (718.856 * -0.537) in out
+    assert "feature_match_error=3.000 num_features_tracking=5 inlier_rate=0.0100" in out
+    assert "iterationsCount=500 reprojectionError=0.500 confidence=0.990" in out
+    assert "nFeatures=2000 fScaleFactor=1.20 nLevels=8 fIniThFAST=20 fMinThFAST=7" in out
+    assert lines["missing"] == "0"
+    assert f"image1 ok=1 rows=37 cols=53 hash={_hash(gray)}" in out
+    assert f"image2 ok=1 rows=37 cols=53 hash={_hash(gray)}" in out
+    g = ((rgb[..., 0].astype(np.int64) * 4899 + rgb[..., 1].astype(np.int64) * 9617 +
+          rgb[..., 2].astype(np.int64) * 1868 + 8192) >> 14).astype(np.uint8)
+    assert f"image3 ok=1 rows=21 cols=34 hash={_hash(g)}" in out
+    assert "image4 ok=0" in out
+
+
+def test_usage_error_returns_nonzero(host_built):
+    r = subprocess.run([os.path.join(host_built, "run_kitti_stereo")], stderr=subprocess.DEVNULL)
+    assert r.returncode == 2
+
+
+@pytest.mark.gpu
+def test_run_kitti_stereo_drop_in(host_built, pkg, small_seq, tmp_path):
+    from PIL import Image
+    seq, frames = small_seq
+    h, w = frames[0][0].shape
+    for cam in (0, 1):
+        os.makedirs(tmp_path / f"image_{cam}")
+    for t, (L, R) in enumerate(frames):
+        Image.fromarray(L).save(tmp_path / "image_0" / f"{t:06d}.png")
+        if t % 2:
+            _write_pgm(tmp_path / "image_1" / f"{t:06d}.pgm", R)          # reader falls back to .pgm
+        else:
+            Image.fromarray(R).save(tmp_path / "image_1" / f"{t:06d}.png")
+    _write_yaml(tmp_path / "cfg.yaml", str(tmp_path), fx=seq.fx, fy=seq.fy, cx=seq.cx, cy=seq.cy)
+    r = subprocess.run([os.path.join(host_built, "run_kitti_stereo"), str(tmp_path / "cfg.yaml"),
+                        str(tmp_path / "poses.txt")], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    poses = np.loadtxt(tmp_path / "poses.txt").reshape(-1, 3, 4)
+    assert poses.shape[0] == len(frames)
+    # the same frames through the C-ABI's online path
+    P1, P2 = seq.proj()
+    c = pkg.Context(w, h, device=0, P1=P1, P2=P2)
+    ref = []
+    for L, R in frames:
+        c.add_frame(L, R)
+        ref.append(c.get_pose()[:3])
+    c.close()
+    assert np.allclose(poses[0], np.eye(4)[:3])
+    assert np.abs(poses - np.array(ref)).max() < 1e-6
+    gt = np.linalg.inv(seq.poses_wc()[0].numpy()) @ seq.poses_wc()[len(frames) - 1].numpy()
+    assert np.abs(poses[-1][:, 3] - gt[:3, 3]).max() < 0.25
