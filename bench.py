@@ -65,12 +65,13 @@ def main():
     pkg = entry.load_package()
     import importlib
     synth = importlib.import_module(entry.PKG_NAME + ".synth")
+    mg = importlib.import_module(entry.PKG_NAME + ".multigpu")
 
     B = args.batch
     F = B + 1
     dev = torch.device("cuda", local_rank)
     # ---- synthetic S0 frames, resident in HBM before the timed region -----------------------
-    seed = 20200710 if world == 1 else 100 + rank
+    seed = mg.sequence_seed(rank, world)
     seq = synth.StereoSequence(width=W, height=H, n_frames=F, seed=seed, device=dev)
     cache = args.frames_cache if world == 1 else ""
     if cache and os.path.exists(cache):
@@ -93,14 +94,11 @@ def main():
     ctx.set_stream(stream.cuda_stream)            # launches, events and the RCCL gather share one stream
     results = torch.zeros((B, pkg.STEP_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     pose_off = pkg.STEP_DTYPE.fields["pose"][1]
-    gather_buf = ([torch.zeros((B, 16), dtype=torch.float64, device=dev) for _ in range(world)]
-                  if (world > 1 and rank == 0) else None)
 
     def step():
         ctx.track_batch(Lv, Rv, results=results)
-        if world > 1:
-            poses = results[:, pose_off:pose_off + 128].contiguous().view(torch.float64).view(B, 16)
-            dist.gather(poses, gather_buf, dst=0)
+        if world > 1:      # the only inter-GPU traffic: 16 doubles per pair to rank 0 (RCCL gather)
+            mg.gather_poses(mg.poses_view(results, pose_off, B), rank, world, dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -119,10 +117,7 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = mg.max_over_ranks(elapsed, dev, world)
 
     stage_ms = dict(ctx.get_timing()) if not args.no_timing_marks else {}
     ctx.enable_timing(False)

@@ -1,0 +1,72 @@
+"""N > 1 path on CPU: world-size-2 gloo run of the sharding / pose-gather / max-over-ranks helpers
+bench.py uses with RCCL on the GPUs (no GPU here, so the tracked poses are stand-ins)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import conftest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    entry = conftest.entry
+    entry.load_package()
+    import importlib
+    mg = importlib.import_module(entry.PKG_NAME + ".multigpu")
+    b = importlib.import_module(entry.PKG_NAME + ".binding")
+    n = 6
+    # packed svo_step_result records whose pose field encodes (rank, pair)
+    rec = np.zeros(n, dtype=b.STEP_DTYPE)
+    for p in range(n):
+        rec["pose"][p] = np.arange(16) + 100 * rank + 1000 * p
+    raw = torch.from_numpy(np.frombuffer(rec.tobytes(), dtype=np.uint8).reshape(n, b.STEP_DTYPE.itemsize).copy())
+    poses = mg.poses_view(raw, b.STEP_DTYPE.fields["pose"][1], n)
+    got = mg.gather_poses(poses, rank, world, dst=0)
+    tmax = mg.max_over_ranks(1.0 + rank, torch.device("cpu"), world)
+    mine = mg.shard_sequences(len(mg.KITTI_LENGTHS), world, rank)
+    ok = tmax == float(world)
+    if rank == 0:
+        ok = ok and len(got) == world
+        for r in range(world):
+            exp = np.stack([np.arange(16) + 100 * r + 1000 * p for p in range(n)]).astype(np.float64)
+            ok = ok and np.array_equal(got[r].numpy(), exp)
+    else:
+        ok = ok and got is None
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(f"{int(ok)} {mg.sequence_seed(rank, world)} {','.join(map(str, mine))}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pose_gather_and_sharding_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = open(tmp_path / "rank0.txt").read().split()
+    r1 = open(tmp_path / "rank1.txt").read().split()
+    assert r0[0] == "1" and r1[0] == "1"
+    assert (r0[1], r1[1]) == ("100", "101")                      # one synthetic sequence per rank
+    assert r0[2] == "0,2,4,6" and r1[2] == "1,3,5,7"             # KITTI 00-07 dealt round-robin
+
+
+def test_single_rank_is_identity(pkg):
+    import importlib
+    mg = importlib.import_module(conftest.entry.PKG_NAME + ".multigpu")
+    p = torch.arange(32, dtype=torch.float64).view(2, 16)
+    assert mg.gather_poses(p, 0, 1)[0] is p
+    assert mg.max_over_ranks(2.5, torch.device("cpu"), 1) == 2.5
+    assert mg.sequence_seed(0, 1) == 20200710
+    assert mg.shard_sequences(8, 1, 0) == list(range(8))
