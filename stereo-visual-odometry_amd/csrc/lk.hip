@@ -4,28 +4,33 @@
 // as called four times per frame by Tracking::LK_Robust_Find_MuliImage_MatchedFeatures
 // (reference src/tracking.cpp:583-622), plus the deleteBadmatchFeatures predicate (:623-660).
 //
-// Mapping: ONE WAVEFRONT PER POINT, four points per 256-thread workgroup, no workgroup barrier
-// (each wave owns a private LDS region, so waves with different iteration counts never wait on
-// each other).  With ncalls == 4 the same wave walks the whole circular chain
-// L1 -> R1 -> R2 -> L2 -> L1' for its point, keeping the running point in registers.
-//
-// Per pyramid level (coarse to fine):
-//   * the 24x24 source tile of I (window + bilinear + Scharr reach) is gathered from the padded
-//     level with 4-byte aligned coalesced loads into LDS;
-//   * lane l owns window row l/3, columns (l%3)*7..+6 (63 lanes x 7 px = 441 px).  It reads its
-//     4 rows x 10 bytes of the tile, forms the Scharr derivatives of the 2x8 positions it
-//     interpolates from ON THE FLY with packed 16-bit math (the reference path materialises a
-//     full int16x2 derivative image per level per call; here it never exists, not even in LDS),
-//     and interpolates I, Ix, Iy with v_dot2_i32_i16; the patch stays in VGPRs for all iterations;
-//   * each iteration reads the lane's two 8-byte J row segments from an LDS-staged 40x32 J tile
-//     (re-gathered only when the window drifts out of it), forms the four-tap fixed-point
-//     bilinear samples with two v_dot4_u32_u8 per pixel (14-bit weights split into bytes), the
-//     two mismatch sums with 24-bit MADs, and reduces them across the wave with DPP adds.
+// Mapping: ONE WAVEFRONT TRACKS FOUR POINTS ("slots"), four waves per workgroup, no workgroup
+// barrier.  The kernel is VALU-issue bound (rocprofv3: ~100 % VALU busy, tiles come from L2), and
+// more than half of a one-point-per-wave iteration is per-point SCALAR work (window position,
+// bilinear weights, 2x2 solve, convergence tests) that a wave executes as full vector
+// instructions.  Here that scalar work is done once for four points: lane l carries the control
+// state of slot (l >> 2) & 3, so one vector instruction advances all four points, while the pixel
+// work is done slot after slot by all 63 pixel lanes:
+//   * lane l owns window row l/3, columns (l%3)*7..+6 of EVERY slot (63 lanes x 7 px = 441 px);
+//   * per level, per slot: the 24x24 source tile of I is gathered into LDS with 4-byte aligned
+//     loads; the lane reads its 4 rows x 10 bytes, forms the Scharr derivatives of the 2x8
+//     positions it interpolates from ON THE FLY with packed 16-bit math (the reference path
+//     materialises a full int16x2 derivative image per level per call), interpolates I, Ix, Iy with
+//     v_dot2_i32_i16 and keeps the patch as 12 packed VGPRs per slot;
+//   * per iteration, per active slot: two 8-byte J row segments from a 40x32 LDS tile (re-gathered
+//     only when the window drifts out of it), four-tap bilinear samples with two v_dot4_u32_u8 per
+//     pixel (14-bit weights split into byte planes), packed differences and v_dot2 mismatch sums;
+//   * the 16 partial sums of an iteration (4 slots x {b1,b2} x {low,high half}) are reduced with ONE
+//     reduce-scatter (DPP quad/row exchanges + v_permlane16/32_swap) that leaves slot s's four
+//     sums in quad s, exactly where that slot's control lanes need them.
+// With ncalls == 4 the wave walks the whole circular chain L1 -> R1 -> R2 -> L2 -> L1' for its
+// four points and stops early once all of them are rejected.
 //
 // Exactness: all pixel arithmetic is upstream's fixed point (14-bit weights, 5 fractional bits);
 // the five sums A11,A12,A22,b1,b2 are accumulated as exact integers (per-lane int32 partials,
-// 64-bit recombination) and converted to float once -- the canonical recipe of oracle/lk.c, so
-// status bytes and point coordinates are bit-identical to the oracle.  FP contraction is off.
+// 16-bit halves reduced separately, recombined through one exact double) and converted to float
+// once -- the canonical recipe of oracle/lk.c, so status bytes and point coordinates are
+// bit-identical to the oracle.  FP contraction is off.
 //
 // Algorithmic HBM bytes (SURVEY.md 8d gather convention): per point per call
 //   sum over 4 levels (24*24 + 22*22) + 8 in + 8 out + 1 status = 4257 B.
@@ -35,9 +40,12 @@
 
 namespace svo {
 
+constexpr int kSlots = 4;                                 // points per wave
 constexpr int kTileIRows = 24, kTileIDw = 8;              // 24 rows x 32 bytes (28 used)
 constexpr int kTileJRows = 32, kTileJDw = 10;             // 32 rows x 40 bytes
-constexpr int kLdsDwPerWave = kTileIRows * kTileIDw + kTileJRows * kTileJDw;   // 512 dwords
+constexpr int kSlotDw = kTileJRows * kTileJDw;            // 320 dwords: the I tile (192) and the J tile
+                                                          // of a slot alias (I is dead once the patch is in VGPRs)
+constexpr int kLdsDwPerWave = kSlots * kSlotDw;           // 1280 dwords = 5 KB
 constexpr int W_BITS = 14;
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -74,6 +82,7 @@ __device__ __forceinline__ Weights bilinear_weights(float a, float b)
 }
 
 // 12 aligned bytes starting at byte offset `off` of an LDS row of dwords: bytes 0-3, 4-7, 8-11
+// (aligned dword reads + v_alignbyte: unaligned ds_read_b64 measured 15 % slower end to end)
 __device__ __forceinline__ void load12(const uint32_t *row, int off, uint32_t &lo, uint32_t &mid, uint32_t &hi)
 {
     const uint32_t *p = row + (off >> 2);
@@ -103,210 +112,278 @@ __device__ __forceinline__ bool window_oob(int ix, int iy, int w, int h)
 __device__ __forceinline__ uint32_t pair01(uint32_t x) { return perm_b32(0, x, 0x0c010c00u); }
 __device__ __forceinline__ uint32_t pair23(uint32_t x) { return perm_b32(0, x, 0x0c030c02u); }
 
-// One cv::calcOpticalFlowPyrLK call for one point, executed by one wave.
-__device__ __forceinline__ void lk_call(const PyrGeom &g, const uint8_t *slotI, const uint8_t *slotJ, float2 prevPt,
-                                     float2 &outPt, int &status, uint32_t *lds, int lane)
-{
-    uint32_t *tileI = lds;
-    uint32_t *tileJ = lds + kTileIRows * kTileIDw;
 
-    const int row = min(lane / 3, kWin - 1), seg = lane - (lane / 3) * 3;
-    const bool lane_on = lane < 63;
+// per-lane constants of the pixel role
+struct PixLane { int row, seg; bool on; };
+
+// ---- phase A for one slot: this lane's 7 patch pixels from the staged I tile -------------------
+// Tile rows row..row+3 = image rows ipy+row-1..ipy+row+2, bytes j = 0..9 = image columns
+// ipx-1+seg*7+j; everything is packed u16/i16 pairs m = (column 2m, column 2m+1).
+// Outputs: packed patch (Iv, Ix, Iy as 4 pairs each; pair 3 has a zero high half) and the three
+// partial sums of Ix^2, Ix*Iy, Iy^2.
+__device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane &pl, int offI, uint32_t W01u,
+                                           uint32_t W23u, int ipx, int ipy, int w, int h,
+                                           uint32_t (&IvP)[4], uint32_t (&IxP)[4], uint32_t (&IyP)[4],
+                                           int &pA11, int &pA12, int &pA22)
+{
+    // (lane 63 carries no window pixel: zero weights make its I, Ix, Iy and sums vanish)
+    const uint32_t W01 = pl.on ? W01u : 0u, W23 = pl.on ? W23u : 0u;
+    uint32_t P[4][5];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        uint32_t lo, mid, hi;
+        load12(tileI + (pl.row + r) * kTileIDw, offI + pl.seg * 7, lo, mid, hi);
+        P[r][0] = pair01(lo); P[r][1] = pair23(lo); P[r][2] = pair01(mid); P[r][3] = pair23(mid);
+        P[r][4] = pair01(hi);
+    }
+    // vertical Scharr passes for derivative rows A (image row ipy+row) and B (ipy+row+1)
+    uint32_t T0A[5], T1A[5], T0B[5], T1B[5];
+    const u16x2 k3 = {3, 3}, k10 = {10, 10};
+#pragma unroll
+    for (int m = 0; m < 5; m++) {
+        u16x2 p0 = as_u16x2(P[0][m]), p1 = as_u16x2(P[1][m]), p2 = as_u16x2(P[2][m]), p3 = as_u16x2(P[3][m]);
+        T0A[m] = as_u32((p0 + p2) * k3 + p1 * k10);
+        T1A[m] = as_u32(p2 - p0);
+        T0B[m] = as_u32((p1 + p3) * k3 + p2 * k10);
+        T1B[m] = as_u32(p3 - p1);
+    }
+    // horizontal passes: derivative positions c = 0..7 (image column ipx+seg*7+c) as pairs
+    uint32_t DXA[4], DYA[4], DXB[4], DYB[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        DXA[m] = as_u32(as_u16x2(T0A[m + 1]) - as_u16x2(T0A[m]));
+        DXB[m] = as_u32(as_u16x2(T0B[m + 1]) - as_u16x2(T0B[m]));
+        u16x2 qa = as_u16x2(alignbit16(T1A[m + 1], T1A[m]));
+        u16x2 qb = as_u16x2(alignbit16(T1B[m + 1], T1B[m]));
+        DYA[m] = as_u32((as_u16x2(T1A[m]) + as_u16x2(T1A[m + 1])) * k3 + qa * k10);
+        DYB[m] = as_u32((as_u16x2(T1B[m]) + as_u16x2(T1B[m + 1])) * k3 + qb * k10);
+    }
+    // the derivative image's border is BORDER_CONSTANT 0: mask positions outside the image
+    // (only possible when the window hangs over the edge; uniform branch)
+    if (ipx < 0 || ipx + kWin >= w || ipy < 0 || ipy + kWin >= h) {
+        const int gyA = ipy + pl.row, gyB = gyA + 1;
+        const uint32_t rowA = (gyA >= 0 && gyA < h) ? 0xFFFFFFFFu : 0u;
+        const uint32_t rowB = (gyB >= 0 && gyB < h) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int gx = ipx + pl.seg * 7 + 2 * m;
+            uint32_t cm = ((gx >= 0 && gx < w) ? 0x0000FFFFu : 0u) | ((gx + 1 >= 0 && gx + 1 < w) ? 0xFFFF0000u : 0u);
+            DXA[m] &= cm & rowA; DYA[m] &= cm & rowA;
+            DXB[m] &= cm & rowB; DYB[m] &= cm & rowB;
+        }
+    }
+    int iv[8], ix[8], iy[8];
+    iv[7] = ix[7] = iy[7] = 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const int m = k >> 1;
+        uint32_t dxa, dya, dxb, dyb, i1, i2;
+        if ((k & 1) == 0) {
+            dxa = DXA[m]; dya = DYA[m]; dxb = DXB[m]; dyb = DYB[m];
+            i1 = alignbit16(P[1][m + 1], P[1][m]);          // intensity bytes j = k+1, k+2
+            i2 = alignbit16(P[2][m + 1], P[2][m]);
+        } else {
+            dxa = alignbit16(DXA[m + 1], DXA[m]); dya = alignbit16(DYA[m + 1], DYA[m]);
+            dxb = alignbit16(DXB[m + 1], DXB[m]); dyb = alignbit16(DYB[m + 1], DYB[m]);
+            i1 = P[1][m + 1]; i2 = P[2][m + 1];
+        }
+        iv[k] = dot2(i2, W23, dot2(i1, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+        ix[k] = dot2(dxb, W23, dot2(dxa, W01, 1 << (W_BITS - 1))) >> W_BITS;
+        iy[k] = dot2(dyb, W23, dot2(dya, W01, 1 << (W_BITS - 1))) >> W_BITS;
+    }
+    pA11 = 0; pA12 = 0; pA22 = 0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        IvP[m] = perm_b32((uint32_t)iv[2 * m + 1], (uint32_t)iv[2 * m], 0x05040100u);
+        IxP[m] = perm_b32((uint32_t)ix[2 * m + 1], (uint32_t)ix[2 * m], 0x05040100u);
+        IyP[m] = perm_b32((uint32_t)iy[2 * m + 1], (uint32_t)iy[2 * m], 0x05040100u);
+        pA11 = dot2(IxP[m], IxP[m], pA11);
+        pA12 = dot2(IxP[m], IyP[m], pA12);
+        pA22 = dot2(IyP[m], IyP[m], pA22);
+    }
+}
+
+// ---- one iteration's pixel work for one slot --------------------------------------------------
+// Column words C_j = (J[r0][j] | J[r1][j] << 16) pair the two window rows, so a bilinear sample is
+//   val_k = dot2(C_k, (w00 | w10 << 16)) + dot2(C_k+1, (w01 | w11 << 16)) + 2^8
+// (signed 16-bit weights: w11 == -1 needs no special case).
+__device__ __forceinline__ void mismatch_slot(const uint32_t *tileJ, const PixLane &pl, int cx, int cy,
+                                              uint32_t Wa, uint32_t Wb, const uint32_t (&IvP)[4],
+                                              const uint32_t (&IxP)[4], const uint32_t (&IyP)[4], int &pb1, int &pb2)
+{
+    uint32_t a0, b0, a1, b1;                 // row 0 / row 1: bytes 0-3 (a), 4-7 (b)
+    load8(tileJ + (cy + pl.row) * kTileJDw, cx + pl.seg * 7, a0, b0);
+    load8(tileJ + (cy + pl.row + 1) * kTileJDw, cx + pl.seg * 7, a1, b1);
+    uint32_t C[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        C[j] = perm_b32(a1, a0, 0x0c040c00u + 0x00010001u * j);
+        C[4 + j] = perm_b32(b1, b0, 0x0c040c00u + 0x00010001u * j);
+    }
+    uint32_t v[8];
+    v[7] = 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+        v[k] = (uint32_t)(dot2(C[k + 1], Wb, dot2(C[k], Wa, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5));
+    pb1 = 0; pb2 = 0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const uint32_t vp = m < 3 ? perm_b32(v[2 * m + 1], v[2 * m], 0x05040100u) : v[6];
+        const uint32_t dp = as_u32(as_u16x2(vp) - as_u16x2(IvP[m]));      // packed J - I (13-bit magnitudes)
+        pb1 = dot2(dp, IxP[m], pb1);
+        pb2 = dot2(dp, IyP[m], pb2);
+    }
+}
+
+// One cv::calcOpticalFlowPyrLK call for the wave's four points.  Control values (prevPt, outPt,
+// status, live) are per lane = per slot (lane >> 2) & 3.
+__device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI, const uint8_t *slotJ, float2 prevPt,
+                                         float2 &outPt, int &status, bool live, uint32_t *lds, int lane)
+{
+    PixLane pl;
+    pl.row = min(lane / 3, kWin - 1); pl.seg = lane - (lane / 3) * 3; pl.on = lane < 63;
     const float half = 10.f;                     // (winSize - 1) * 0.5
     const float FLT_SCALE = 1.f / (1 << 20);
 
+    uint32_t IvP[kSlots][4], IxP[kSlots][4], IyP[kSlots][4];
     status = 1;
     float nx = 0.f, ny = 0.f;                    // nextPts[i]
     for (int level = g.nlevels - 1; level >= 0; --level) {
         const int w = g.w[level], h = g.h[level], pitch = g.pitch[level];
         const uint8_t *I = slotI + g.origin[level];
         const uint8_t *J = slotJ + g.origin[level];
+        // ---- control: window position and weights of every slot
         const float lscale = 1.f / (float)(1 << level);
         float px = prevPt.x * lscale, py = prevPt.y * lscale;
         if (level == g.nlevels - 1) { nx = px; ny = py; }
         else { nx = nx * 2.f; ny = ny * 2.f; }
         px -= half; py -= half;
         const int ipx = cv_floor(px), ipy = cv_floor(py);
-        if (window_oob(ipx, ipy, w, h)) {
-            if (level == 0) status = 0;
-            continue;
-        }
+        const bool oob = window_oob(ipx, ipy, w, h);
+        if (live && oob && level == 0) status = 0;
+        bool lvl_on = live && !oob;
         const Weights wt = bilinear_weights(px - (float)ipx, py - (float)ipy);
-        // (lane 63 carries no window pixel: zero weights make its I, Ix, Iy and sums vanish)
-        const uint32_t W01 = lane_on ? ((uint32_t)wt.w00 | ((uint32_t)wt.w01 << 16)) : 0u;
-        const uint32_t W23 = lane_on ? ((uint32_t)wt.w10 | ((uint32_t)wt.w11 << 16)) : 0u;
-
-        // ---- gather the 24x24 I tile (rows ipy-1.., columns from the aligned x0 <= ipx-1)
+        const uint32_t W01 = (uint32_t)wt.w00 | ((uint32_t)wt.w01 << 16);
+        const uint32_t W23 = (uint32_t)wt.w10 | ((uint32_t)wt.w11 << 16);
         const int x0 = (ipx - 1) & ~3;
         const int offI = (ipx - 1) - x0;
-        for (int i = lane; i < kTileIRows * kTileIDw; i += kWave) {
-            int r = i >> 3, c = i & 7;
-            uint32_t v = 0;
-            if (c < 7) v = *(const uint32_t *)(I + (int64_t)(ipy - 1 + r) * pitch + x0 + 4 * c);
-            tileI[i] = v;
+
+        // ---- gather the 24x24 I tile of every active slot
+        const unsigned long long m_on = __ballot(lvl_on);
+#pragma unroll
+        for (int s = 0; s < kSlots; s++) {
+            if (!((m_on >> (4 * s)) & 1ull)) continue;
+            const int x0s = __builtin_amdgcn_readlane(x0, 4 * s), ipys = __builtin_amdgcn_readlane(ipy, 4 * s);
+            uint32_t *tile = lds + s * kSlotDw;
+            const uint8_t *base = I + (int64_t)(ipys - 1) * pitch + x0s;
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int i = lane + 64 * t, r = i >> 3, c = i & 7;
+                uint32_t v = 0;
+                if (c < 7) v = *(const uint32_t *)(base + (int64_t)r * pitch + 4 * c);
+                tile[i] = v;
+            }
         }
         wave_lds_fence();
 
-        // ---- this lane's 7 patch pixels.  Tile rows row..row+3 = image rows ipy+row-1..ipy+row+2,
-        //      bytes j = 0..9 = image columns ipx-1+seg*7+j.  Everything below is packed u16/i16
-        //      pairs m = (column 2m, column 2m+1).
-        int Iv[7], Ix[7], Iy[7];
-        int pA11 = 0, pA12 = 0, pA22 = 0;
-        {
-            uint32_t P[4][5];
+        // ---- patches + A sums
+        int pA[kSlots][3];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                uint32_t lo, mid, hi;
-                load12(tileI + (row + r) * kTileIDw, offI + seg * 7, lo, mid, hi);
-                P[r][0] = pair01(lo); P[r][1] = pair23(lo); P[r][2] = pair01(mid); P[r][3] = pair23(mid);
-                P[r][4] = pair01(hi);
-            }
-            // vertical Scharr passes for derivative rows A (image row ipy+row) and B (ipy+row+1)
-            uint32_t T0A[5], T1A[5], T0B[5], T1B[5];
-#pragma unroll
-            for (int m = 0; m < 5; m++) {
-                u16x2 p0 = as_u16x2(P[0][m]), p1 = as_u16x2(P[1][m]), p2 = as_u16x2(P[2][m]), p3 = as_u16x2(P[3][m]);
-                const u16x2 k3 = {3, 3}, k10 = {10, 10};
-                T0A[m] = as_u32((p0 + p2) * k3 + p1 * k10);
-                T1A[m] = as_u32(p2 - p0);
-                T0B[m] = as_u32((p1 + p3) * k3 + p2 * k10);
-                T1B[m] = as_u32(p3 - p1);
-            }
-            // horizontal passes: derivative positions c = 0..7 (image column ipx+seg*7+c) as pairs
-            uint32_t DXA[4], DYA[4], DXB[4], DYB[4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const u16x2 k3 = {3, 3}, k10 = {10, 10};
-                DXA[m] = as_u32(as_u16x2(T0A[m + 1]) - as_u16x2(T0A[m]));
-                DXB[m] = as_u32(as_u16x2(T0B[m + 1]) - as_u16x2(T0B[m]));
-                u16x2 qa = as_u16x2(alignbit16(T1A[m + 1], T1A[m]));
-                u16x2 qb = as_u16x2(alignbit16(T1B[m + 1], T1B[m]));
-                DYA[m] = as_u32((as_u16x2(T1A[m]) + as_u16x2(T1A[m + 1])) * k3 + qa * k10);
-                DYB[m] = as_u32((as_u16x2(T1B[m]) + as_u16x2(T1B[m + 1])) * k3 + qb * k10);
-            }
-            // the derivative image's border is BORDER_CONSTANT 0: mask positions outside the image
-            // (only possible when the window hangs over the edge)
-            if (ipx < 0 || ipx + kWin >= w || ipy < 0 || ipy + kWin >= h) {
-                const int gyA = ipy + row, gyB = gyA + 1;
-                const uint32_t rowA = (gyA >= 0 && gyA < h) ? 0xFFFFFFFFu : 0u;
-                const uint32_t rowB = (gyB >= 0 && gyB < h) ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const int gx = ipx + seg * 7 + 2 * m;
-                    uint32_t cm = ((gx >= 0 && gx < w) ? 0x0000FFFFu : 0u) | ((gx + 1 >= 0 && gx + 1 < w) ? 0xFFFF0000u : 0u);
-                    DXA[m] &= cm & rowA; DYA[m] &= cm & rowA;
-                    DXB[m] &= cm & rowB; DYB[m] &= cm & rowB;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 7; k++) {
-                const int m = k >> 1;
-                uint32_t dxa, dya, dxb, dyb, i1, i2;
-                if ((k & 1) == 0) {
-                    dxa = DXA[m]; dya = DYA[m]; dxb = DXB[m]; dyb = DYB[m];
-                    // intensity bytes j = k+1, k+2: an odd-aligned pair
-                    i1 = alignbit16(P[1][m + 1], P[1][m]);
-                    i2 = alignbit16(P[2][m + 1], P[2][m]);
-                } else {
-                    dxa = alignbit16(DXA[m + 1], DXA[m]); dya = alignbit16(DYA[m + 1], DYA[m]);
-                    dxb = alignbit16(DXB[m + 1], DXB[m]); dyb = alignbit16(DYB[m + 1], DYB[m]);
-                    i1 = P[1][m + 1]; i2 = P[2][m + 1];
-                }
-                int ival = dot2(i2, W23, dot2(i1, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-                int ixv = dot2(dxb, W23, dot2(dxa, W01, 1 << (W_BITS - 1))) >> W_BITS;
-                int iyv = dot2(dyb, W23, dot2(dya, W01, 1 << (W_BITS - 1))) >> W_BITS;
-                Iv[k] = ival; Ix[k] = ixv; Iy[k] = iyv;
-                pA11 += __mul24(ixv, ixv); pA12 += __mul24(ixv, iyv); pA22 += __mul24(iyv, iyv);
-            }
+        for (int s = 0; s < kSlots; s++) {
+            pA[s][0] = pA[s][1] = pA[s][2] = 0;
+            if (!((m_on >> (4 * s)) & 1ull)) continue;
+            const int offIs = __builtin_amdgcn_readlane(offI, 4 * s);
+            const uint32_t W01s = __builtin_amdgcn_readlane(W01, 4 * s), W23s = __builtin_amdgcn_readlane(W23, 4 * s);
+            const int ipxs = __builtin_amdgcn_readlane(ipx, 4 * s), ipys = __builtin_amdgcn_readlane(ipy, 4 * s);
+            patch_slot(lds + s * kSlotDw, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IvP[s], IxP[s], IyP[s],
+                       pA[s][0], pA[s][1], pA[s][2]);
         }
-        int s11l, s11h, s12l, s12h, s22l, s22h;
-        wave_sum4_i32(lane, pA11 & 0xFFFF, pA11 >> 16, pA12 & 0xFFFF, pA12 >> 16, s11l, s11h, s12l, s12h);
-        wave_sum2_i32(lane, pA22 & 0xFFFF, pA22 >> 16, s22l, s22h);
-        const float A11 = wide_to_f32(s11h, s11l) * FLT_SCALE;
-        const float A12 = wide_to_f32(s12h, s12l) * FLT_SCALE;
-        const float A22 = wide_to_f32(s22h, s22l) * FLT_SCALE;
-        float D = A11 * A22 - A12 * A12;
+        wave_lds_fence();                        // the J tiles reuse the I tiles' LDS
+        float A11, A12, A22, D;
+        {
+            int v1[8], v2[8];
+#pragma unroll
+            for (int s = 0; s < kSlots; s++) {
+                v1[2 * s] = pA[s][0]; v1[2 * s + 1] = pA[s][1];
+                v2[2 * s] = pA[s][2]; v2[2 * s + 1] = 0;
+            }
+            const int r1 = reduce_scatter8_wide(v1, lane), r2 = reduce_scatter8_wide(v2, lane);
+            A11 = wide_to_f32(quad_bcast<2>(r1), quad_bcast<0>(r1)) * FLT_SCALE;
+            A12 = wide_to_f32(quad_bcast<3>(r1), quad_bcast<1>(r1)) * FLT_SCALE;
+            A22 = wide_to_f32(quad_bcast<2>(r2), quad_bcast<0>(r2)) * FLT_SCALE;
+        }
+        D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
                              (float)(2 * kWin * kWin);
-        if (minEig < 0.001f || D < 1.1920929e-07f) {
-            if (level == 0) status = 0;
-            continue;
-        }
+        const bool degenerate = minEig < 0.001f || D < 1.1920929e-07f;
+        if (lvl_on && degenerate && level == 0) status = 0;
+        lvl_on = lvl_on && !degenerate;
         D = 1.f / D;
 
-        // ---- iterations
+        // ---- iterations (all slots in lockstep; a slot drops out when it converges or leaves)
         float qx = nx - half, qy = ny - half;       // nextPt - halfWin
         float pdx = 0.f, pdy = 0.f;
         int tx0 = -(1 << 20), ty0 = 0;                // no J tile staged yet
+        bool it_on = lvl_on;
         for (int j = 0; j < kLkMaxIter; j++) {
+            if (!__any(it_on)) break;
             const int inx = cv_floor(qx), iny = cv_floor(qy);
-            if (window_oob(inx, iny, w, h)) {
+            if (it_on && window_oob(inx, iny, w, h)) {
                 if (level == 0) status = 0;
-                break;
+                it_on = false;
             }
-            Weights wj = bilinear_weights(qx - (float)inx, qy - (float)iny);
-            // w11 = 2^14 - (three rounded products) can come out as -1 (never lower); the byte-plane
-            // dot products need non-negative weights, so that case is corrected with J11 afterwards
-            const bool w11neg = wj.w11 < 0;
-            if (w11neg) wj.w11 = 0;
-            // weights as byte planes for v_dot4_u32_u8: taps (J00, J01, J10, J11)
-            const uint32_t p01 = (uint32_t)wj.w00 | ((uint32_t)wj.w01 << 16);
-            const uint32_t p23 = (uint32_t)wj.w10 | ((uint32_t)wj.w11 << 16);
-            const uint32_t WL = perm_b32(p23, p01, 0x06040200u);
-            const uint32_t WH = perm_b32(p23, p01, 0x07050301u);
+            const Weights wj = bilinear_weights(qx - (float)inx, qy - (float)iny);
+            const uint32_t Wa = ((uint32_t)wj.w00 & 0xFFFFu) | ((uint32_t)wj.w10 << 16);
+            const uint32_t Wb = ((uint32_t)wj.w01 & 0xFFFFu) | ((uint32_t)wj.w11 << 16);
             int cx = inx - tx0, cy = iny - ty0;
-            if ((unsigned)cx > 17u || (unsigned)cy > 10u) {
-                tx0 = (inx - 8) & ~3; ty0 = iny - 5;
-                for (int i = lane; i < kTileJRows * kTileJDw; i += kWave) {
-                    int r = i / kTileJDw, c = i - r * kTileJDw;
-                    tileJ[i] = *(const uint32_t *)(J + (int64_t)(ty0 + r) * pitch + tx0 + 4 * c);
-                }
-                wave_lds_fence();
-                cx = inx - tx0; cy = iny - ty0;
-            }
-            uint32_t a0, b0, a1, b1;                 // row 0 / row 1: bytes 0-3 (a), 4-7 (b)
-            load8(tileJ + (cy + row) * kTileJDw, cx + seg * 7, a0, b0);
-            load8(tileJ + (cy + row + 1) * kTileJDw, cx + seg * 7, a1, b1);
-            const uint32_t m0 = __builtin_amdgcn_alignbyte(b0, a0, 2);      // bytes 2-5
-            const uint32_t m1 = __builtin_amdgcn_alignbyte(b1, a1, 2);
-            int pb1 = 0, pb2 = 0;
-            auto pixels = [&](auto neg) {
+            const bool restage = it_on && ((unsigned)cx > 17u || (unsigned)cy > 10u);
+            if (restage) { tx0 = (inx - 8) & ~3; ty0 = iny - 5; cx = inx - tx0; cy = iny - ty0; }
+            const unsigned long long m_it = __ballot(it_on), m_rs = __ballot(restage);
+            int pb[kSlots][2];
 #pragma unroll
-                for (int k = 0; k < 7; k++) {
-                    // T = (J[r0][k], J[r0][k+1], J[r1][k], J[r1][k+1])
-                    uint32_t T;
-                    if (k < 3) T = perm_b32(a1, a0, 0x05040100u + 0x01010101u * k);
-                    else if (k == 3) T = perm_b32(m1, m0, 0x06050201u);
-                    else T = perm_b32(b1, b0, 0x05040100u + 0x01010101u * (k - 4));
-                    uint32_t vlo = __builtin_amdgcn_udot4(T, WL, 1u << (W_BITS - 5 - 1), false);
-                    uint32_t vhi = __builtin_amdgcn_udot4(T, WH, 0u, false);
-                    uint32_t val = (vhi << 8) + vlo;
-                    if (decltype(neg)::value) val -= T >> 24;        // w11 == -1
-                    int diff = (int)(val >> (W_BITS - 5)) - Iv[k];
-                    pb1 += __mul24(diff, Ix[k]);
-                    pb2 += __mul24(diff, Iy[k]);
+            for (int s = 0; s < kSlots; s++) {
+                pb[s][0] = pb[s][1] = 0;
+                if (!((m_it >> (4 * s)) & 1ull)) continue;
+                uint32_t *tile = lds + s * kSlotDw;
+                if ((m_rs >> (4 * s)) & 1ull) {
+                    const int tx0s = __builtin_amdgcn_readlane(tx0, 4 * s), ty0s = __builtin_amdgcn_readlane(ty0, 4 * s);
+                    const uint8_t *base = J + (int64_t)ty0s * pitch + tx0s;
+#pragma unroll
+                    for (int t = 0; t < 5; t++) {
+                        const int i = lane + 64 * t, r = i / kTileJDw, c = i - r * kTileJDw;
+                        tile[i] = *(const uint32_t *)(base + (int64_t)r * pitch + 4 * c);
+                    }
+                    wave_lds_fence();
                 }
-            };
-            if (__builtin_expect(w11neg, 0)) pixels(std::true_type{});
-            else pixels(std::false_type{});
-            int s1l, s1h, s2l, s2h;
-            wave_sum4_i32(lane, pb1 & 0xFFFF, pb1 >> 16, pb2 & 0xFFFF, pb2 >> 16, s1l, s1h, s2l, s2h);
-            const float b1f = wide_to_f32(s1h, s1l) * FLT_SCALE;
-            const float b2f = wide_to_f32(s2h, s2l) * FLT_SCALE;
+                const int cxs = __builtin_amdgcn_readlane(cx, 4 * s), cys = __builtin_amdgcn_readlane(cy, 4 * s);
+                const uint32_t Was = __builtin_amdgcn_readlane(Wa, 4 * s), Wbs = __builtin_amdgcn_readlane(Wb, 4 * s);
+                mismatch_slot(tile, pl, cxs, cys, Was, Wbs, IvP[s], IxP[s], IyP[s], pb[s][0], pb[s][1]);
+            }
+            float b1f, b2f;
+            {
+                int v[8];
+#pragma unroll
+                for (int s = 0; s < kSlots; s++) { v[2 * s] = pb[s][0]; v[2 * s + 1] = pb[s][1]; }
+                const int r = reduce_scatter8_wide(v, lane);       // quad s: {b1.lo, b2.lo, b1.hi, b2.hi} of slot s
+                b1f = wide_to_f32(quad_bcast<2>(r), quad_bcast<0>(r)) * FLT_SCALE;
+                b2f = wide_to_f32(quad_bcast<3>(r), quad_bcast<1>(r)) * FLT_SCALE;
+            }
             const float dlx = (A12 * b2f - A22 * b1f) * D;
             const float dly = (A12 * b1f - A11 * b2f) * D;
-            qx += dlx; qy += dly;
-            nx = qx + half; ny = qy + half;
-            if ((double)dlx * (double)dlx + (double)dly * (double)dly <= 0.01 * 0.01) break;
-            // "std::abs(delta.x + prevDelta.x) < 0.01" compares a float with the double 0.01; the
-            // largest float below 0.01 is 0.01f itself, so "<= 0.01f" in float is the same predicate
-            if (j > 0 && fabsf(dlx + pdx) <= 0.01f && fabsf(dly + pdy) <= 0.01f) {
-                nx -= dlx * 0.5f; ny -= dly * 0.5f;
-                break;
+            if (it_on) {
+                qx += dlx; qy += dly;
+                nx = qx + half; ny = qy + half;
+                if ((double)dlx * (double)dlx + (double)dly * (double)dly <= 0.01 * 0.01) it_on = false;
+                // "std::abs(delta.x + prevDelta.x) < 0.01" compares a float with the double 0.01; the
+                // largest float below 0.01 is 0.01f itself, so "<= 0.01f" in float is the same predicate
+                else if (j > 0 && fabsf(dlx + pdx) <= 0.01f && fabsf(dly + pdy) <= 0.01f) {
+                    nx -= dlx * 0.5f; ny -= dly * 0.5f;
+                    it_on = false;
+                }
+                pdx = dlx; pdy = dly;
             }
-            pdx = dlx; pdy = dly;
         }
-        if (status && level == 0) {
+        if (live && status && level == 0) {
             // err is requested by the reference: the final window must still be inside (A.4 step 7)
             int fx = cv_floor(nx - half), fy = cv_floor(ny - half);
             if (window_oob(fx, fy, w, h)) status = 0;
@@ -320,38 +397,46 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
     __shared__ uint32_t lds[4 * kLdsDwPerWave];
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int idx = blockIdx.x * 4 + wave;
+    const int slot = (lane >> 2) & 3;
     int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
     n = min(n, a.cap);
-    if (idx >= n) return;
+    const int first = (blockIdx.x * 4 + wave) * kSlots;
+    if (first >= n) return;
+    const int idx = first + slot;
+    const bool valid = idx < n;
+    const bool writer = valid && lane == 4 * slot;         // one lane per slot stores results
     uint32_t *my = lds + wave * kLdsDwPerWave;
-    const int64_t po = (int64_t)b * a.pts_stride + idx;
+    const int64_t po = (int64_t)b * a.pts_stride + (valid ? idx : first);
     const float2 p0 = a.pts_in[po];
     float2 cur = p0, nxt;
     bool outside = p0.x < 0 || p0.y < 0, bad = false, noepi = false;
+    bool live = valid;
     float prev_y = p0.y;
 #pragma nounroll
     for (int c = 0; c < a.ncalls; c++) {
         const uint8_t *sI = a.prev[c] + (int64_t)b * a.slot_stride;
         const uint8_t *sJ = a.next[c] + (int64_t)b * a.slot_stride;
         int st;
-        lk_call(a.g, sI, sJ, cur, nxt, st, my, lane);
-        if (lane == 0) {
+        lk_call4(a.g, sI, sJ, cur, nxt, st, live, my, lane);
+        if (writer && live) {
             a.pts_out[c][po] = nxt;
             a.status[c][po] = (uint8_t)st;
         }
         // Tracking::deleteBadmatchFeatures terms (p0 = t1_left, p1 = t1_right, p2 = t2_right,
         // p3 = t2_left, p0_return = LK#4 output; call-site mapping src/tracking.cpp:619-620)
-        outside = outside || nxt.x < 0 || nxt.y < 0;
-        bad = bad || st == 0;
-        if (c == 0 || c == 2) noepi = noepi || (double)fabsf(prev_y - nxt.y) > a.match_err;   // |y0-y1|, |y2-y3|
-        prev_y = nxt.y;
-        cur = nxt;
+        if (live) {
+            outside = outside || nxt.x < 0 || nxt.y < 0;
+            bad = bad || st == 0;
+            if (c == 0 || c == 2) noepi = noepi || (double)fabsf(prev_y - nxt.y) > a.match_err;   // |y0-y1|, |y2-y3|
+            prev_y = nxt.y;
+            cur = nxt;
+        }
         // a rejected point can never be kept: the remaining calls of the circular chain only feed
         // the keep predicate (their pts_out/status entries are scratch in the fused mode)
-        if (a.ncalls == 4 && (outside || bad || noepi)) break;
+        if (a.ncalls == 4 && (outside || bad || noepi)) live = false;
+        if (!__any(live)) break;
     }
-    if (a.ncalls == 4 && lane == 0) a.keep[po] = !(outside || bad || noepi);
+    if (a.ncalls == 4 && writer) a.keep[po] = !(outside || bad || noepi);
 }
 
 // Stable compaction (deleteBadmatchFeatures erases in place, preserving order): one workgroup of
@@ -391,7 +476,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(CompactArgs a)
 void launch_lk(const LkArgs &a, int batch, int max_pts, hipStream_t st)
 {
     if (max_pts <= 0 || batch <= 0) return;
-    dim3 grid((max_pts + 3) / 4, batch, 1), blk(256, 1, 1);
+    dim3 grid((max_pts + 4 * kSlots - 1) / (4 * kSlots), batch, 1), blk(256, 1, 1);
     hipLaunchKernelGGL(lk_kernel, grid, blk, 0, st, a);
 }
 

@@ -94,6 +94,79 @@ __device__ inline void wave_sum4_i32(int lane, int v0, int v1, int v2, int v3, i
     s3 = __builtin_amdgcn_readlane(k, 3);
 }
 
+// Reduce-scatter of 16 per-lane values: lane l returns the 64-lane total of value index (l & 15).
+// Steps: quad xor-1 and xor-2 exchanges, row_ror:4 / row_ror:8 exchanges (every lane keeps the
+// half of its values whose index bit matches its lane bit and hands the other half over), then an
+// all-reduce across the four rows.  51 cross-lane/select instructions for 16 sums.
+__device__ inline int reduce_scatter16_i32(const int (&v)[16], int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    int a[8], b[4], c[2];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int keep = b0 ? v[2 * i + 1] : v[2 * i], give = b0 ? v[2 * i] : v[2 * i + 1];
+        a[i] = keep + dpp_xor1(give);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int keep = b1 ? a[2 * i + 1] : a[2 * i], give = b1 ? a[2 * i] : a[2 * i + 1];
+        b[i] = keep + dpp_xor2(give);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        int keep = b2 ? b[2 * i + 1] : b[2 * i], give = b2 ? b[2 * i] : b[2 * i + 1];
+        c[i] = keep + dpp_ror4(give);
+    }
+    int keep = b3 ? c[1] : c[0], give = b3 ? c[0] : c[1];
+    int d = keep + dpp_ror8(give);
+    auto x = __builtin_amdgcn_permlane16_swap((unsigned)d, (unsigned)d, false, false);
+    d = (int)(x[0] + x[1]);
+    auto y = __builtin_amdgcn_permlane32_swap((unsigned)d, (unsigned)d, false, false);
+    return (int)(y[0] + y[1]);
+}
+
+// Reduce-scatter of 8 per-lane values v[2*slot + t] (slot 0..3, t 0..1) whose 64-lane totals may
+// exceed 32 bits (each |v| < 2^29).  Two exchange steps first add groups of four lanes in full
+// 32-bit precision; the 4-lane sums are then split into 16-bit halves, which are reduced
+// separately (their 64-lane totals fit easily).  On return the lane with bits (b3 b2 b1 b0) holds
+// the total of:   slot = 2*b3 + b2,   half = b1 (0: low 16 bits, 1: arithmetic high part),   t = b0
+// i.e. quad `slot` holds that slot's {t0.lo, t1.lo, t0.hi, t1.hi}.  37 cross-lane/select ops.
+__device__ inline int reduce_scatter8_wide(const int (&v)[8], int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    int a[4], c[2], h[4], e[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {                          // split on t: a[slot]
+        int keep = b0 ? v[2 * i + 1] : v[2 * i], give = b0 ? v[2 * i] : v[2 * i + 1];
+        a[i] = keep + dpp_xor1(give);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {                          // split on slot & 1 (lane bit 2): c[slot >> 1]
+        int keep = b2 ? a[2 * i + 1] : a[2 * i], give = b2 ? a[2 * i] : a[2 * i + 1];
+        c[i] = keep + dpp_ror4(give);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) { h[2 * i] = c[i] & 0xFFFF; h[2 * i + 1] = c[i] >> 16; }   // h[2*(slot>>1) + half]
+#pragma unroll
+    for (int i = 0; i < 2; i++) {                          // split on half (lane bit 1): e[slot >> 1]
+        int keep = b1 ? h[2 * i + 1] : h[2 * i], give = b1 ? h[2 * i] : h[2 * i + 1];
+        e[i] = keep + dpp_xor2(give);
+    }
+    int keep = b3 ? e[1] : e[0], give = b3 ? e[0] : e[1];   // split on slot >> 1 (lane bit 3)
+    int d = keep + dpp_ror8(give);
+    auto x = __builtin_amdgcn_permlane16_swap((unsigned)d, (unsigned)d, false, false);
+    d = (int)(x[0] + x[1]);
+    auto y = __builtin_amdgcn_permlane32_swap((unsigned)d, (unsigned)d, false, false);
+    return (int)(y[0] + y[1]);
+}
+
+// broadcast lane q of every quad to the whole quad
+template <int Q>
+__device__ inline int quad_bcast(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, Q * 0x55, 0xF, 0xF, true);
+}
+
 // two wave-wide int32 sums
 __device__ inline void wave_sum2_i32(int lane, int v0, int v1, int &s0, int &s1)
 {
