@@ -59,6 +59,14 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
 }
+// first link of a dot chain: the rounding constant comes from an SGPR through the VOP3P encoding
+// (the VOP2 v_dot2c form accumulates in place and would need a v_mov of the constant every time)
+__device__ __forceinline__ int dot2_k(uint32_t a, uint32_t b, int k)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
 __device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 
@@ -121,6 +129,7 @@ struct PixLane { int row, seg; bool on; };
 // ipx-1+seg*7+j; everything is packed u16/i16 pairs m = (column 2m, column 2m+1).
 // Outputs: packed patch (Iv, Ix, Iy as 4 pairs each; pair 3 has a zero high half) and the three
 // partial sums of Ix^2, Ix*Iy, Iy^2.
+template <bool EDGE>
 __device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane &pl, int offI, uint32_t W01u,
                                            uint32_t W23u, int ipx, int ipy, int w, int h,
                                            uint32_t (&IvP)[4], uint32_t (&IxP)[4], uint32_t (&IyP)[4],
@@ -159,8 +168,8 @@ __device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane 
         DYB[m] = as_u32((as_u16x2(T1B[m]) + as_u16x2(T1B[m + 1])) * k3 + qb * k10);
     }
     // the derivative image's border is BORDER_CONSTANT 0: mask positions outside the image
-    // (only possible when the window hangs over the edge; uniform branch)
-    if (ipx < 0 || ipx + kWin >= w || ipy < 0 || ipy + kWin >= h) {
+    // (only possible when the window hangs over the edge: the EDGE instantiation)
+    if (EDGE) {
         const int gyA = ipy + pl.row, gyB = gyA + 1;
         const uint32_t rowA = (gyA >= 0 && gyA < h) ? 0xFFFFFFFFu : 0u;
         const uint32_t rowB = (gyB >= 0 && gyB < h) ? 0xFFFFFFFFu : 0u;
@@ -187,9 +196,9 @@ __device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane 
             dxb = alignbit16(DXB[m + 1], DXB[m]); dyb = alignbit16(DYB[m + 1], DYB[m]);
             i1 = P[1][m + 1]; i2 = P[2][m + 1];
         }
-        iv[k] = dot2(i2, W23, dot2(i1, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-        ix[k] = dot2(dxb, W23, dot2(dxa, W01, 1 << (W_BITS - 1))) >> W_BITS;
-        iy[k] = dot2(dyb, W23, dot2(dya, W01, 1 << (W_BITS - 1))) >> W_BITS;
+        iv[k] = dot2(i2, W23, dot2_k(i1, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+        ix[k] = dot2(dxb, W23, dot2_k(dxa, W01, 1 << (W_BITS - 1))) >> W_BITS;
+        iy[k] = dot2(dyb, W23, dot2_k(dya, W01, 1 << (W_BITS - 1))) >> W_BITS;
     }
     pA11 = 0; pA12 = 0; pA22 = 0;
 #pragma unroll
@@ -224,7 +233,7 @@ __device__ __forceinline__ void mismatch_slot(const uint32_t *tileJ, const PixLa
     v[7] = 0;
 #pragma unroll
     for (int k = 0; k < 7; k++)
-        v[k] = (uint32_t)(dot2(C[k + 1], Wb, dot2(C[k], Wa, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5));
+        v[k] = (uint32_t)(dot2(C[k + 1], Wb, dot2_k(C[k], Wa, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5));
     pb1 = 0; pb2 = 0;
 #pragma unroll
     for (int m = 0; m < 4; m++) {
@@ -295,8 +304,12 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
             const int offIs = __builtin_amdgcn_readlane(offI, 4 * s);
             const uint32_t W01s = __builtin_amdgcn_readlane(W01, 4 * s), W23s = __builtin_amdgcn_readlane(W23, 4 * s);
             const int ipxs = __builtin_amdgcn_readlane(ipx, 4 * s), ipys = __builtin_amdgcn_readlane(ipy, 4 * s);
-            patch_slot(lds + s * kSlotDw, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IvP[s], IxP[s], IyP[s],
-                       pA[s][0], pA[s][1], pA[s][2]);
+            if (__builtin_expect(ipxs < 0 || ipxs + kWin >= w || ipys < 0 || ipys + kWin >= h, 0))
+                patch_slot<true>(lds + s * kSlotDw, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IvP[s], IxP[s], IyP[s],
+                                 pA[s][0], pA[s][1], pA[s][2]);
+            else
+                patch_slot<false>(lds + s * kSlotDw, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IvP[s], IxP[s], IyP[s],
+                                  pA[s][0], pA[s][1], pA[s][2]);
         }
         wave_lds_fence();                        // the J tiles reuse the I tiles' LDS
         float A11, A12, A22, D;
