@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="stereo pairs per step (per GPU)")
     ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-timing-marks", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run the pose stage in stream order")
     ap.add_argument("--frames-cache", default="", help="torch file to load/save the rendered S0 frames "
                     "(keeps profiler traces free of the renderer's torch kernels)")
     return ap.parse_args()
@@ -92,12 +93,14 @@ def main():
     ctx = pkg.Context(W, H, device=local_rank, max_batch=B, P1=P1, P2=P2)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)            # launches, events and the RCCL gather share one stream
+    ctx.set_overlap(not args.no_overlap)          # pose stage of step k runs beside the front end of step k+1
     results = torch.zeros((B, pkg.STEP_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     pose_off = pkg.STEP_DTYPE.fields["pose"][1]
 
     def step():
         ctx.track_batch(Lv, Rv, results=results)
         if world > 1:      # the only inter-GPU traffic: 16 doubles per pair to rank 0 (RCCL gather)
+            ctx.wait_results()
             mg.gather_poses(mg.poses_view(results, pose_off, B), rank, world, dst=0)
 
     for _ in range(args.warmup):
@@ -119,6 +122,7 @@ def main():
     elapsed = t1 - t0
     elapsed = mg.max_over_ranks(elapsed, dev, world)
 
+    ctx.sync()
     stage_ms = dict(ctx.get_timing()) if not args.no_timing_marks else {}
     ctx.enable_timing(False)
     res = np.frombuffer(results.cpu().numpy().tobytes(), dtype=pkg.STEP_DTYPE)

@@ -155,6 +155,15 @@ int svo_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t *rig
                     int pitch, int64_t frame_stride, int n_frames, const double *pose0,
                     svo_step_result *results, int results_mem);
 
+/* Overlap mode for svo_track_batch with DEVICE-resident results (off by default).  The pose stage
+ * (RANSAC-EPnP + LM, gates, chain: one latency-bound wave per pair) of batch k then runs on a side
+ * stream while the context's stream already builds pyramids / detects / tracks batch k+1.  The
+ * results of a batch are complete after svo_sync(), or -- in stream order, without a host sync --
+ * after svo_wait_results(); the next svo_track_batch call waits for them by itself before it
+ * reuses the shared buffers. */
+int svo_set_overlap(svo_ctx *ctx, int on);
+int svo_wait_results(svo_ctx *ctx);
+
 /* Kernel-level timing of the last svo_track_batch / svo_add_frame, measured with HIP events on
  * the context's stream: fills up to `cap` (name, milliseconds) pairs, returns the count.
  * Enabled by svo_enable_timing(ctx, 1); adds event records between stages. */

@@ -151,6 +151,13 @@ class Context:
     def num_levels(self):
         return self.lib.svo_num_levels(self.h)
 
+    def set_overlap(self, on=True):
+        """Pose stage of batch k on a side stream, overlapped with batch k+1's front end."""
+        self._check(self.lib.svo_set_overlap(self.h, int(on)))
+
+    def wait_results(self):
+        self._check(self.lib.svo_wait_results(self.h))
+
     def enable_timing(self, on=True):
         self._check(self.lib.svo_enable_timing(self.h, int(on)))
 

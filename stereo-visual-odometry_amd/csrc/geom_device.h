@@ -25,13 +25,17 @@ namespace svo {
 // JacobiSVDImpl_<double>: At is n rows of length m, element (i,k) at At[(i*m+k)*as].
 // Vt (n x n, element stride vs) may be null; `sort_rows` makes the rows of At follow the
 // descending sort and get normalised even without Vt (what cv::SVD does when U is requested).
-__device__ inline void jacobi_svd_d(double *At, int as, int m, int n, double *W, double *Vt, int vs,
-                                    bool sort_rows)
+// M, N are compile-time so the k-loops unroll: their LDS / scratch loads are then issued together
+// instead of one dependent load per multiply (the run-time-bound version was latency-bound).
+template <int M, int N>
+__device__ inline void jacobi_svd_d(double *At, int as, double *W, double *Vt, int vs, bool sort_rows)
 {
+    constexpr int m = M, n = N;
     const double eps = SVO_DBL_EPS * 10, minval = SVO_DBL_MIN;
     const int max_iter = m > 30 ? m : 30;
     for (int i = 0; i < n; i++) {
         double sd = 0;
+#pragma unroll
         for (int k = 0; k < m; k++) { double t = At[(i * m + k) * as]; sd += t * t; }
         W[i] = sd;
         if (Vt) {
@@ -45,7 +49,13 @@ __device__ inline void jacobi_svd_d(double *At, int as, int m, int n, double *W,
             for (int j = i + 1; j < n; j++) {
                 double *Ai = At + (i * m) * as, *Aj = At + (j * m) * as;
                 double a = W[i], p = 0, b = W[j], c, s;
-                for (int k = 0; k < m; k++) p += Ai[k * as] * Aj[k * as];
+                {
+                    double xi[M], xj[M];
+#pragma unroll
+                    for (int k = 0; k < m; k++) { xi[k] = Ai[k * as]; xj[k] = Aj[k * as]; }
+#pragma unroll
+                    for (int k = 0; k < m; k++) p += xi[k] * xj[k];
+                }
                 if (fabs(p) <= eps * sqrt(a * b)) continue;
                 p *= 2;
                 double beta = a - b, gamma = sqrt(p * p + beta * beta);
@@ -58,6 +68,7 @@ __device__ inline void jacobi_svd_d(double *At, int as, int m, int n, double *W,
                     s = p / (gamma * c * 2);
                 }
                 a = b = 0;
+#pragma unroll
                 for (int k = 0; k < m; k++) {
                     double x = Ai[k * as], y = Aj[k * as];
                     double t0 = c * x + s * y;
@@ -69,6 +80,7 @@ __device__ inline void jacobi_svd_d(double *At, int as, int m, int n, double *W,
                 changed = true;
                 if (Vt) {
                     double *Vi = Vt + (i * n) * vs, *Vj = Vt + (j * n) * vs;
+#pragma unroll
                     for (int k = 0; k < n; k++) {
                         double x = Vi[k * vs], y = Vj[k * vs];
                         double t0 = c * x + s * y;
@@ -81,6 +93,7 @@ __device__ inline void jacobi_svd_d(double *At, int as, int m, int n, double *W,
     }
     for (int i = 0; i < n; i++) {
         double sd = 0;
+#pragma unroll
         for (int k = 0; k < m; k++) { double t = At[(i * m + k) * as]; sd += t * t; }
         W[i] = sqrt(sd);
     }
@@ -108,11 +121,17 @@ __device__ inline void jacobi_svd_d(double *At, int as, int m, int n, double *W,
 }
 
 // cv::solve(A, b, x, DECOMP_SVD), A m x n row-major (m >= n, n <= 6, m <= 6), one right-hand side.
-__device__ inline void svd_solve_d(const double *A, int m, int n, const double *b, double *x)
+// ws: workspace of >= 72 elements with element stride st (the lane-interleaved LDS image when the
+// caller has one: private arrays with run-time indexing live in scratch memory, which is what
+// made the first version of the pose kernel latency-bound).
+template <int M, int N>
+__device__ inline void svd_solve_d(const double *A, const double *b, double *x, double *ws, int st)
 {
-    double At[36], W[6], Vt[36];
-    for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) At[j * m + i] = A[i * n + j];
-    jacobi_svd_d(At, 1, m, n, W, Vt, 1, false);
+    constexpr int m = M, n = N;
+    double W[6];
+    double *At = ws, *Vt = ws + 36 * st;
+    for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) At[(j * m + i) * st] = A[i * n + j];
+    jacobi_svd_d<M, N>(At, st, W, Vt, st, false);
     double threshold = 0;
     for (int i = 0; i < n; i++) x[i] = 0;
     for (int i = 0; i < n; i++) threshold += W[i];
@@ -122,18 +141,19 @@ __device__ inline void svd_solve_d(const double *A, int m, int n, const double *
         if (fabs(wi) <= threshold) continue;
         wi = 1 / wi;
         double s = 0;
-        for (int j = 0; j < m; j++) s += At[i * m + j] * b[j];
+        for (int j = 0; j < m; j++) s += At[(i * m + j) * st] * b[j];
         s *= wi;
-        for (int j = 0; j < n; j++) x[j] = x[j] + s * Vt[i * n + j];
+        for (int j = 0; j < n; j++) x[j] = x[j] + s * Vt[(i * n + j) * st];
     }
 }
 
 // cv::invert(A, Ainv, DECOMP_SVD) for 3x3
-__device__ inline void svd_invert3_d(const double *A, double *Ainv)
+__device__ inline void svd_invert3_d(const double *A, double *Ainv, double *ws, int st)
 {
-    double At[9], W[3], Vt[9], buffer[3], threshold = 0;
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) At[j * 3 + i] = A[i * 3 + j];
-    jacobi_svd_d(At, 1, 3, 3, W, Vt, 1, false);
+    double W[3], buffer[3], threshold = 0;
+    double *At = ws, *Vt = ws + 9 * st;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) At[(j * 3 + i) * st] = A[i * 3 + j];
+    jacobi_svd_d<3, 3>(At, st, W, Vt, st, false);
     for (int i = 0; i < 9; i++) Ainv[i] = 0;
     for (int i = 0; i < 3; i++) threshold += W[i];
     threshold *= SVO_DBL_EPS * 2;
@@ -141,9 +161,9 @@ __device__ inline void svd_invert3_d(const double *A, double *Ainv)
         double wi = W[i];
         if (fabs(wi) <= threshold) continue;
         wi = 1 / wi;
-        for (int j = 0; j < 3; j++) buffer[j] = At[i * 3 + j] * wi;
+        for (int j = 0; j < 3; j++) buffer[j] = At[(i * 3 + j) * st] * wi;
         for (int j = 0; j < 3; j++)
-            for (int k = 0; k < 3; k++) Ainv[j * 3 + k] = Ainv[j * 3 + k] + Vt[i * 3 + j] * buffer[k];
+            for (int k = 0; k < 3; k++) Ainv[j * 3 + k] = Ainv[j * 3 + k] + Vt[(i * 3 + j) * st] * buffer[k];
     }
 }
 
@@ -204,7 +224,7 @@ struct Epnp5 {
 
 // compute_ccs + compute_pcs + solve_for_sign + estimate_R_and_t + reprojection_error
 __device__ inline double epnp_R_and_t_d(Epnp5 &e, const double *v /* 4 x 12: ut rows 11,10,9,8 */,
-                                        const double *betas, double R[9], double t[3])
+                                        const double *betas, double R[9], double t[3], double *ws, int st)
 {
     const int n = 5;
     for (int i = 0; i < 4; i++) e.ccs[i][0] = e.ccs[i][1] = e.ccs[i][2] = 0.0;
@@ -224,7 +244,8 @@ __device__ inline double epnp_R_and_t_d(Epnp5 &e, const double *v /* 4 x 12: ut 
     double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
     for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) { pc0[j] += e.pcs[3 * i + j]; pw0[j] += e.pws[3 * i + j]; }
     for (int j = 0; j < 3; j++) { pc0[j] /= n; pw0[j] /= n; }
-    double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, abt_d[3], abt_ut[9], abt_vt[9];
+    double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, abt_d[3];
+    double *abt_ut = ws, *abt_vt = ws + 9 * st;
     for (int i = 0; i < n; i++) {
         const double *pc = e.pcs + 3 * i, *pw = e.pws + 3 * i;
         for (int j = 0; j < 3; j++) {
@@ -233,12 +254,12 @@ __device__ inline double epnp_R_and_t_d(Epnp5 &e, const double *v /* 4 x 12: ut 
             abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
         }
     }
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) abt_ut[j * 3 + i] = abt[i * 3 + j];
-    jacobi_svd_d(abt_ut, 1, 3, 3, abt_d, abt_vt, 1, false);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) abt_ut[(j * 3 + i) * st] = abt[i * 3 + j];
+    jacobi_svd_d<3, 3>(abt_ut, st, abt_d, abt_vt, st, false);
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++)
-            R[i * 3 + j] = abt_ut[0 * 3 + i] * abt_vt[0 * 3 + j] + abt_ut[1 * 3 + i] * abt_vt[1 * 3 + j] +
-                           abt_ut[2 * 3 + i] * abt_vt[2 * 3 + j];
+            R[i * 3 + j] = abt_ut[(0 * 3 + i) * st] * abt_vt[(0 * 3 + j) * st] + abt_ut[(1 * 3 + i) * st] * abt_vt[(1 * 3 + j) * st] +
+                           abt_ut[(2 * 3 + i) * st] * abt_vt[(2 * 3 + j) * st];
     const double det = R[0] * R[4] * R[8] + R[1] * R[5] * R[6] + R[2] * R[3] * R[7] -
                        R[2] * R[4] * R[6] - R[1] * R[3] * R[8] - R[0] * R[5] * R[7];
     if (det < 0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
@@ -267,7 +288,8 @@ __device__ inline void epnp5_d(Epnp5 &e, double *big, int bs, double Rout[9], do
     for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) e.cws[0][j] += e.pws[3 * i + j];
     for (int j = 0; j < 3; j++) e.cws[0][j] /= n;
     {
-        double PW0[15], c3[9], dc[3], uct[9], vt3[9];
+        double PW0[15], c3[9], dc[3];
+        double *uct = big, *vt3 = big + 9 * bs;
         for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) PW0[3 * i + j] = e.pws[3 * i + j] - e.cws[0][j];
         for (int i = 0; i < 3; i++)
             for (int j = i; j < 3; j++) {
@@ -276,18 +298,18 @@ __device__ inline void epnp5_d(Epnp5 &e, double *big, int bs, double Rout[9], do
                 c3[i * 3 + j] = s;
             }
         for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) c3[i * 3 + j] = c3[j * 3 + i];
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) uct[j * 3 + i] = c3[i * 3 + j];
-        jacobi_svd_d(uct, 1, 3, 3, dc, vt3, 1, false);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) uct[(j * 3 + i) * bs] = c3[i * 3 + j];
+        jacobi_svd_d<3, 3>(uct, bs, dc, vt3, bs, false);
         for (int i = 1; i < 4; i++) {
             double k = sqrt(dc[i - 1] / n);
-            for (int j = 0; j < 3; j++) e.cws[i][j] = e.cws[0][j] + k * uct[3 * (i - 1) + j];
+            for (int j = 0; j < 3; j++) e.cws[i][j] = e.cws[0][j] + k * uct[(3 * (i - 1) + j) * bs];
         }
     }
     // ---- compute_barycentric_coordinates
     {
         double cc[9], ci[9];
         for (int i = 0; i < 3; i++) for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = e.cws[j][i] - e.cws[0][i];
-        svd_invert3_d(cc, ci);
+        svd_invert3_d(cc, ci, big, bs);
         for (int i = 0; i < n; i++) {
             const double *pi = e.pws + 3 * i;
             double *a = e.alphas + 4 * i;
@@ -313,7 +335,7 @@ __device__ inline void epnp5_d(Epnp5 &e, double *big, int bs, double Rout[9], do
     }
     for (int i = 0; i < 12; i++) for (int j = 0; j < i; j++) big[(i * 12 + j) * bs] = big[(j * 12 + i) * bs];
     double d12[12];
-    jacobi_svd_d(big, bs, 12, 12, d12, nullptr, 0, true);
+    jacobi_svd_d<12, 12>(big, bs, d12, nullptr, 0, true);
     double v[48];                                   // ut rows 11, 10, 9, 8
     for (int i = 0; i < 4; i++) for (int k = 0; k < 12; k++) v[i * 12 + k] = big[((11 - i) * 12 + k) * bs];
 
@@ -359,7 +381,10 @@ __device__ inline void epnp5_d(Epnp5 &e, double *big, int bs, double Rout[9], do
                 int col = N == 1 ? (j == 0 ? 0 : j == 1 ? 1 : j == 2 ? 3 : 6) : j;
                 Lr[i * nc + j] = L[10 * i + col];
             }
-        svd_solve_d(Lr, 6, nc, rho, bb);
+        // the 12x12 image is free again (v[] holds what is needed)
+        if (N == 1) svd_solve_d<6, 4>(Lr, rho, bb, big, bs);
+        else if (N == 2) svd_solve_d<6, 3>(Lr, rho, bb, big, bs);
+        else svd_solve_d<6, 5>(Lr, rho, bb, big, bs);
         if (N == 1) {
             if (bb[0] < 0) {
                 betas[0] = sqrt(-bb[0]);
@@ -400,7 +425,7 @@ __device__ inline void epnp5_d(Epnp5 &e, double *big, int bs, double Rout[9], do
             for (int i = 0; i < 4; i++) betas[i] += x[i];
         }
         double Rn[9], tn[3];
-        double rep = epnp_R_and_t_d(e, v, betas, Rn, tn);
+        double rep = epnp_R_and_t_d(e, v, betas, Rn, tn, big, bs);
         // "N = 1; if (rep[2] < rep[1]) N = 2; if (rep[3] < rep[N]) N = 3;"
         if (N == 1 || rep < best_rep) {
             best_rep = rep;
@@ -448,15 +473,16 @@ __device__ inline void rodrigues_vec2mat_d(const double r[3], double R[9], doubl
 }
 
 // cv::Rodrigues matrix -> vector
-__device__ inline void rodrigues_mat2vec_d(const double Rin[9], double r[3])
+__device__ inline void rodrigues_mat2vec_d(const double Rin[9], double r[3], double *ws, int st)
 {
-    double At[9], W[3], Vt[9], R[9];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) At[j * 3 + i] = Rin[i * 3 + j];
-    jacobi_svd_d(At, 1, 3, 3, W, Vt, 1, false);
+    double W[3], R[9];
+    double *At = ws, *Vt = ws + 9 * st;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) At[(j * 3 + i) * st] = Rin[i * 3 + j];
+    jacobi_svd_d<3, 3>(At, st, W, Vt, st, false);
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) {
             double s = 0;
-            for (int k = 0; k < 3; k++) s += At[k * 3 + i] * Vt[k * 3 + j];
+            for (int k = 0; k < 3; k++) s += At[(k * 3 + i) * st] * Vt[(k * 3 + j) * st];
             R[i * 3 + j] = s;
         }
     double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];

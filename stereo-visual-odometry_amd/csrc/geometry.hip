@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64) void triangulate_kernel(TriArgs a)
         }
     }
     for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) At[k * 4 + j] = A[j * 4 + k];
-    jacobi_svd_d(At, 1, 4, 4, W, Vt, 1, false);
+    jacobi_svd_d<4, 4>(At, 1, W, Vt, 1, false);
     // 4 x N CV_32F homogeneous result, then convertPointsFromHomogeneous in float
     const float X = (float)Vt[12], Y = (float)Vt[13], Z = (float)Vt[14], Wh = (float)Vt[15];
     const float scale = Wh != 0.f ? 1.f / Wh : 1.f;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64) void pnp_ransac_kernel(PnpArgs a)
 
     // ---- refit on the inliers: solvePnP(ITERATIVE, useExtrinsicGuess) == CvLevMarq on 6 params
     double param[6], prevParam[6], JtJ[36], JtErr[6];
-    rodrigues_mat2vec_d(bR, param);
+    rodrigues_mat2vec_d(bR, param, big + lane, 64);
     param[3] = bt[0]; param[4] = bt[1]; param[5] = bt[2];
     const double POW10[33] = {1e-16, 1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6,
                               1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8,
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void pnp_ransac_kernel(PnpArgs a)
             const double lambda = POW10[lambdaLg10 + 16];
             for (int i = 0; i < 36; i++) A[i] = JtJ[i];
             for (int i = 0; i < 6; i++) A[i * 6 + i] *= 1. + lambda;
-            svd_solve_d(A, 6, 6, JtErr, x);
+            svd_solve_d<6, 6>(A, JtErr, x, big + lane, 64);
             for (int i = 0; i < 6; i++) param[i] = prevParam[i] - x[i];
             errNorm = sqrt(lm_eval(param, X3, img, mask, n, fx, fy, cx, cy, lane, nullptr, nullptr));
             if (errNorm > prevErrNorm) {
@@ -407,7 +407,7 @@ void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const floa
     hipLaunchKernelGGL(triangulate_kernel, dim3((max_pts + 63) / 64, n_items), dim3(64), 0, ctx->stream, a);
 }
 
-void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n_pts, int n_fixed)
+void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n_pts, int n_fixed, hipStream_t st)
 {
     PnpArgs a{};
     a.X3 = ctx->X3; a.img = img; a.stride = ctx->cfg.max_keypoints;
@@ -418,23 +418,27 @@ void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n
     a.confidence = (double)ctx->cfg.confidence;
     a.mask = (uint8_t *)ctx->pnp_ws + ws_off_mask(ctx->cfg.max_batch);
     a.out = (PnpRecord *)ctx->pnp_ws;
-    hipLaunchKernelGGL(pnp_ransac_kernel, dim3(n_items), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(pnp_ransac_kernel, dim3(n_items), dim3(64), 0, st, a);
 }
 
-void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur, const double *pose0_host)
+void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur, const double *pose0_host,
+                           hipStream_t st)
 {
     FinalizeArgs f{};
     f.pnp = (const PnpRecord *)ctx->pnp_ws; f.n_prev = n_prev; f.n_cur = n_cur; f.n_tracked = ctx->m_out;
     f.n_pairs = n_pairs; f.num_features_tracking = ctx->cfg.num_features_tracking;
     f.inlier_rate = ctx->cfg.inlier_rate; f.min_move2 = ctx->cfg.min_move2; f.max_move2 = ctx->cfg.max_move2;
     f.res = ctx->d_results;
-    hipLaunchKernelGGL(finalize_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, f);
-    double *d_pose0 = (double *)((char *)ctx->pnp_ws + ws_off_pose0(ctx->cfg, ctx->cfg.max_batch));
-    // pose0 goes through the pinned scratch so the async copy is valid
-    double *h = (double *)((char *)ctx->h_pinned + 128);
+    hipLaunchKernelGGL(finalize_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, f);
+    // pose0 goes through pinned scratch so the async copy is valid; two alternating copies so a
+    // pose stage still pending on the side stream never sees the next call's seed
+    static_assert(sizeof(double) * 32 <= 256, "pose0 ring");
+    const int ring = (ctx->pose0_ring++) & 1;
+    double *d_pose0 = (double *)((char *)ctx->pnp_ws + ws_off_pose0(ctx->cfg, ctx->cfg.max_batch)) + 16 * ring;
+    double *h = (double *)((char *)ctx->h_pinned + 512) + 16 * ring;
     for (int i = 0; i < 16; i++) h[i] = pose0_host ? pose0_host[i] : ((i % 5 == 0) ? 1.0 : 0.0);
-    (void)hipMemcpyAsync(d_pose0, h, sizeof(double) * 16, hipMemcpyHostToDevice, ctx->stream);
-    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_results, n_pairs, d_pose0);
+    (void)hipMemcpyAsync(d_pose0, h, sizeof(double) * 16, hipMemcpyHostToDevice, st);
+    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, st, ctx->d_results, n_pairs, d_pose0);
 }
 
 // ---- stage API ------------------------------------------------------------------------------

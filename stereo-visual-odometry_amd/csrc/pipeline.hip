@@ -58,7 +58,11 @@ static int ingest_frames(svo_ctx *ctx, const uint8_t *L, const uint8_t *R, int p
 }
 
 // Tracks `n_pairs` pairs; pair p = (frame slot fp0 + p*fstep, frame slot fc0 + p*fstep).
-static int run_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, const double *pose0_host)
+// Front half on the context's stream: circular LK, compaction, triangulation.  Back half (pose
+// solver, gates, chain, optional copy of the records to `results_dev`) on `back_stream`, which is
+// the context's stream, or -- overlap mode -- the side stream, ordered after the front by an event.
+static int run_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, const double *pose0_host,
+                     svo_step_result *results_dev)
 {
     const PyrGeom &g = ctx->geom;
     const int cap = ctx->cfg.max_keypoints;
@@ -71,18 +75,22 @@ static int run_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, con
     a.prev[1] = S(2 * fp0 + 1); a.next[1] = S(2 * fc0 + 1);
     a.prev[2] = S(2 * fc0 + 1); a.next[2] = S(2 * fc0);
     a.prev[3] = S(2 * fc0);     a.next[3] = S(2 * fp0);
-    // matched_t1_left = the previous frame's FAST keypoints (:268-271), read in place
+    // matched_t1_left = the previous frame's FAST keypoints (:268-271), read in place.  Outputs use
+    // the same per-item stride (po = b * pts_stride + idx); n_pts is indexed by the batch item, so
+    // fstep must be 1 when n_pairs > 1.
     a.pts_in = ctx->kp_xy + (size_t)fp0 * cap; a.pts_stride = (int64_t)fstep * cap;
     a.n_pts = ctx->kp_n + fp0;
-    // NOTE: n_pts is indexed by batch item b, so fstep must be 1 when n_pairs > 1
     a.n_fixed = 0; a.cap = cap;
     for (int i = 0; i < 4; i++) { a.pts_out[i] = ctx->pts_out[i]; a.status[i] = ctx->status[i]; }
     a.keep = ctx->keep;
     a.match_err = ctx->cfg.feature_match_error; a.match_err_f = (float)ctx->cfg.feature_match_error;
-    // LK writes its outputs with the INPUT stride (pts_stride); keep outputs dense per item:
-    // outputs are addressed with the same po = b*pts_stride + idx, so give them the same stride
     launch_lk(a, n_pairs, cap, ctx->stream);
     mark(ctx, kTLk);
+    // the previous batch's pose stage (overlap mode) still reads the compacted lists / 3-D points
+    if (ctx->back_pending) {
+        SVO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_back, 0));
+        ctx->back_pending = false;
+    }
     CompactArgs c{};
     c.keep = ctx->keep; c.n_pts = ctx->kp_n + fp0; c.n_fixed = 0; c.pts_stride = (int64_t)fstep * cap; c.cap = cap;
     c.in[0] = a.pts_in; c.in[1] = ctx->pts_out[0]; c.in[2] = ctx->pts_out[1]; c.in[3] = ctx->pts_out[2];
@@ -90,13 +98,39 @@ static int run_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, con
     c.m_out = ctx->m_out;
     launch_compact(c, n_pairs, ctx->stream);
     mark(ctx, kTCompact);
-    // triangulatePoints(P1, P2, t1_left, t1_right) (:292-294); solvePnPRansac(X, t2_left) (:299)
+    // triangulatePoints(P1, P2, t1_left, t1_right) (:292-294)
     launch_triangulate_batch(ctx, n_pairs, cap, ctx->cmp[0], ctx->cmp[1], ctx->m_out, 0);
+    // keypoint counts of the frames involved, frozen for the pose stage (FAST of the next batch
+    // overwrites kp_n): snap[p] = n_prev of pair p, snap[n_pairs + p] = n_cur of pair p
+    if (fstep == 1) {
+        SVO_HIP(hipMemcpyAsync(ctx->kp_n_snap, ctx->kp_n + fp0, sizeof(int) * n_pairs, hipMemcpyDeviceToDevice, ctx->stream));
+        SVO_HIP(hipMemcpyAsync(ctx->kp_n_snap + n_pairs, ctx->kp_n + fc0, sizeof(int) * n_pairs, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        SVO_HIP(hipMemcpyAsync(ctx->kp_n_snap, ctx->kp_n + fp0, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        SVO_HIP(hipMemcpyAsync(ctx->kp_n_snap + 1, ctx->kp_n + fc0, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    }
     mark(ctx, kTTri);
-    launch_pnp_batch(ctx, n_pairs, ctx->cmp[3], ctx->m_out, 0);
-    mark(ctx, kTPnp);
-    launch_finalize_chain(ctx, n_pairs, ctx->kp_n + fp0, ctx->kp_n + fc0, pose0_host);
-    mark(ctx, kTFin);
+
+    hipStream_t bs = ctx->stream;
+    const bool side = ctx->overlap && results_dev != nullptr;
+    if (side) {
+        SVO_HIP(hipEventRecord(ctx->ev_front, ctx->stream));
+        SVO_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_front, 0));
+        bs = ctx->side_stream;
+    }
+    // solvePnPRansac(X, t2_left) (:299), gates, frame_pose_ chain
+    launch_pnp_batch(ctx, n_pairs, ctx->cmp[3], ctx->m_out, 0, bs);
+    if (!side) mark(ctx, kTPnp);
+    launch_finalize_chain(ctx, n_pairs, ctx->kp_n_snap, ctx->kp_n_snap + n_pairs, pose0_host, bs);
+    if (results_dev)
+        SVO_HIP(hipMemcpyAsync(results_dev, ctx->d_results, sizeof(svo_step_result) * (size_t)n_pairs,
+                               hipMemcpyDeviceToDevice, bs));
+    if (side) {
+        SVO_HIP(hipEventRecord(ctx->ev_back, ctx->side_stream));
+        ctx->back_pending = true;
+    } else {
+        mark(ctx, kTFin);
+    }
     return SVO_OK;
 }
 
@@ -114,14 +148,10 @@ int pipeline_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t
     int rc = ingest_frames(ctx, left_frames, right_frames, pitch, frame_stride, 0, n_frames);
     if (rc) return rc;
     // the LK outputs use the keypoint stride (cap) per item: frame slots are consecutive (fstep 1)
-    rc = run_pairs(ctx, n_pairs, 0, 1, 1, pose0);
+    rc = run_pairs(ctx, n_pairs, 0, 1, 1, pose0, results_mem == SVO_MEM_DEVICE ? results : nullptr);
     if (rc) return rc;
     SVO_HIP(hipGetLastError());
-    if (results_mem == SVO_MEM_DEVICE) {
-        SVO_HIP(hipMemcpyAsync(results, ctx->d_results, sizeof(svo_step_result) * (size_t)n_pairs,
-                               hipMemcpyDeviceToDevice, ctx->stream));
-        return SVO_OK;
-    }
+    if (results_mem == SVO_MEM_DEVICE) return SVO_OK;
     svo_step_result *h = (svo_step_result *)((char *)ctx->h_pinned + 4096);
     SVO_HIP(hipMemcpyAsync(h, ctx->d_results, sizeof(svo_step_result) * (size_t)n_pairs, hipMemcpyDeviceToHost, ctx->stream));
     SVO_HIP(hipStreamSynchronize(ctx->stream));
@@ -162,7 +192,7 @@ int pipeline_add_frame(svo_ctx *ctx, const uint8_t *left, const uint8_t *right, 
         ctx->online_frames = 1; ctx->online_cur = cur;
         return SVO_OK;
     }
-    rc = run_pairs(ctx, 1, prev, cur, 0, ctx->pose);
+    rc = run_pairs(ctx, 1, prev, cur, 0, ctx->pose, nullptr);
     if (rc) return rc;
     SVO_HIP(hipGetLastError());
     svo_step_result *h = (svo_step_result *)((char *)ctx->h_pinned + 4096);

@@ -49,6 +49,7 @@ static void make_geom(int w, int h, PyrGeom *g)
     g->slot_bytes = off;
 }
 
+extern "C" int svo_wait_results(svo_ctx *ctx);
 extern "C" int svo_abi_version(void) { return SVO_ABI_VERSION; }
 
 extern "C" void svo_default_config(svo_config *cfg, int width, int height)
@@ -80,7 +81,10 @@ static void free_all(svo_ctx *c)
     F(c->slots); F(c->stage_img); F(c->score); F(c->rowcount); F(c->kp_xy); F(c->kp_resp); F(c->kp_n);
     F(c->pts_in);
     for (int i = 0; i < 4; i++) { F(c->pts_out[i]); F(c->status[i]); F(c->cmp[i]); }
-    F(c->keep); F(c->m_out); F(c->X3); F(c->pnp_ws); F(c->d_results); F(c->bslots);
+    F(c->keep); F(c->m_out); F(c->X3); F(c->pnp_ws); F(c->d_results); F(c->bslots); F(c->kp_n_snap);
+    if (c->ev_front) (void)hipEventDestroy(c->ev_front);
+    if (c->ev_back) (void)hipEventDestroy(c->ev_back);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -141,6 +145,10 @@ extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
     CK(hipMalloc(&ctx->pnp_ws, ctx->pnp_ws_bytes));
     CK(hipMalloc(&ctx->d_results, sizeof(svo_step_result) * (size_t)B));
     CK(hipMalloc(&ctx->bslots, (size_t)2 * n_img * ctx->geom.slot_bytes));
+    CK(hipMalloc(&ctx->kp_n_snap, sizeof(int) * (size_t)(2 * n_img)));
+    CK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    CK(hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&ctx->ev_back, hipEventDisableTiming));
     ctx->h_pinned_bytes = sizeof(svo_step_result) * (size_t)B + 4096 +
                           (size_t)cap * (sizeof(float2) + sizeof(float)) + sizeof(int) * 64;
     CK(hipHostMalloc(&ctx->h_pinned, ctx->h_pinned_bytes, hipHostMallocDefault));
@@ -155,6 +163,7 @@ extern "C" void svo_destroy(svo_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     free_all(ctx);
     delete ctx;
 }
@@ -164,6 +173,7 @@ extern "C" const char *svo_last_error(const svo_ctx *ctx) { return ctx ? ctx->er
 extern "C" int svo_set_stream(svo_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return SVO_ERR_ARG;
+    if (svo_wait_results(ctx) != SVO_OK) return SVO_ERR_HIP;
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return SVO_OK;
 }
@@ -172,6 +182,28 @@ extern "C" int svo_sync(svo_ctx *ctx)
 {
     if (!ctx) return SVO_ERR_ARG;
     SVO_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->back_pending) { SVO_HIP(hipStreamSynchronize(ctx->side_stream)); ctx->back_pending = false; }
+    return SVO_OK;
+}
+
+extern "C" int svo_set_overlap(svo_ctx *ctx, int on)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    int rc = svo_wait_results(ctx);
+    if (rc) return rc;
+    ctx->overlap = on != 0;
+    return SVO_OK;
+}
+
+// Makes the context's stream wait (on the device, no host sync) for the pose stage of the last
+// svo_track_batch when overlap mode runs it on the side stream.
+extern "C" int svo_wait_results(svo_ctx *ctx)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    if (ctx->back_pending) {
+        SVO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_back, 0));
+        ctx->back_pending = false;
+    }
     return SVO_OK;
 }
 
@@ -385,6 +417,7 @@ extern "C" int svo_circular_match(svo_ctx *ctx, int slot_prevL, int slot_prevR, 
     SVO_ARG(n >= 0 && n <= ctx->cfg.max_keypoints, "n exceeds max_keypoints");
     SVO_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE, "bad mem");
     SVO_ARG(m_out != nullptr, "null m_out");
+    if (svo_wait_results(ctx) != SVO_OK) return SVO_ERR_HIP;
     *m_out = 0;
     if (n == 0) return SVO_OK;
     SVO_ARG(t1_left && out_t1_left && out_t1_right && out_t2_right && out_t2_left, "null pointer");
@@ -429,6 +462,7 @@ extern "C" int svo_triangulate(svo_ctx *ctx, const double P1[12], const double P
                                const svo_pt2f *x2, int n, svo_pt3f *out, int mem)
 {
     if (!ctx) return SVO_ERR_ARG;
+    if (svo_wait_results(ctx) != SVO_OK) return SVO_ERR_HIP;     // shares X3 / cmp with a pending pose stage
     return stage_triangulate(ctx, P1, P2, x1, x2, n, out, mem);
 }
 
@@ -437,6 +471,7 @@ extern "C" int svo_pnp_ransac(svo_ctx *ctx, const svo_pt3f *obj, const svo_pt2f 
                               uint8_t *inlier_mask, int mem)
 {
     if (!ctx) return SVO_ERR_ARG;
+    if (svo_wait_results(ctx) != SVO_OK) return SVO_ERR_HIP;
     return stage_pnp_ransac(ctx, obj, img, n, K, iterations, reproj_err, confidence, res, inlier_mask, mem);
 }
 

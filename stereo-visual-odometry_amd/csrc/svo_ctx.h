@@ -42,6 +42,14 @@ struct svo_ctx {
     double pose[16];
     // ---- pinned host scratch
     void *h_pinned = nullptr; size_t h_pinned_bytes = 0;
+    // ---- overlap mode (svo_set_overlap): the pose stage of batch k runs on side_stream while
+    //      the caller's stream already ingests / tracks batch k+1
+    bool overlap = false;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_front = nullptr, ev_back = nullptr;
+    bool back_pending = false;
+    unsigned pose0_ring = 0;
+    int *kp_n_snap = nullptr;         // n_prev / n_cur of the batch the pose stage works on
     // ---- timing
     // stage marks are HIP events recorded on the context's stream; they are resolved (elapsed
     // times averaged per stage over all steps since the last query) in svo_get_timing
@@ -71,7 +79,7 @@ namespace svo {
 int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes);
 void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const float2 *x1, const float2 *x2,
                               const int *n_pts, int n_fixed);
-void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n_pts, int n_fixed);
+void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n_pts, int n_fixed, hipStream_t st);
 void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur,
-                           const double *pose0_host);
+                           const double *pose0_host, hipStream_t st);
 }  // namespace svo

@@ -197,6 +197,36 @@ def test_track_batch_parity(pkg, oracle, tc, small_seq):
     c.close()
 
 
+def test_track_batch_overlap_mode(pkg, oracle, tc, small_seq):
+    """Overlap mode (pose stage of batch k beside the front end of batch k+1) changes no result."""
+    seq, frames = small_seq
+    h, w = frames[0][0].shape
+    P1s, P2s = seq.proj()
+    F = len(frames)
+    c = pkg.Context(w, h, device=0, P1=P1s, P2=P2s, max_batch=F - 1)
+    L = tc.stack([tc.from_numpy(f[0]) for f in frames]).cuda()
+    R = tc.stack([tc.from_numpy(f[1]) for f in frames]).cuda()
+    ref = c.track_batch(L, R)                                     # host results, stream order
+    c.set_overlap(True)
+    outs = [tc.zeros((F - 1, pkg.STEP_DTYPE.itemsize), dtype=tc.uint8, device="cuda") for _ in range(3)]
+    for o in outs:                                                # back-to-back batches, no host sync between
+        c.track_batch(L, R, results=o)
+    c.sync()
+    for o in outs:
+        got = np.frombuffer(o.cpu().numpy().tobytes(), dtype=pkg.STEP_DTYPE)
+        assert got.tobytes() == ref.tobytes()
+    # stage calls and the online path wait for a pending pose stage by themselves
+    c.track_batch(L, R, results=outs[0])
+    X = np.random.default_rng(0).uniform(1, 5, (50, 3)).astype(np.float32)
+    x = (X[:, :2] / X[:, 2:] * 100 + 200).astype(np.float32)
+    assert c.triangulate(P1, P2, x, x + np.float32([5, 0])).shape == (50, 3)
+    c.wait_results()
+    got = np.frombuffer(outs[0].cpu().numpy().tobytes(), dtype=pkg.STEP_DTYPE)
+    assert got.tobytes() == ref.tobytes()
+    c.set_overlap(False)
+    c.close()
+
+
 def test_failure_stages_parity(pkg, oracle, tc, small_seq):
     """Frames that make the reference return false: too few corners, static scene (|t| gate)."""
     seq, frames = small_seq
