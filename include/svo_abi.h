@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 1
+#define SVO_ABI_VERSION 2
 
 /* status codes */
 #define SVO_OK                 0
@@ -69,7 +69,17 @@ typedef struct {
     double  inlier_rate;            /* :77                                                     */
     double  min_move2, max_move2;   /* squared translation gate; LK mode: 0.0005^2, 100 (:311) */
     double  P1[12], P2[12];         /* projMatr1_/projMatr2_, src/parameter.cpp:44-45          */
+    /* track_mode (config/default.yaml:75) and the ORBextractor constructor arguments (:89-93)   */
+    int32_t track_mode;             /* SVO_MODE_LK ("LK_stereof2f_pnp") or SVO_MODE_ORB ("ORB_stereof2f_pnp");
+                                       in ORB mode min_move2 / max_move2 = minmove^2 / maxmove^2 (:87-88) */
+    int32_t orb_nfeatures;          /* nFeatures 2000 */
+    float   orb_scale_factor;       /* fScaleFactor 1.2 */
+    int32_t orb_nlevels;            /* nLevels 8 */
+    int32_t orb_ini_th, orb_min_th; /* fIniThFAST 20, fMinThFAST 7 */
 } svo_config;
+
+#define SVO_MODE_LK  0
+#define SVO_MODE_ORB 1
 
 typedef struct {                    /* solvePnPRansac + Rodrigues outcome */
     double rvec[3], tvec[3], R[9];
@@ -134,6 +144,23 @@ int svo_triangulate(svo_ctx *ctx, const double P1[12], const double P2[12], cons
 int svo_pnp_ransac(svo_ctx *ctx, const svo_pt3f *obj, const svo_pt2f *img, int n, const double K[9],
                    int iterations, float reproj_err, double confidence, svo_pnp_result *res,
                    uint8_t *inlier_mask, int mem);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors) -- src/ORBextractor.cpp:990-1055,
+ * called twice per frame by Tracking::Detect_MyORBFeatures (src/tracking.cpp:502-532).  kps is a HOST
+ * array of cv::KeyPoint records, desc n x 32 bytes (HOST).  per_level (8 ints, may be NULL) receives
+ * the keypoints kept per pyramid level. */
+int svo_orb_extract(svo_ctx *ctx, const uint8_t *img, int pitch, int mem, svo_keypoint *kps, uint8_t *desc,
+                    int cap, int *n_out, int *per_level);
+/* test/debug read-back of one ORB pyramid level (tight rows) of the last svo_orb_extract */
+int svo_orb_read_level(svo_ctx *ctx, int level, uint8_t *out, int *w, int *h);
+/* test/debug: FAST candidates (x, y, response, 0) of one level of the last svo_orb_extract, before the quadtree */
+int svo_orb_read_candidates(svo_ctx *ctx, int level, float *out4, int cap, int *n_out);
+
+/* DescriptorMatcher::create("BruteForce-Hamming")->match(query, train, matches) --
+ * src/tracking.cpp:539-544: for every query row the first train row of minimum Hamming distance.
+ * Descriptors are 32-byte rows (16-byte aligned when device-resident). */
+int svo_match_hamming(svo_ctx *ctx, const uint8_t *query, int nq, const uint8_t *train, int nt, int32_t *train_idx,
+                      float *distance, int mem);
 
 /* ---- fused API: Tracking::AddFrame in LK mode (src/tracking.cpp:49-77, 258-344) ------------ */
 

@@ -263,3 +263,111 @@ def lk_track_step(params, prevL, prevR, curL, curR, prev_kps, pose, cur_cap=1 <<
     if want_tracks:
         d["tracks"] = tracks[:, :res.n_tracked].copy()
     return d, cur[:min(res.n_cur_kps, cur_cap)].copy(), pose.reshape(4, 4)
+
+
+# ---- ORB path -------------------------------------------------------------------------------
+def orb_setup(nfeatures=2000, scale_factor=1.2, nlevels=8):
+    sc = np.zeros(nlevels, np.float32)
+    inv = np.zeros(nlevels, np.float32)
+    quota = np.zeros(nlevels, np.int32)
+    umax = np.zeros(16, np.int32)
+    lib().orc_orb_setup(int(nfeatures), C.c_float(scale_factor), int(nlevels), sc.ctypes.data_as(C.c_void_p),
+                        inv.ctypes.data_as(C.c_void_p), quota.ctypes.data_as(C.c_void_p), umax.ctypes.data_as(C.c_void_p))
+    return sc, inv, quota, umax
+
+
+def resize_linear(img, dw, dh):
+    img, p = _u8(img)
+    h, w = img.shape
+    out = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(p, w, h, w, out.ctypes.data_as(C.c_void_p), dw, dh, dw)
+    return out
+
+
+def orb_pyramid_level(img, level, scale_factor=1.2, nlevels=8):
+    img, p = _u8(img)
+    h, w = img.shape
+    ow, oh = C.c_int(0), C.c_int(0)
+    lib().orc_orb_pyramid_level(p, w, h, w, C.c_float(scale_factor), nlevels, level, None, C.byref(ow), C.byref(oh))
+    out = np.zeros((oh.value, ow.value), np.uint8)
+    lib().orc_orb_pyramid_level(p, w, h, w, C.c_float(scale_factor), nlevels, level, out.ctypes.data_as(C.c_void_p),
+                                C.byref(ow), C.byref(oh))
+    return out
+
+
+def fast_atan2(y, x):
+    lib().orc_fast_atan2.restype = C.c_float
+    return float(lib().orc_fast_atan2(C.c_float(y), C.c_float(x)))
+
+
+def gauss7_kernel():
+    k = (C.c_int * 7)()
+    lib().orc_gauss7_kernel(k)
+    return list(k)
+
+
+def gauss_blur7(img):
+    img, p = _u8(img)
+    h, w = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orc_gauss_blur7(p, w, h, w, out.ctypes.data_as(C.c_void_p), w)
+    return out
+
+
+def orb_extract(img, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, cap=8192):
+    """ORBextractor::operator(): (keypoints, descriptors (n,32) uint8, per-level counts)."""
+    img, p = _u8(img)
+    h, w = img.shape
+    kps = np.zeros(cap, dtype=KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    per = np.zeros(8, np.int32)
+    n = lib().orc_orb_extract(p, w, h, w, int(nfeatures), C.c_float(scale_factor), int(nlevels), int(ini_th),
+                              int(min_th), kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap,
+                              per.ctypes.data_as(C.c_void_p))
+    return kps[:n].copy(), desc[:n].copy(), per
+
+
+def match_hamming(q, t):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    idx = np.zeros(max(len(q), 1), np.int32)
+    dist = np.zeros(max(len(q), 1), np.float32)
+    lib().orc_match_hamming(q.ctypes.data_as(C.c_void_p), len(q), t.ctypes.data_as(C.c_void_p), len(t),
+                            idx.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p))
+    return idx[:len(q)], dist[:len(q)]
+
+
+def orb_robust_match(lastL, dLastL, lastR, dLastR, curL, dCurL, match_err=3.0):
+    ks = [np.ascontiguousarray(k, dtype=KP_DTYPE) for k in (lastL, lastR, curL)]
+    ds = [np.ascontiguousarray(d, np.uint8).reshape(-1, 32) for d in (dLastL, dLastR, dCurL)]
+    cap = max(len(ks[0]), 1)
+    outs = [np.zeros((cap, 2), np.float32) for _ in range(3)]
+    m = lib().orc_orb_robust_match(ks[0].ctypes.data_as(C.c_void_p), ds[0].ctypes.data_as(C.c_void_p), len(ks[0]),
+                                   ks[1].ctypes.data_as(C.c_void_p), ds[1].ctypes.data_as(C.c_void_p), len(ks[1]),
+                                   ks[2].ctypes.data_as(C.c_void_p), ds[2].ctypes.data_as(C.c_void_p), len(ks[2]),
+                                   C.c_double(match_err), *[o.ctypes.data_as(C.c_void_p) for o in outs])
+    return [o[:m].copy() for o in outs]          # t2_left, t1_left, t1_right
+
+
+def orb_track_step(params, lastL, dLastL, lastR, dLastR, curL, dCurL, pose):
+    ks = [np.ascontiguousarray(k, dtype=KP_DTYPE) for k in (lastL, lastR, curL)]
+    ds = [np.ascontiguousarray(d, np.uint8).reshape(-1, 32) for d in (dLastL, dLastR, dCurL)]
+    pose = np.ascontiguousarray(pose, np.float64).reshape(16).copy()
+    res = StepResult()
+    lib().orc_orb_track_step(C.byref(params), ks[0].ctypes.data_as(C.c_void_p), ds[0].ctypes.data_as(C.c_void_p), len(ks[0]),
+                             ks[1].ctypes.data_as(C.c_void_p), ds[1].ctypes.data_as(C.c_void_p), len(ks[1]),
+                             ks[2].ctypes.data_as(C.c_void_p), ds[2].ctypes.data_as(C.c_void_p), len(ks[2]),
+                             pose.ctypes.data_as(C.c_void_p), C.byref(res))
+    d = dict(ok=res.ok, fail_stage=res.fail_stage, n_prev_kps=res.n_prev_kps, n_cur_kps=res.n_cur_kps,
+             n_tracked=res.n_tracked, n_inliers=res.n_inliers, rvec=np.array(res.rvec), tvec=np.array(res.tvec),
+             R=np.array(res.R).reshape(3, 3), T_rel_inv=np.array(res.T_rel_inv).reshape(4, 4))
+    return d, pose.reshape(4, 4)
+
+
+def orb_candidates(img, level, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, cap=1 << 16):
+    img, p = _u8(img)
+    h, w = img.shape
+    out = np.zeros((cap, 3), np.float32)
+    n = lib().orc_orb_candidates(p, w, h, w, C.c_float(scale_factor), nlevels, level, ini_th, min_th,
+                                 out.ctypes.data_as(C.c_void_p), cap)
+    return out[:n].copy()

@@ -145,6 +145,33 @@ int orc_lk_track_step(const orc_track_params *prm,
                       orc_pt2f *tracks /* 4*n_prev (t1l,t1r,t2r,t2l compacted) or NULL */,
                       int threads);
 
+/* ---- a8-a14: ORB path (reference src/ORBextractor.cpp, src/tracking.cpp:168-249, 502-581) ------ */
+void orc_orb_setup(int nfeatures, float scale_factor, int nlevels, float *scale, float *inv_scale,
+                   int *quota /* nlevels */, int *umax /* 16 */);
+void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, int spitch, uint8_t *dst, int dw, int dh,
+                          int dpitch);
+int  orc_orb_pyramid_level(const uint8_t *img, int w, int h, int pitch, float scaleFactor, int nlevels, int level,
+                           uint8_t *out /* tight, may be NULL */, int *ow, int *oh);
+int  orc_orb_candidates(const uint8_t *img, int w, int h, int pitch, float scaleFactor, int nlevels, int level,
+                        int iniTh, int minTh, float *out3, int cap);
+float orc_fast_atan2(float y, float x);
+void orc_gauss7_kernel(int k[7]);
+void orc_gauss_blur7(const uint8_t *src, int w, int h, int spitch, uint8_t *dst, int dpitch);
+/* ORBextractor::operator()(image, mask, keypoints, descriptors): returns the keypoint count;
+ * desc is n x 32 bytes; per_level (8 ints, may be NULL) receives the keypoints kept per level. */
+int  orc_orb_extract(const uint8_t *img, int w, int h, int pitch, int nfeatures, float scaleFactor, int nlevels,
+                     int iniTh, int minTh, orc_keypoint *kps, uint8_t *desc, int cap, int *per_level);
+/* DescriptorMatcher("BruteForce-Hamming")->match(query, train): first minimum per query row */
+void orc_match_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int *idx, float *dist);
+int  orc_orb_robust_match(const orc_keypoint *lastL, const uint8_t *dLastL, int nLastL, const orc_keypoint *lastR,
+                          const uint8_t *dLastR, int nLastR, const orc_keypoint *curL, const uint8_t *dCurL,
+                          int nCurL, double match_err, orc_pt2f *t2l, orc_pt2f *t1l, orc_pt2f *t1r);
+/* one ORB-mode frame step given the features of the last frame (L, R) and the current left image;
+ * prm->min_t2 / max_t2 are minmove^2 / maxmove^2 (src/tracking.cpp:215) */
+int  orc_orb_track_step(const orc_track_params *prm, const orc_keypoint *lastL, const uint8_t *dLastL, int nLastL,
+                        const orc_keypoint *lastR, const uint8_t *dLastR, int nLastR, const orc_keypoint *curL,
+                        const uint8_t *dCurL, int nCurL, double pose[16], orc_step_result *res);
+
 #ifdef __cplusplus
 }
 #endif

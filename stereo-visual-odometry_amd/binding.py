@@ -25,7 +25,12 @@ class Config(C.Structure):
                 ("reproj_err", C.c_float), ("confidence", C.c_float),
                 ("feature_match_error", C.c_double), ("inlier_rate", C.c_double),
                 ("min_move2", C.c_double), ("max_move2", C.c_double),
-                ("P1", C.c_double * 12), ("P2", C.c_double * 12)]
+                ("P1", C.c_double * 12), ("P2", C.c_double * 12),
+                ("track_mode", C.c_int32), ("orb_nfeatures", C.c_int32), ("orb_scale_factor", C.c_float),
+                ("orb_nlevels", C.c_int32), ("orb_ini_th", C.c_int32), ("orb_min_th", C.c_int32)]
+
+
+MODE_LK, MODE_ORB = 0, 1
 
 
 class PnPResult(C.Structure):
@@ -273,6 +278,49 @@ class Context:
                     R=np.array(res.R).reshape(3, 3), n_inliers=res.n_inliers,
                     ransac_iters=res.ransac_iters, best_iter=res.best_iter, lm_iters=res.lm_iters,
                     mask=np.asarray(mask[:n]).copy())
+
+    # ---- ORB path ---------------------------------------------------------------------------
+    def orb_extract(self, img, cap=None):
+        """ORBextractor::operator(): (keypoints, descriptors (n,32) uint8, per-level counts)."""
+        cap = cap or self.cfg.max_keypoints
+        p, pitch, mem = self._img(img)
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        per = np.zeros(8, np.int32)
+        n = C.c_int(0)
+        self._check(self.lib.svo_orb_extract(self.h, p, pitch, mem, C.c_void_p(kps.ctypes.data),
+                                             C.c_void_p(desc.ctypes.data), cap, C.byref(n), C.c_void_p(per.ctypes.data)))
+        return kps[:n.value].copy(), desc[:n.value].copy(), per
+
+    def orb_read_level(self, level):
+        w, h = C.c_int(0), C.c_int(0)
+        self._check(self.lib.svo_orb_read_level(self.h, level, None, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        self._check(self.lib.svo_orb_read_level(self.h, level, C.c_void_p(out.ctypes.data), C.byref(w), C.byref(h)))
+        return out
+
+    def orb_read_candidates(self, level, cap=8192):
+        out = np.zeros((cap, 4), np.float32)
+        n = C.c_int(0)
+        self._check(self.lib.svo_orb_read_candidates(self.h, level, C.c_void_p(out.ctypes.data), cap, C.byref(n)))
+        return out[:min(n.value, cap), :3].copy()
+
+    def match_hamming(self, query, train):
+        if isinstance(query, np.ndarray):
+            query = np.ascontiguousarray(query, np.uint8).reshape(-1, 32)
+            train = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+            idx = np.zeros(max(len(query), 1), np.int32)
+            dist = np.zeros(max(len(query), 1), np.float32)
+        else:
+            import torch
+            idx = torch.zeros(max(len(query), 1), dtype=torch.int32, device=query.device)
+            dist = torch.zeros(max(len(query), 1), dtype=torch.float32, device=query.device)
+        pq, mem = _ptr(query)
+        self._check(self.lib.svo_match_hamming(self.h, pq, len(query), _ptr(train)[0], len(train), _ptr(idx)[0],
+                                               _ptr(dist)[0], mem))
+        if mem == MEM_DEVICE:
+            self.sync()
+        return idx[:len(query)], dist[:len(query)]
 
     # ---- fused API --------------------------------------------------------------------------
     def add_frame(self, left, right):

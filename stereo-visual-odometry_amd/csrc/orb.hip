@@ -1,0 +1,849 @@
+// orb.hip -- the reference's ORB path on gfx950 (BASELINE config #3):
+//   ORBextractor::operator() (reference src/ORBextractor.cpp:990-1055): 8-level bilinear pyramid
+//   (:1061-1085), per-cell FAST with threshold fallback (:717-807), quadtree distribution
+//   (:430-485, 487-715), intensity-centroid orientation (:21-48), 7x7 sigma-2 blur + rotated BRIEF
+//   (:51-97, 981-988), and Tracking::ORB_Robust_Find_MuliImage_MatchedFeatures
+//   (src/tracking.cpp:534-581) with its BruteForce-Hamming matcher.
+// Everything is integer or single-precision with the reference's operation order (FP contraction
+// off), so keypoints, angles, descriptors and matches are bit-identical to oracle/orb.c.
+//
+// Launch sequence for a batch of images (every kernel covers all images of the batch):
+//   copy0/border -> [resize(l), border(l)] x7 -> cellfast(l) x8 -> gather -> distribute -> blur rows/cols
+//   -> orient+describe -> assemble.
+// The quadtree (std::list / sort / pointer code in the reference) is restated as an array-based
+// doubly linked list walked by ONE lane per (image, level): it is serial by nature (each split
+// decision depends on the node count so far) and small (<= a few thousand keys, <= ~450 leaves);
+// 16 instances per frame run concurrently on different waves.
+#include <cstring>
+#include "svo_ctx.h"
+#include "orb_pattern.h"
+
+namespace svo {
+
+__constant__ signed char c_pattern[1024];
+
+// ---- pyramid ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void orb_copy0_kernel(OrbGeom g, const uint8_t *img, int pitch, int64_t img_stride,
+                                                        uint8_t *slots, int64_t slot_stride)
+{
+    const int b = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= g.w[0]) return;
+    slots[(int64_t)b * slot_stride + g.origin[0] + (int64_t)y * g.pitch[0] + x] = img[(int64_t)b * img_stride + (int64_t)y * pitch + x];
+}
+
+// frame (kPad wide, only 19 are ever read) of level l by reflect-101 from the level's interior
+__global__ __launch_bounds__(256) void orb_border_kernel(OrbGeom g, uint8_t *slots, int64_t slot_stride, int l)
+{
+    const int b = blockIdx.z;
+    const int w = g.w[l], h = g.h[l], pitch = g.pitch[l];
+    uint8_t *lvl = slots + (int64_t)b * slot_stride + g.origin[l];
+    const int py = blockIdx.y - kPad;
+    int px = blockIdx.x * 256 + threadIdx.x;
+    if (py >= 0 && py < h) {
+        if (px >= 2 * kPad) return;
+        px = px < kPad ? px - kPad : w + (px - kPad);
+    } else {
+        if (px >= w + 2 * kPad) return;
+        px -= kPad;
+    }
+    lvl[(int64_t)py * pitch + px] = lvl[(int64_t)refl101(py, h) * pitch + refl101(px, w)];
+}
+
+// cv::resize(level l-1 -> level l, INTER_LINEAR), 8-bit fixed point (11-bit coefficients)
+__global__ __launch_bounds__(256) void orb_resize_kernel(OrbGeom g, uint8_t *slots, int64_t slot_stride, int l)
+{
+    const int b = blockIdx.z, dy = blockIdx.y, dx = blockIdx.x * 256 + threadIdx.x;
+    const int dw = g.w[l], dh = g.h[l], sw = g.w[l - 1], sh = g.h[l - 1], sp = g.pitch[l - 1];
+    if (dx >= dw) return;
+    uint8_t *slot = slots + (int64_t)b * slot_stride;
+    const uint8_t *src = slot + g.origin[l - 1];
+    const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
+    const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    const int a0 = (short)__float2int_rn((1.f - fx) * 2048), a1 = (short)__float2int_rn(fx * 2048);
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= sy;
+    const int b0 = (short)__float2int_rn((1.f - fy) * 2048), b1 = (short)__float2int_rn(fy * 2048);
+    const int y0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+    const int y1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
+    const int sx1 = sx + 1 < sw ? sx + 1 : sx;
+    const uint8_t *S0 = src + (int64_t)y0 * sp, *S1 = src + (int64_t)y1 * sp;
+    const int r0 = S0[sx] * a0 + S0[sx1] * a1, r1 = S1[sx] * a0 + S1[sx1] * a1;
+    slot[g.origin[l] + (int64_t)dy * g.pitch[l] + dx] =
+        (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+}
+
+// ---- per-cell FAST ---------------------------------------------------------------------------
+constexpr int kCellMax = 66;                 // wCell = ceil(width / floor(width / 30)) < 60, +6 overlap
+constexpr int kCellCap = 256;                // candidates kept per cell
+
+// FAST cornerness V = largest t for which the pixel is a FAST-9/16 corner (0 when < 1):
+// corner at threshold t <=> V >= t, and cornerScore == V.
+__device__ __forceinline__ int fast_cornerness(const uint8_t *c, int P)
+{
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * P];       d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];   d[3] = v - c[P + 3];
+    d[4] = v - c[3];           d[5] = v - c[-P + 3];      d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];
+    d[8] = v - c[-3 * P];      d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-P - 3];
+    d[12] = v - c[-3];         d[13] = v - c[P - 3];      d[14] = v - c[2 * P - 2];  d[15] = v - c[3 * P - 1];
+    int mn[16], mx[16], t1[16], t2[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { t1[i] = min(d[i], d[(i + 1) & 15]); t2[i] = max(d[i], d[(i + 1) & 15]); }
+#pragma unroll
+    for (int i = 0; i < 16; i++) { mn[i] = min(t1[i], t1[(i + 2) & 15]); mx[i] = max(t2[i], t2[(i + 2) & 15]); }
+#pragma unroll
+    for (int i = 0; i < 16; i++) { t1[i] = min(mn[i], mn[(i + 4) & 15]); t2[i] = max(mx[i], mx[(i + 4) & 15]); }
+    int best = -255, bestn = -255;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        best = max(best, min(t1[i], d[(i + 8) & 15]));
+        bestn = max(bestn, -max(t2[i], d[(i + 8) & 15]));
+    }
+    const int V = max(best, bestn) - 1;
+    return V > 0 ? V : 0;
+}
+
+// One workgroup per cell (grid.x = cell, grid.y = level-local unused, grid.z = image).
+__global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint8_t *slots, int64_t slot_stride, int l,
+                                                           int iniTh, int minTh, float4 *cell_cand, int *cell_cnt,
+                                                           int64_t cand_img_stride, int64_t cnt_img_stride)
+{
+    __shared__ uint8_t raw[kCellMax * kCellMax];
+    __shared__ uint8_t V[kCellMax * kCellMax];
+    __shared__ uint8_t keep[kCellMax * kCellMax];
+    __shared__ int s_any, s_found;
+    const int b = blockIdx.z, cell = blockIdx.x;
+    const int W = g.w[l], H = g.h[l], pitch = g.pitch[l];
+    const int minBX = 16, minBY = 16, maxBX = W - 16, maxBY = H - 16;
+    const int nCols = g.nCols[l], wCell = g.wCell[l], hCell = g.hCell[l];
+    const int ci = cell / nCols, cj = cell - ci * nCols;
+    const float iniY = (float)(minBY + ci * hCell), iniX = (float)(minBX + cj * wCell);
+    float maxY = iniY + hCell + 6, maxX = iniX + wCell + 6;
+    int *cnt = cell_cnt + (int64_t)b * cnt_img_stride + g.cell_off[l] + cell;
+    const int tid = threadIdx.x;
+    bool skip = iniY >= maxBY - 3 || iniX >= maxBX - 6;
+    if (maxY > maxBY) maxY = (float)maxBY;
+    if (maxX > maxBX) maxX = (float)maxBX;
+    const int x0 = (int)iniX, y0 = (int)iniY, cw = (int)maxX - x0, ch = (int)maxY - y0;
+    if (skip || cw < 7 || ch < 7) { if (tid == 0) *cnt = 0; return; }
+    const uint8_t *img = slots + (int64_t)b * slot_stride + g.origin[l];
+    if (tid == 0) { s_any = 0; s_found = 0; }
+    for (int i = tid; i < cw * ch; i += 256) {
+        int y = i / cw, x = i - y * cw;
+        raw[y * kCellMax + x] = img[(int64_t)(y0 + y) * pitch + x0 + x];
+    }
+    __syncthreads();
+    int any = 0;
+    for (int i = tid; i < cw * ch; i += 256) {
+        int y = i / cw, x = i - y * cw, v = 0;
+        if (x >= 3 && x < cw - 3 && y >= 3 && y < ch - 3) v = fast_cornerness(&raw[y * kCellMax + x], kCellMax);
+        V[y * kCellMax + x] = (uint8_t)v;
+        any |= v >= iniTh;
+    }
+    if (any) s_any = 1;
+    __syncthreads();
+    int thr = s_any ? iniTh : minTh;
+    for (int pass = 0; pass < 2; pass++) {
+        int found = 0;
+        for (int i = tid; i < cw * ch; i += 256) {
+            int y = i / cw, x = i - y * cw, k = 0;
+            if (x >= 3 && x < cw - 3 && y >= 3 && y < ch - 3) {
+                const uint8_t *p = &V[y * kCellMax + x];
+                const int s = p[0];
+                if (s >= thr) {
+#define SC(o) (p[o] >= thr ? (int)p[o] : 0)
+                    k = s > SC(-1) && s > SC(1) && s > SC(-kCellMax - 1) && s > SC(-kCellMax) && s > SC(-kCellMax + 1) &&
+                        s > SC(kCellMax - 1) && s > SC(kCellMax) && s > SC(kCellMax + 1);
+#undef SC
+                }
+            }
+            keep[y * kCellMax + x] = (uint8_t)k;
+            found |= k;
+        }
+        if (found) s_found = 1;
+        __syncthreads();
+        // "if (vKeysCell.empty()) FAST(..., minThFAST)": strict NMS can empty a cell whose corners tie
+        if (s_found || thr == minTh) break;
+        thr = minTh;
+        __syncthreads();
+    }
+    // ordered (row-major) emission by wave 0
+    if (tid < 64) {
+        float4 *out = cell_cand + (int64_t)b * cand_img_stride + ((int64_t)g.cell_off[l] + cell) * kCellCap;
+        int n = 0;
+        for (int i0 = 0; i0 < cw * ch; i0 += 64) {
+            const int i = i0 + tid;
+            int y = 0, x = 0, k = 0;
+            if (i < cw * ch) { y = i / cw; x = i - y * cw; k = keep[y * kCellMax + x]; }
+            const unsigned long long m = __ballot(k != 0);
+            if (k) {
+                const int idx = n + __popcll(m & ((1ull << tid) - 1ull));
+                if (idx < kCellCap)
+                    out[idx] = make_float4((float)x + (float)(cj * wCell), (float)y + (float)(ci * hCell),
+                                           (float)V[y * kCellMax + x], 0.f);
+            }
+            n += __popcll(m);
+        }
+        if (tid == 0) *cnt = n;          // may exceed kCellCap: checked on the host side of the stage API
+    }
+}
+
+// cells -> level candidate list (cells row-major): one workgroup per (level, image)
+__global__ __launch_bounds__(256) void orb_gather_kernel(OrbGeom g, const float4 *cell_cand, const int *cell_cnt,
+                                                         int64_t cand_img_stride, int64_t cnt_img_stride,
+                                                         float4 *lvl_cand, int *lvl_cnt, int cand_cap, int *overflow)
+{
+    __shared__ int offs[1024];
+    __shared__ int total;
+    const int l = blockIdx.x, b = blockIdx.y;
+    const int ncell = g.ncell[l];
+    const int *cnt = cell_cnt + (int64_t)b * cnt_img_stride + g.cell_off[l];
+    if (threadIdx.x == 0) {
+        int s = 0;
+        bool ovf = false;
+        for (int c = 0; c < ncell; c++) { offs[c] = s; s += min(cnt[c], kCellCap); ovf = ovf || cnt[c] > kCellCap; }
+        total = s;
+        if (ovf || s > cand_cap) atomicOr(overflow, 2);
+    }
+    __syncthreads();
+    const float4 *src = cell_cand + (int64_t)b * cand_img_stride + (int64_t)g.cell_off[l] * kCellCap;
+    float4 *dst = lvl_cand + ((int64_t)b * g.nlevels + l) * cand_cap;
+    for (int c = threadIdx.x >> 6; c < ncell; c += 4) {
+        const int n = min(cnt[c], kCellCap), o = offs[c];
+        for (int k = threadIdx.x & 63; k < n; k += 64)
+            if (o + k < cand_cap) dst[o + k] = src[(int64_t)c * kCellCap + k];
+    }
+    if (threadIdx.x == 0) lvl_cnt[b * g.nlevels + l] = min(total, cand_cap);
+}
+
+// ---- DistributeOctTree: array-based std::list, one lane per (level, image) ---------------------
+struct QNode { int ulx, uly, brx, bry, begin, count, prev, next, seq; };   // flags: count == 1 -> bNoMore
+constexpr int kQNodes = 4096;
+
+struct QTree {
+    QNode *nodes; int *idx; int *tmp; int *free_list;
+    int n_free, n_alloc, head, tail, size, seq;
+    const float4 *keys;
+    bool overflow;
+};
+
+__device__ inline int qt_new(QTree &t)
+{
+    int id;
+    if (t.n_free > 0) id = t.free_list[--t.n_free];
+    else if (t.n_alloc < kQNodes) id = t.n_alloc++;
+    else { t.overflow = true; id = kQNodes - 1; }
+    t.nodes[id].seq = t.seq++;
+    return id;
+}
+__device__ inline void qt_push_front(QTree &t, int id)
+{
+    t.nodes[id].next = t.head; t.nodes[id].prev = -1;
+    if (t.head >= 0) t.nodes[t.head].prev = id; else t.tail = id;
+    t.head = id; t.size++;
+}
+__device__ inline void qt_push_back(QTree &t, int id)
+{
+    t.nodes[id].prev = t.tail; t.nodes[id].next = -1;
+    if (t.tail >= 0) t.nodes[t.tail].next = id; else t.head = id;
+    t.tail = id; t.size++;
+}
+__device__ inline void qt_erase(QTree &t, int id)
+{
+    const int p = t.nodes[id].prev, n = t.nodes[id].next;
+    if (p >= 0) t.nodes[p].next = n; else t.head = n;
+    if (n >= 0) t.nodes[n].prev = p; else t.tail = p;
+    t.size--;
+    t.free_list[t.n_free++] = id;
+}
+// ExtractorNode::DivideNode: stable 4-way partition of the node's key range (in place via tmp)
+__device__ inline void qt_divide(QTree &t, int id, int ch[4])
+{
+    const QNode P = t.nodes[id];
+    const int halfX = (int)ceilf((float)(P.brx - P.ulx) / 2), halfY = (int)ceilf((float)(P.bry - P.uly) / 2);
+    const int midx = P.ulx + halfX, midy = P.uly + halfY;
+    int cnt[4] = {0, 0, 0, 0};
+    for (int k = 0; k < P.count; k++) {
+        const float4 kp = t.keys[t.idx[P.begin + k]];
+        const int q = kp.x < (float)midx ? (kp.y < (float)midy ? 0 : 2) : (kp.y < (float)midy ? 1 : 3);
+        t.tmp[k] = q; cnt[q]++;
+    }
+    int off[4] = {0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2]};
+    // stable scatter into tmp[count ..] then copy back
+    int pos[4] = {off[0], off[1], off[2], off[3]};
+    for (int k = 0; k < P.count; k++) { const int q = t.tmp[k]; t.tmp[P.count + pos[q]++] = t.idx[P.begin + k]; }
+    for (int k = 0; k < P.count; k++) t.idx[P.begin + k] = t.tmp[P.count + k];
+    const int ulx[4] = {P.ulx, midx, P.ulx, midx}, uly[4] = {P.uly, P.uly, midy, midy};
+    const int brx[4] = {midx, P.brx, midx, P.brx}, bry[4] = {midy, midy, P.bry, P.bry};
+    for (int q = 0; q < 4; q++) {
+        ch[q] = -1;
+        if (cnt[q] == 0) continue;
+        const int nid = qt_new(t);
+        QNode &c = t.nodes[nid];
+        c.ulx = ulx[q]; c.uly = uly[q]; c.brx = brx[q]; c.bry = bry[q];
+        c.begin = P.begin + off[q]; c.count = cnt[q];
+        ch[q] = nid;
+    }
+}
+
+// sort key: (size, creation order) ascending -- CANONICAL (O1)
+__device__ inline bool exp_less(const int2 &a, const int2 &b, const QNode *nodes)
+{
+    return a.x != b.x ? a.x < b.x : nodes[a.y].seq < nodes[b.y].seq;
+}
+__device__ inline void exp_sort(int2 *v, int n, const QNode *nodes)      // heapsort
+{
+    for (int start = n / 2 - 1; start >= 0; start--) {
+        int root = start;
+        for (;;) {
+            int child = 2 * root + 1;
+            if (child >= n) break;
+            if (child + 1 < n && exp_less(v[child], v[child + 1], nodes)) child++;
+            if (!exp_less(v[root], v[child], nodes)) break;
+            int2 t = v[root]; v[root] = v[child]; v[child] = t; root = child;
+        }
+    }
+    for (int end = n - 1; end > 0; end--) {
+        int2 t = v[0]; v[0] = v[end]; v[end] = t;
+        int root = 0;
+        for (;;) {
+            int child = 2 * root + 1;
+            if (child >= end) break;
+            if (child + 1 < end && exp_less(v[child], v[child + 1], nodes)) child++;
+            if (!exp_less(v[root], v[child], nodes)) break;
+            int2 t2 = v[root]; v[root] = v[child]; v[child] = t2; root = child;
+        }
+    }
+}
+
+struct OrbDistArgs {
+    OrbGeom g;
+    const float4 *lvl_cand; const int *lvl_cnt; int cand_cap;
+    // scratch per instance
+    QNode *nodes; int *idx; int *tmp; int *free_list; int2 *exp_a; int2 *exp_b;
+    // outputs: selected candidate indices in list order
+    int *sel; int *sel_cnt; int sel_cap;
+    int *overflow;
+};
+
+__global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
+{
+    if (threadIdx.x != 0) return;
+    const int l = blockIdx.x, b = blockIdx.y, inst = b * a.g.nlevels + l;
+    const int nkeys = a.lvl_cnt[inst];
+    const float4 *keys = a.lvl_cand + (int64_t)inst * a.cand_cap;
+    int *sel = a.sel + (int64_t)inst * a.sel_cap;
+    const int W = a.g.w[l], H = a.g.h[l];
+    const int minX = 16, maxX = W - 16, minY = 16, maxY = H - 16, N = a.g.quota[l];
+    QTree t;
+    t.nodes = a.nodes + (int64_t)inst * kQNodes; t.idx = a.idx + (int64_t)inst * a.cand_cap;
+    t.tmp = a.tmp + (int64_t)inst * 2 * a.cand_cap; t.free_list = a.free_list + (int64_t)inst * kQNodes;
+    int2 *ea = a.exp_a + (int64_t)inst * kQNodes, *eb = a.exp_b + (int64_t)inst * kQNodes;
+    t.n_free = 0; t.n_alloc = 0; t.head = t.tail = -1; t.size = 0; t.seq = 0; t.keys = keys; t.overflow = false;
+    if (maxX <= minX || maxY <= minY || nkeys == 0) { a.sel_cnt[inst] = 0; return; }
+    const int nIni = (int)roundf((float)(maxX - minX) / (maxY - minY));
+    if (nIni <= 0) { a.sel_cnt[inst] = 0; return; }
+    const float hX = (float)(maxX - minX) / nIni;
+    // root nodes: count, then fill (stable)
+    int rbeg = 0;
+    for (int i = 0; i < nIni && i < 64; i++) t.tmp[i] = 0;
+    for (int k = 0; k < nkeys; k++) t.tmp[min((int)(keys[k].x / hX), nIni - 1)]++;
+    int root[64];
+    for (int i = 0; i < nIni && i < 64; i++) {
+        const int id = qt_new(t);
+        QNode &n = t.nodes[id];
+        n.ulx = (int)(hX * (float)i); n.uly = 0; n.brx = (int)(hX * (float)(i + 1)); n.bry = maxY - minY;
+        n.begin = rbeg; n.count = 0;
+        rbeg += t.tmp[i];
+        qt_push_back(t, id);
+        root[i] = id;
+    }
+    for (int k = 0; k < nkeys; k++) { QNode &n = t.nodes[root[min((int)(keys[k].x / hX), nIni - 1)]]; t.idx[n.begin + n.count++] = k; }
+    for (int i = t.head; i >= 0;) { const int nx = t.nodes[i].next; if (t.nodes[i].count == 0) qt_erase(t, i); i = nx; }
+
+    bool finish = false;
+    int n_exp = 0;
+    while (!finish) {
+        int prevSize = t.size, nToExpand = 0, lit = t.head, ch[4];
+        n_exp = 0;
+        while (lit >= 0) {
+            if (t.nodes[lit].count == 1) { lit = t.nodes[lit].next; continue; }
+            qt_divide(t, lit, ch);
+            for (int q = 0; q < 4; q++)
+                if (ch[q] >= 0) {
+                    qt_push_front(t, ch[q]);
+                    if (t.nodes[ch[q]].count > 1) { nToExpand++; if (n_exp < kQNodes) ea[n_exp++] = make_int2(t.nodes[ch[q]].count, ch[q]); }
+                }
+            const int nx = t.nodes[lit].next;
+            qt_erase(t, lit);
+            lit = nx;
+        }
+        if (t.size >= N || t.size == prevSize) finish = true;
+        else if (t.size + nToExpand * 3 > N) {
+            while (!finish) {
+                prevSize = t.size;
+                const int n_prev = n_exp;
+                for (int j = 0; j < n_prev; j++) eb[j] = ea[j];
+                n_exp = 0;
+                exp_sort(eb, n_prev, t.nodes);
+                for (int j = n_prev - 1; j >= 0; j--) {
+                    qt_divide(t, eb[j].y, ch);
+                    for (int q = 0; q < 4; q++)
+                        if (ch[q] >= 0) {
+                            qt_push_front(t, ch[q]);
+                            if (t.nodes[ch[q]].count > 1 && n_exp < kQNodes) ea[n_exp++] = make_int2(t.nodes[ch[q]].count, ch[q]);
+                        }
+                    qt_erase(t, eb[j].y);
+                    if (t.size >= N) break;
+                }
+                if (t.size >= N || t.size == prevSize) finish = true;
+            }
+        }
+        if (t.overflow) break;
+    }
+    int m = 0;
+    for (int i = t.head; i >= 0 && m < a.sel_cap; i = t.nodes[i].next) {
+        const QNode &n = t.nodes[i];
+        int best = t.idx[n.begin];
+        float maxR = keys[best].z;
+        for (int k = 1; k < n.count; k++) {
+            const int c = t.idx[n.begin + k];
+            if (keys[c].z > maxR) { best = c; maxR = keys[c].z; }
+        }
+        sel[m++] = best;
+    }
+    a.sel_cnt[inst] = m;
+    if (t.overflow) atomicOr(a.overflow, 1);
+}
+
+// ---- blur (7x7, sigma 2, reflect-101; integer kernel, (sum + 2^15) >> 16, saturated) -------------
+__global__ __launch_bounds__(256) void orb_blur_rows_kernel(OrbGeom g, const uint8_t *slots, int64_t slot_stride, int l,
+                                                            int *tmp, int64_t tmp_img_stride)
+{
+    const int b = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    const int w = g.w[l];
+    if (x >= w) return;
+    const uint8_t *row = slots + (int64_t)b * slot_stride + g.origin[l] + (int64_t)y * g.pitch[l];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) s += g.gk[i] * row[refl101(x + i - 3, w)];
+    tmp[(int64_t)b * tmp_img_stride + g.blur_off[l] + (int64_t)y * w + x] = s;
+}
+__global__ __launch_bounds__(256) void orb_blur_cols_kernel(OrbGeom g, const int *tmp, int64_t tmp_img_stride, int l,
+                                                            uint8_t *blur, int64_t blur_img_stride)
+{
+    const int b = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    const int w = g.w[l], h = g.h[l];
+    if (x >= w) return;
+    const int *t = tmp + (int64_t)b * tmp_img_stride + g.blur_off[l];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) s += g.gk[i] * t[(int64_t)refl101(y + i - 3, h) * w + x];
+    s = (s + (1 << 15)) >> 16;
+    blur[(int64_t)b * blur_img_stride + g.blur_off[l] + (int64_t)y * w + x] = (uint8_t)(s > 255 ? 255 : s);
+}
+
+// ---- orientation + descriptor + final keypoint record -------------------------------------------
+__device__ inline float fast_atan2_deg(float y, float x)
+{
+    const float scale = (float)(180 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale,
+                p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+struct OrbDescArgs {
+    OrbGeom g;
+    const uint8_t *slots; int64_t slot_stride;
+    const uint8_t *blur; int64_t blur_img_stride;
+    const float4 *lvl_cand; int cand_cap;
+    const int *sel; const int *sel_cnt; int sel_cap;
+    svo_keypoint *kps; uint8_t *desc; int *n_out; int out_cap;       // per image: out_cap keypoints
+};
+
+// one wave per keypoint: lanes 0..31 compute one descriptor byte each; the angle is computed by
+// the whole wave (749 patch pixels reduced with exact integer sums)
+__global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int gidx = blockIdx.x * 4 + (threadIdx.x >> 6);            // keypoint index in the image's output
+    // locate level: prefix over the per-level selected counts
+    int l = 0, base = 0, total = 0;
+    for (int q = 0; q < a.g.nlevels; q++) total += a.sel_cnt[b * a.g.nlevels + q];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.n_out[b] = min(total, a.out_cap);
+    if (gidx >= total || gidx >= a.out_cap) return;
+    for (l = 0; l < a.g.nlevels; l++) {
+        const int c = a.sel_cnt[b * a.g.nlevels + l];
+        if (gidx < base + c) break;
+        base += c;
+    }
+    const int inst = b * a.g.nlevels + l;
+    const float4 cand = a.lvl_cand[(int64_t)inst * a.cand_cap + a.sel[(int64_t)inst * a.sel_cap + (gidx - base)]];
+    const float x = cand.x + 16.f, y = cand.y + 16.f;                // += minBorderX / minBorderY
+    const int ix = __float2int_rn(x), iy = __float2int_rn(y);
+    const int pitch = a.g.pitch[l], w = a.g.w[l];
+    const uint8_t *center = a.slots + (int64_t)b * a.slot_stride + a.g.origin[l] + (int64_t)iy * pitch + ix;
+    // IC_Angle: m10 = sum u * I, m01 = sum v * I over the circular patch (rows v = -15..15)
+    int m10 = 0, m01 = 0;
+    if (lane < 31) {
+        const int v = lane - 15, d = a.g.umax[v < 0 ? -v : v];
+        const uint8_t *row = center + (int64_t)v * pitch;
+        int s = 0, su = 0;
+        for (int u = -d; u <= d; ++u) { const int val = row[u]; s += val; su += u * val; }
+        m10 = su; m01 = v * s;
+    }
+    m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // computeOrbDescriptor on the blurred level
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float ang = angle * factorPI;
+    const float ca = (float)cos((double)ang), sb = (float)sin((double)ang);
+    const uint8_t *bc = a.blur + (int64_t)b * a.blur_img_stride + a.g.blur_off[l] + (int64_t)iy * w + ix;
+    if (lane < 32) {
+        const signed char *pat = c_pattern + lane * 32;
+        int val = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float xa = (float)pat[4 * k], ya = (float)pat[4 * k + 1], xb = (float)pat[4 * k + 2], yb = (float)pat[4 * k + 3];
+            const int t0 = bc[__float2int_rn(xa * sb + ya * ca) * w + __float2int_rn(xa * ca - ya * sb)];
+            const int t1 = bc[__float2int_rn(xb * sb + yb * ca) * w + __float2int_rn(xb * ca - yb * sb)];
+            val |= (t0 < t1) << k;
+        }
+        a.desc[((int64_t)b * a.out_cap + gidx) * 32 + lane] = (uint8_t)val;
+    }
+    if (lane == 0) {
+        svo_keypoint kp;
+        const float sc = a.g.scale[l];
+        kp.x = l != 0 ? x * sc : x; kp.y = l != 0 ? y * sc : y;
+        kp.size = (float)(int)(31 * sc); kp.angle = angle; kp.response = cand.z; kp.octave = l; kp.class_id = -1;
+        a.kps[(int64_t)b * a.out_cap + gidx] = kp;
+    }
+}
+
+// ---- BruteForce-Hamming match: one wave per query row, first minimum ------------------------------
+__global__ __launch_bounds__(256) void orb_match_kernel(const uint8_t *q, const int *nq_p, int nq_fixed, int64_t q_stride,
+                                                        const uint8_t *t, const int *nt_p, int nt_fixed, int64_t t_stride,
+                                                        int *idx, float *dist, int64_t out_stride)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nq = nq_p ? nq_p[b] : nq_fixed, nt = nt_p ? nt_p[b] : nt_fixed;
+    if (i >= nq) return;
+    const uint4 *qr = (const uint4 *)(q + (int64_t)b * q_stride + (int64_t)i * 32);
+    const uint4 q0 = qr[0], q1 = qr[1];
+    int best = 1 << 30, bj = -1;
+    for (int j = lane; j < nt; j += 64) {
+        const uint4 *tr = (const uint4 *)(t + (int64_t)b * t_stride + (int64_t)j * 32);
+        const uint4 t0 = tr[0], t1 = tr[1];
+        const int d = __popc(q0.x ^ t0.x) + __popc(q0.y ^ t0.y) + __popc(q0.z ^ t0.z) + __popc(q0.w ^ t0.w) +
+                      __popc(q1.x ^ t1.x) + __popc(q1.y ^ t1.y) + __popc(q1.z ^ t1.z) + __popc(q1.w ^ t1.w);
+        if (d < best) { best = d; bj = j; }        // j ascends per lane: first minimum kept
+    }
+    // lexicographic (distance, index) minimum across the wave == first minimum overall
+    unsigned long long key = bj >= 0 ? (((unsigned long long)(unsigned)best << 32) | (unsigned)bj) : ~0ull;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long o = __shfl_xor(key, m, 64);
+        key = o < key ? o : key;
+    }
+    if (lane == 0) {
+        idx[(int64_t)b * out_stride + i] = nt > 0 ? (int)(unsigned)key : -1;
+        dist[(int64_t)b * out_stride + i] = nt > 0 ? (float)(int)(key >> 32) : (float)(1 << 30);
+    }
+}
+
+// Tracking::ORB_Robust_Find_MuliImage_MatchedFeatures' filter (src/tracking.cpp:546-577): one
+// workgroup per pair; ordered emission of (t1_left, t1_right, t2_left).
+struct OrbFilterArgs {
+    const svo_keypoint *lastL, *lastR, *curL; int64_t kp_stride_prev, kp_stride_cur;   // per pair strides (keypoints)
+    const int *nLastL, *nLastR, *nCurL; int n_stride;
+    const int *i1, *i2; const float *d1, *d2; int64_t m_stride;
+    double match_err;
+    float2 *t1l, *t1r, *t2l; int64_t out_stride;
+    int *m_out;
+};
+__global__ __launch_bounds__(256) void orb_filter_kernel(OrbFilterArgs a)
+{
+    __shared__ float s_min[4], s_max[4];
+    __shared__ int s_base, s_wave[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nL = a.nLastL[b * a.n_stride], nR = a.nLastR[b * a.n_stride], nC = a.nCurL[b * a.n_stride];
+    const int des_index = min(min(nL, nR), nC);
+    const float *d1 = a.d1 + (int64_t)b * a.m_stride, *d2 = a.d2 + (int64_t)b * a.m_stride;
+    const int *i1 = a.i1 + (int64_t)b * a.m_stride, *i2 = a.i2 + (int64_t)b * a.m_stride;
+    float mn = 10000.f, mx = 0.f;
+    for (int i = tid; i < des_index; i += 256) { const float d = fmaxf(d1[i], d2[i]); mn = fminf(mn, d); mx = fmaxf(mx, d); }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { mn = fminf(mn, __shfl_xor(mn, m, 64)); mx = fmaxf(mx, __shfl_xor(mx, m, 64)); }
+    if (lane == 0) { s_min[wv] = mn; s_max[wv] = mx; }
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    const double min_dist = (double)fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
+    const double thr = 2 * min_dist > 30.0 ? 2 * min_dist : 30.0;
+    const svo_keypoint *lastL = a.lastL + (int64_t)b * a.kp_stride_prev, *lastR = a.lastR + (int64_t)b * a.kp_stride_prev;
+    const svo_keypoint *curL = a.curL + (int64_t)b * a.kp_stride_cur;
+    const int64_t o = (int64_t)b * a.out_stride;
+    for (int start = 0; start < des_index; start += 256) {
+        const int i = start + tid;
+        bool k = false;
+        if (i < des_index)
+            k = ((double)d1[i] <= thr) && ((double)d2[i] <= thr) &&
+                ((double)fabsf(lastL[i].y - lastR[i1[i]].y) < a.match_err);
+        const unsigned long long m = __ballot(k);
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wv] = __popcll(m);
+        __syncthreads();
+        int pre = 0, tot = 0;
+        for (int q = 0; q < 4; q++) { if (q < wv) pre += s_wave[q]; tot += s_wave[q]; }
+        if (k) {
+            const int dst = s_base + pre + rank;
+            a.t1l[o + dst] = make_float2(lastL[i].x, lastL[i].y);
+            a.t1r[o + dst] = make_float2(lastR[i1[i]].x, lastR[i1[i]].y);
+            a.t2l[o + dst] = make_float2(curL[i2[i]].x, curL[i2[i]].y);
+        }
+        __syncthreads();
+        if (tid == 0) s_base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) a.m_out[b] = s_base;
+}
+
+// ---- host side --------------------------------------------------------------------------------
+static int align_up_i(int v, int a) { return (v + a - 1) / a * a; }
+
+// ORBextractor::ORBextractor + ComputePyramid geometry (all float/double expressions as the
+// reference evaluates them)
+int orb_make_geom(const svo_config &cfg, OrbGeom *g)
+{
+    memset(g, 0, sizeof(*g));
+    const int nlevels = cfg.orb_nlevels, nfeatures = cfg.orb_nfeatures;
+    if (nlevels < 1 || nlevels > kOrbMaxLevels) return SVO_ERR_ARG;
+    g->nlevels = nlevels;
+    const double scaleFactor = (double)cfg.orb_scale_factor;
+    float inv_scale[kOrbMaxLevels];
+    g->scale[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) g->scale[i] = (float)(g->scale[i - 1] * scaleFactor);
+    for (int i = 0; i < nlevels; i++) inv_scale[i] = 1.0f / g->scale[i];
+    const float factor = (float)(1.0f / scaleFactor);
+    float nDesired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int level = 0; level < nlevels - 1; level++) {
+        g->quota[level] = (int)lrintf(nDesired);
+        sum += g->quota[level];
+        nDesired *= factor;
+    }
+    g->quota[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+    const int vmax = (int)floor(15 * sqrt(2.f) / 2 + 1), vmin = (int)ceil(15 * sqrt(2.f) / 2);
+    for (int v = 0; v <= vmax; ++v) g->umax[v] = (int)lrint(sqrt(225.0 - v * v));
+    for (int v = 15, v0 = 0; v >= vmin; --v) {
+        while (g->umax[v0] == g->umax[v0 + 1]) ++v0;
+        g->umax[v] = v0;
+        ++v0;
+    }
+    // getGaussianKernel(7, 2, CV_32F) * 256, rounded (legacy 8-bit fixed-point GaussianBlur)
+    {
+        double t[7], s = 0;
+        for (int i = 0; i < 7; i++) { double x = i - 3; float f = (float)exp(-0.5 / (2.0 * 2.0) * x * x); t[i] = f; s += f; }
+        s = 1. / s;
+        for (int i = 0; i < 7; i++) { float f = (float)(t[i] * s); g->gk[i] = (int)lrintf(f * 256.f); }
+    }
+    int64_t off = 0, boff = 0;
+    int coff = 0;
+    for (int l = 0; l < nlevels; l++) {
+        g->w[l] = (int)lrintf((float)cfg.width * inv_scale[l]);
+        g->h[l] = (int)lrintf((float)cfg.height * inv_scale[l]);
+        if (g->w[l] < 1 || g->h[l] < 1) return SVO_ERR_ARG;
+        g->pitch[l] = align_up_i(g->w[l] + 2 * kPad, 64);
+        g->origin[l] = off + (int64_t)kPad * g->pitch[l] + kPad;
+        off += (int64_t)g->pitch[l] * (g->h[l] + 2 * kPad);
+        off = (off + 255) / 256 * 256;
+        g->blur_off[l] = boff;
+        boff += (int64_t)g->w[l] * g->h[l];
+        // cell grid of ComputeKeyPointsOctTree (:729-741)
+        const int maxBX = g->w[l] - 16, maxBY = g->h[l] - 16;
+        const float width = (float)(maxBX - 16), height = (float)(maxBY - 16);
+        const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
+        g->cell_off[l] = coff;
+        if (nCols > 0 && nRows > 0 && width > 0 && height > 0) {
+            g->nCols[l] = nCols; g->nRows[l] = nRows;
+            g->wCell[l] = (int)ceil(width / nCols); g->hCell[l] = (int)ceil(height / nRows);
+            if (g->wCell[l] + 6 > kCellMax || g->hCell[l] + 6 > kCellMax) return SVO_ERR_ARG;
+            g->ncell[l] = nCols * nRows;
+            if (g->ncell[l] > 1024) return SVO_ERR_ARG;
+        }
+        coff += g->ncell[l];
+    }
+    g->slot_bytes = off;
+    g->blur_total = boff;
+    g->cells_total = coff;
+    return SVO_OK;
+}
+
+static const int kSelCap = 1024;      // quadtree leaves per (image, level)
+
+int orb_alloc(svo_ctx *ctx)
+{
+    if (ctx->orb_ready) return SVO_OK;
+    OrbGeom &g = ctx->orb_geom;
+    int rc = orb_make_geom(ctx->cfg, &g);
+    if (rc) { ctx->err = "ORB geometry: unsupported image size / level count"; return rc; }
+    const int n_img = 2 * ctx->n_img;                  // left + right of every frame slot
+    const int L = g.nlevels;
+    ctx->orb_cand_cap = 4 * ctx->cfg.max_keypoints;      // FAST candidates kept per (image, level)
+    const int kCandCap = ctx->orb_cand_cap;
+    SVO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), svo_bit_pattern_31, 1024));
+    SVO_HIP(hipMalloc(&ctx->orb_slots, (size_t)g.slot_bytes * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_blur, (size_t)g.blur_total * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_tmp, sizeof(int) * (size_t)g.blur_total * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_cell_cand, sizeof(float4) * (size_t)g.cells_total * kCellCap * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_cell_cnt, sizeof(int) * (size_t)g.cells_total * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_lvl_cand, sizeof(float4) * (size_t)kCandCap * L * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_lvl_cnt, sizeof(int) * (size_t)L * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_nodes, sizeof(QNode) * (size_t)kQNodes * L * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_idx, sizeof(int) * (size_t)kCandCap * L * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_qtmp, sizeof(int) * (size_t)2 * kCandCap * L * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_free, sizeof(int) * (size_t)kQNodes * L * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_exp_a, sizeof(int2) * (size_t)kQNodes * L * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_exp_b, sizeof(int2) * (size_t)kQNodes * L * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_sel, sizeof(int) * (size_t)kSelCap * L * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_sel_cnt, sizeof(int) * (size_t)L * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_overflow, sizeof(int)));
+    SVO_HIP(hipMemset(ctx->orb_overflow, 0, sizeof(int)));
+    ctx->orb_kp_cap = ctx->cfg.max_keypoints;
+    SVO_HIP(hipMalloc(&ctx->orb_kps, sizeof(svo_keypoint) * (size_t)ctx->orb_kp_cap * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_desc, (size_t)32 * ctx->orb_kp_cap * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_n, sizeof(int) * (size_t)n_img));
+    const int B = ctx->cfg.max_batch;
+    for (int k = 0; k < 2; k++) {
+        SVO_HIP(hipMalloc(&ctx->orb_midx[k], sizeof(int) * (size_t)ctx->orb_kp_cap * B));
+        SVO_HIP(hipMalloc(&ctx->orb_mdist[k], sizeof(float) * (size_t)ctx->orb_kp_cap * B));
+    }
+    ctx->orb_ready = true;
+    return SVO_OK;
+}
+
+void orb_free(svo_ctx *c)
+{
+    auto F = [](void *p) { if (p) (void)hipFree(p); };
+    F(c->orb_slots); F(c->orb_blur); F(c->orb_tmp); F(c->orb_cell_cand); F(c->orb_cell_cnt); F(c->orb_lvl_cand);
+    F(c->orb_lvl_cnt); F(c->orb_nodes); F(c->orb_idx); F(c->orb_qtmp); F(c->orb_free); F(c->orb_exp_a); F(c->orb_exp_b);
+    F(c->orb_sel); F(c->orb_sel_cnt); F(c->orb_overflow); F(c->orb_kps); F(c->orb_desc); F(c->orb_n);
+    for (int k = 0; k < 2; k++) { F(c->orb_midx[k]); F(c->orb_mdist[k]); }
+}
+
+// ORBextractor::operator() on `n_img` images (image b at img + b*img_stride, or interleaved L/R
+// when img2 != null) into output slots [slot0, slot0 + n_img).
+int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int pitch, int64_t img_stride, int slot0,
+                      int n_img, hipStream_t st)
+{
+    const OrbGeom &g = ctx->orb_geom;
+    const int L = g.nlevels, kCandCap = ctx->orb_cand_cap;
+    uint8_t *slots = ctx->orb_slots + (size_t)slot0 * g.slot_bytes;
+    dim3 blk(256);
+    if (img2) {
+        // left images -> even slots, right images -> odd slots
+        hipLaunchKernelGGL(orb_copy0_kernel, dim3((g.w[0] + 255) / 256, g.h[0], n_img / 2), blk, 0, st, g, img, pitch, img_stride,
+                           slots, 2 * g.slot_bytes);
+        hipLaunchKernelGGL(orb_copy0_kernel, dim3((g.w[0] + 255) / 256, g.h[0], n_img / 2), blk, 0, st, g, img2, pitch, img_stride,
+                           slots + g.slot_bytes, 2 * g.slot_bytes);
+    } else {
+        hipLaunchKernelGGL(orb_copy0_kernel, dim3((g.w[0] + 255) / 256, g.h[0], n_img), blk, 0, st, g, img, pitch, img_stride,
+                           slots, g.slot_bytes);
+    }
+    for (int l = 0; l < L; l++) {
+        if (l > 0)
+            hipLaunchKernelGGL(orb_resize_kernel, dim3((g.w[l] + 255) / 256, g.h[l], n_img), blk, 0, st, g, slots, g.slot_bytes, l);
+        hipLaunchKernelGGL(orb_border_kernel, dim3((g.w[l] + 2 * kPad + 255) / 256, g.h[l] + 2 * kPad, n_img), blk, 0, st, g,
+                           slots, g.slot_bytes, l);
+    }
+    float4 *cell_cand = ctx->orb_cell_cand + (size_t)slot0 * g.cells_total * kCellCap;
+    int *cell_cnt = ctx->orb_cell_cnt + (size_t)slot0 * g.cells_total;
+    for (int l = 0; l < L; l++)
+        if (g.ncell[l] > 0)
+            hipLaunchKernelGGL(orb_cellfast_kernel, dim3(g.ncell[l], 1, n_img), blk, 0, st, g, slots, g.slot_bytes, l,
+                               ctx->cfg.orb_ini_th, ctx->cfg.orb_min_th, cell_cand, cell_cnt,
+                               (int64_t)g.cells_total * kCellCap, (int64_t)g.cells_total);
+    float4 *lvl_cand = ctx->orb_lvl_cand + (size_t)slot0 * L * kCandCap;
+    int *lvl_cnt = ctx->orb_lvl_cnt + (size_t)slot0 * L;
+    hipLaunchKernelGGL(orb_gather_kernel, dim3(L, n_img), blk, 0, st, g, cell_cand, cell_cnt, (int64_t)g.cells_total * kCellCap,
+                       (int64_t)g.cells_total, lvl_cand, lvl_cnt, kCandCap, ctx->orb_overflow);
+    OrbDistArgs d{};
+    d.g = g; d.lvl_cand = lvl_cand; d.lvl_cnt = lvl_cnt; d.cand_cap = kCandCap;
+    d.nodes = (QNode *)ctx->orb_nodes + (size_t)slot0 * L * kQNodes; d.idx = ctx->orb_idx + (size_t)slot0 * L * kCandCap;
+    d.tmp = ctx->orb_qtmp + (size_t)slot0 * L * 2 * kCandCap; d.free_list = ctx->orb_free + (size_t)slot0 * L * kQNodes;
+    d.exp_a = (int2 *)ctx->orb_exp_a + (size_t)slot0 * L * kQNodes; d.exp_b = (int2 *)ctx->orb_exp_b + (size_t)slot0 * L * kQNodes;
+    d.sel = ctx->orb_sel + (size_t)slot0 * L * kSelCap; d.sel_cnt = ctx->orb_sel_cnt + (size_t)slot0 * L; d.sel_cap = kSelCap;
+    d.overflow = ctx->orb_overflow;
+    hipLaunchKernelGGL(orb_distribute_kernel, dim3(L, n_img), dim3(64), 0, st, d);
+    int *tmp = ctx->orb_tmp + (size_t)slot0 * g.blur_total;
+    uint8_t *blur = ctx->orb_blur + (size_t)slot0 * g.blur_total;
+    for (int l = 0; l < L; l++) {
+        hipLaunchKernelGGL(orb_blur_rows_kernel, dim3((g.w[l] + 255) / 256, g.h[l], n_img), blk, 0, st, g, slots, g.slot_bytes, l,
+                           tmp, g.blur_total);
+        hipLaunchKernelGGL(orb_blur_cols_kernel, dim3((g.w[l] + 255) / 256, g.h[l], n_img), blk, 0, st, g, tmp, g.blur_total, l,
+                           blur, g.blur_total);
+    }
+    OrbDescArgs e{};
+    e.g = g; e.slots = slots; e.slot_stride = g.slot_bytes; e.blur = blur; e.blur_img_stride = g.blur_total;
+    e.lvl_cand = lvl_cand; e.cand_cap = kCandCap; e.sel = d.sel; e.sel_cnt = d.sel_cnt; e.sel_cap = kSelCap;
+    e.kps = (svo_keypoint *)ctx->orb_kps + (size_t)slot0 * ctx->orb_kp_cap; e.desc = ctx->orb_desc + (size_t)slot0 * ctx->orb_kp_cap * 32;
+    e.n_out = ctx->orb_n + slot0; e.out_cap = ctx->orb_kp_cap;
+    int max_kp = 0;
+    for (int l = 0; l < L; l++) max_kp += g.quota[l] + 8;
+    if (max_kp > ctx->orb_kp_cap) max_kp = ctx->orb_kp_cap;
+    hipLaunchKernelGGL(orb_describe_kernel, dim3((max_kp + 3) / 4, n_img), blk, 0, st, e);
+    return SVO_OK;
+}
+
+void orb_launch_match_fixed(svo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, hipStream_t st)
+{
+    hipLaunchKernelGGL(orb_match_kernel, dim3((nq + 3) / 4, 1), dim3(256), 0, st, q, (const int *)nullptr, nq, (int64_t)0, t,
+                       (const int *)nullptr, nt, (int64_t)0, ctx->orb_midx[0], ctx->orb_mdist[0], (int64_t)ctx->orb_kp_cap);
+}
+
+// match + filter for n_pairs pairs: pair p = (frame fp0 + p*fstep, frame fc0 + p*fstep); writes
+// cmp[0] = t1_left, cmp[1] = t1_right, cmp[3] = t2_left, m_out
+int orb_match_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipStream_t st)
+{
+    const int cap = ctx->orb_kp_cap;
+    const uint8_t *D = ctx->orb_desc;
+    const int *N = ctx->orb_n;
+    const svo_keypoint *K = (const svo_keypoint *)ctx->orb_kps;
+    const int64_t fs = (int64_t)fstep * 2;                         // image slots per pair step
+    // match1: last.left -> last.right ; match2: last.left -> cur.left  (src/tracking.cpp:543-544)
+    hipLaunchKernelGGL(orb_match_kernel, dim3((cap + 3) / 4, n_pairs), dim3(256), 0, st, D + (size_t)(2 * fp0) * cap * 32,
+                       N + 2 * fp0, 0, fs * cap * 32, D + (size_t)(2 * fp0 + 1) * cap * 32, N + 2 * fp0 + 1, 0, fs * cap * 32,
+                       ctx->orb_midx[0], ctx->orb_mdist[0], (int64_t)cap);
+    hipLaunchKernelGGL(orb_match_kernel, dim3((cap + 3) / 4, n_pairs), dim3(256), 0, st, D + (size_t)(2 * fp0) * cap * 32,
+                       N + 2 * fp0, 0, fs * cap * 32, D + (size_t)(2 * fc0) * cap * 32, N + 2 * fc0, 0, fs * cap * 32,
+                       ctx->orb_midx[1], ctx->orb_mdist[1], (int64_t)cap);
+    OrbFilterArgs f{};
+    f.lastL = K + (size_t)(2 * fp0) * cap; f.lastR = K + (size_t)(2 * fp0 + 1) * cap; f.curL = K + (size_t)(2 * fc0) * cap;
+    f.kp_stride_prev = fs * cap; f.kp_stride_cur = fs * cap;
+    f.nLastL = N + 2 * fp0; f.nLastR = N + 2 * fp0 + 1; f.nCurL = N + 2 * fc0; f.n_stride = (int)fs;
+    f.i1 = ctx->orb_midx[0]; f.i2 = ctx->orb_midx[1]; f.d1 = ctx->orb_mdist[0]; f.d2 = ctx->orb_mdist[1]; f.m_stride = cap;
+    f.match_err = ctx->cfg.feature_match_error;
+    f.t1l = ctx->cmp[0]; f.t1r = ctx->cmp[1]; f.t2l = ctx->cmp[3]; f.out_stride = ctx->cfg.max_keypoints;
+    f.m_out = ctx->m_out;
+    hipLaunchKernelGGL(orb_filter_kernel, dim3(n_pairs), dim3(256), 0, st, f);
+    return SVO_OK;
+}
+
+}  // namespace svo

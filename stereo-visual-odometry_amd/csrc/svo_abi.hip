@@ -73,6 +73,12 @@ extern "C" void svo_default_config(svo_config *cfg, int width, int height)
     const double P2[12] = {fx, 0, cx, fx * tx, 0, fy, cy, 0, 0, 0, 1, 0};
     memcpy(cfg->P1, P1, sizeof(P1));
     memcpy(cfg->P2, P2, sizeof(P2));
+    cfg->track_mode = SVO_MODE_LK;
+    cfg->orb_nfeatures = 2000;              // config/default.yaml:93
+    cfg->orb_scale_factor = 1.2f;           // :92
+    cfg->orb_nlevels = 8;                   // :91
+    cfg->orb_ini_th = 20;                   // :90
+    cfg->orb_min_th = 7;                    // :89
 }
 
 static void free_all(svo_ctx *c)
@@ -85,6 +91,7 @@ static void free_all(svo_ctx *c)
     if (c->ev_front) (void)hipEventDestroy(c->ev_front);
     if (c->ev_back) (void)hipEventDestroy(c->ev_back);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    orb_free(c);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -150,10 +157,16 @@ extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
     CK(hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&ctx->ev_back, hipEventDisableTiming));
     ctx->h_pinned_bytes = sizeof(svo_step_result) * (size_t)B + 4096 +
-                          (size_t)cap * (sizeof(float2) + sizeof(float)) + sizeof(int) * 64;
+                          (size_t)cap * (sizeof(svo_keypoint) + 32) + sizeof(int) * 64;
     CK(hipHostMalloc(&ctx->h_pinned, ctx->h_pinned_bytes, hipHostMallocDefault));
     CK(hipStreamSynchronize(ctx->stream));
 #undef CK
+    if (cfg->track_mode == SVO_MODE_ORB) {
+        int rc = orb_alloc(ctx);
+        if (rc != SVO_OK) { fprintf(stderr, "svo_create: %s\n", ctx->err.c_str()); return fail(rc); }
+    } else if (cfg->track_mode != SVO_MODE_LK) {
+        return fail(SVO_ERR_ARG);
+    }
     *out = ctx;
     return SVO_OK;
 }
@@ -454,6 +467,109 @@ extern "C" int svo_circular_match(svo_ctx *ctx, int slot_prevL, int slot_prevR, 
         for (int i = 0; i < 4; i++)
             SVO_HIP(hipMemcpyAsync(outs[i], ctx->cmp[i], sizeof(float2) * (size_t)*h_m, hipMemcpyDeviceToHost, ctx->stream));
         SVO_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return SVO_OK;
+}
+
+extern "C" int svo_orb_extract(svo_ctx *ctx, const uint8_t *img, int pitch, int mem, svo_keypoint *kps, uint8_t *desc,
+                               int cap, int *n_out, int *per_level)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(kps && desc && n_out && cap >= 0, "null output");
+    SVO_HIP(hipSetDevice(ctx->device));
+    int rc = orb_alloc(ctx);
+    if (rc) return rc;
+    const uint8_t *d; int dp;
+    rc = resolve_image(ctx, img, pitch, mem, 0, &d, &dp);
+    if (rc) return rc;
+    rc = orb_extract_batch(ctx, d, nullptr, dp, 0, 0, 1, ctx->stream);
+    if (rc) return rc;
+    SVO_HIP(hipGetLastError());
+    int *h = (int *)ctx->h_pinned;        // [0] n, [1] overflow, [8..16) per-level counts, [32..) cell counts
+    SVO_HIP(hipMemcpyAsync(h, ctx->orb_n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipMemcpyAsync(h + 1, ctx->orb_overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipMemcpyAsync(h + 8, ctx->orb_sel_cnt, sizeof(int) * ctx->orb_geom.nlevels, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    const int n = h[0];
+    *n_out = n;
+    if (h[1]) {
+        ctx->err = (h[1] & 2) ? "ORB: FAST candidates exceed the per-level capacity (4 * max_keypoints)" : "ORB quadtree node pool overflow";
+        SVO_HIP(hipMemsetAsync(ctx->orb_overflow, 0, sizeof(int), ctx->stream));
+        return SVO_ERR_ARG;
+    }
+    if (per_level) for (int l = 0; l < 8; l++) per_level[l] = l < ctx->orb_geom.nlevels ? h[8 + l] : 0;
+    if (n > cap) { ctx->err = "ORB: keypoints exceed caller capacity"; return SVO_ERR_ARG; }
+    if (n == 0) return SVO_OK;
+    svo_keypoint *hk = (svo_keypoint *)((char *)ctx->h_pinned + 256);
+    uint8_t *hd = (uint8_t *)(hk + ctx->orb_kp_cap);
+    SVO_HIP(hipMemcpyAsync(hk, ctx->orb_kps, sizeof(svo_keypoint) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipMemcpyAsync(hd, ctx->orb_desc, (size_t)32 * n, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(kps, hk, sizeof(svo_keypoint) * (size_t)n);
+    memcpy(desc, hd, (size_t)32 * n);
+    return SVO_OK;
+}
+
+extern "C" int svo_orb_read_level(svo_ctx *ctx, int level, uint8_t *out, int *w, int *h)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_HIP(hipSetDevice(ctx->device));
+    int rc = orb_alloc(ctx);
+    if (rc) return rc;
+    SVO_ARG(level >= 0 && level < ctx->orb_geom.nlevels, "level out of range");
+    const OrbGeom &g = ctx->orb_geom;
+    if (w) *w = g.w[level];
+    if (h) *h = g.h[level];
+    if (!out) return SVO_OK;
+    SVO_HIP(hipMemcpy2DAsync(out, g.w[level], ctx->orb_slots + g.origin[level], g.pitch[level], g.w[level], g.h[level],
+                             hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    return SVO_OK;
+}
+
+extern "C" int svo_orb_read_candidates(svo_ctx *ctx, int level, float *out4, int cap, int *n_out)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_HIP(hipSetDevice(ctx->device));
+    int rc = orb_alloc(ctx);
+    if (rc) return rc;
+    SVO_ARG(level >= 0 && level < ctx->orb_geom.nlevels && out4 && n_out, "bad argument");
+    int n = 0;
+    SVO_HIP(hipMemcpy(&n, ctx->orb_lvl_cnt + level, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (n > cap) n = cap;
+    if (n > 0) SVO_HIP(hipMemcpy(out4, ctx->orb_lvl_cand + (size_t)level * ctx->orb_cand_cap, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return SVO_OK;
+}
+
+extern "C" int svo_match_hamming(svo_ctx *ctx, const uint8_t *query, int nq, const uint8_t *train, int nt,
+                                 int32_t *train_idx, float *distance, int mem)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE, "bad mem");
+    SVO_HIP(hipSetDevice(ctx->device));
+    int rc = orb_alloc(ctx);
+    if (rc) return rc;
+    SVO_ARG(nq >= 0 && nt >= 0 && nq <= ctx->orb_kp_cap && nt <= ctx->orb_kp_cap, "descriptor count exceeds max_keypoints");
+    if (nq == 0) return SVO_OK;
+    SVO_ARG(query && train_idx && distance && (train || nt == 0), "null pointer");
+    if (svo_wait_results(ctx) != SVO_OK) return SVO_ERR_HIP;
+    const uint8_t *dq = query, *dt = train;
+    if (mem == SVO_MEM_HOST) {
+        // stage through the descriptor slots of image 0 / 1
+        SVO_HIP(hipMemcpyAsync(ctx->orb_desc, query, (size_t)32 * nq, hipMemcpyHostToDevice, ctx->stream));
+        if (nt > 0) SVO_HIP(hipMemcpyAsync(ctx->orb_desc + (size_t)32 * ctx->orb_kp_cap, train, (size_t)32 * nt, hipMemcpyHostToDevice, ctx->stream));
+        dq = ctx->orb_desc; dt = ctx->orb_desc + (size_t)32 * ctx->orb_kp_cap;
+    }
+    orb_launch_match_fixed(ctx, dq, nq, dt, nt, ctx->stream);
+    SVO_HIP(hipGetLastError());
+    if (mem == SVO_MEM_HOST) {
+        SVO_HIP(hipMemcpyAsync(train_idx, ctx->orb_midx[0], sizeof(int) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+        SVO_HIP(hipMemcpyAsync(distance, ctx->orb_mdist[0], sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+        SVO_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+        SVO_HIP(hipMemcpyAsync(train_idx, ctx->orb_midx[0], sizeof(int) * (size_t)nq, hipMemcpyDeviceToDevice, ctx->stream));
+        SVO_HIP(hipMemcpyAsync(distance, ctx->orb_mdist[0], sizeof(float) * (size_t)nq, hipMemcpyDeviceToDevice, ctx->stream));
     }
     return SVO_OK;
 }

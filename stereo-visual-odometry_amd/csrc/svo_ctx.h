@@ -40,6 +40,17 @@ struct svo_ctx {
     int online_frames = 0;            // frames fed since reset
     int online_cur = 0;               // which half of the 2-frame ring holds the latest frame
     double pose[16];
+    // ---- ORB path (allocated on first use: orb_alloc)
+    bool orb_ready = false;
+    svo::OrbGeom orb_geom;
+    uint8_t *orb_slots = nullptr, *orb_blur = nullptr; int *orb_tmp = nullptr;
+    float4 *orb_cell_cand = nullptr; int *orb_cell_cnt = nullptr;
+    float4 *orb_lvl_cand = nullptr; int *orb_lvl_cnt = nullptr;
+    void *orb_nodes = nullptr; int *orb_idx = nullptr, *orb_qtmp = nullptr, *orb_free = nullptr;
+    void *orb_exp_a = nullptr, *orb_exp_b = nullptr;
+    int *orb_sel = nullptr, *orb_sel_cnt = nullptr, *orb_overflow = nullptr;
+    void *orb_kps = nullptr; uint8_t *orb_desc = nullptr; int *orb_n = nullptr; int orb_kp_cap = 0, orb_cand_cap = 0;
+    int *orb_midx[2] = {nullptr, nullptr}; float *orb_mdist[2] = {nullptr, nullptr};
     // ---- pinned host scratch
     void *h_pinned = nullptr; size_t h_pinned_bytes = 0;
     // ---- overlap mode (svo_set_overlap): the pose stage of batch k runs on side_stream while
@@ -80,6 +91,13 @@ int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes);
 void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const float2 *x1, const float2 *x2,
                               const int *n_pts, int n_fixed);
 void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n_pts, int n_fixed, hipStream_t st);
+// orb.hip
+int orb_alloc(svo_ctx *ctx);
+void orb_free(svo_ctx *ctx);
+int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int pitch, int64_t img_stride, int slot0,
+                      int n_img, hipStream_t st);
+int orb_match_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipStream_t st);
+void orb_launch_match_fixed(svo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, hipStream_t st);
 void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur,
                            const double *pose0_host, hipStream_t st);
 }  // namespace svo

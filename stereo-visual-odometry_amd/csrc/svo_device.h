@@ -20,6 +20,22 @@ struct PyrGeom {
     int64_t slot_bytes;             // slot size (multiple of 256)
 };
 
+// Geometry of one ORB pyramid slot (8 levels, scale 1.2) + the per-level tables of ORBextractor.
+constexpr int kOrbMaxLevels = 8;
+struct OrbGeom {
+    int nlevels;
+    int w[kOrbMaxLevels], h[kOrbMaxLevels], pitch[kOrbMaxLevels];
+    int64_t origin[kOrbMaxLevels];       // byte offset of pixel (0,0) of level l inside the slot
+    int64_t blur_off[kOrbMaxLevels];     // offset of level l in the tight blurred / row-sum images
+    int64_t slot_bytes, blur_total;
+    float scale[kOrbMaxLevels];          // mvScaleFactor
+    int quota[kOrbMaxLevels];            // mnFeaturesPerLevel
+    int umax[16];
+    int gk[7];                           // integer 7-tap Gaussian, sigma 2, scale 256
+    int nCols[kOrbMaxLevels], nRows[kOrbMaxLevels], wCell[kOrbMaxLevels], hCell[kOrbMaxLevels];
+    int ncell[kOrbMaxLevels], cell_off[kOrbMaxLevels], cells_total;
+};
+
 __host__ __device__ inline int refl101(int i, int n)
 {
     if (n == 1) return 0;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = ctypes.CDLL(pkg.library_path())
     missing = [s for s in _declared_symbols() if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.svo_abi_version() == 1
+    assert lib.svo_abi_version() == 2
 
 
 def test_default_config_matches_reference_yaml(pkg):
@@ -40,6 +40,9 @@ def test_default_config_matches_reference_yaml(pkg):
     assert cfg.P1[0] == 718.856 and cfg.P1[2] == 607.193 and cfg.P1[6] == 185.216
     assert abs(cfg.P2[3] - 718.856 * -0.537) < 1e-12
     assert cfg.min_move2 == 0.0005 * 0.0005 and cfg.max_move2 == 100.0
+    # ORBextractor arguments, config/default.yaml:89-93
+    assert (cfg.orb_nfeatures, cfg.orb_nlevels, cfg.orb_ini_th, cfg.orb_min_th) == (2000, 8, 20, 7)
+    assert abs(cfg.orb_scale_factor - 1.2) < 1e-7 and cfg.track_mode == 0
 
 
 def test_create_fails_loudly_without_gpu(pkg):

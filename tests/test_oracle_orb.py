@@ -1,0 +1,153 @@
+"""Known-answer tests pinning the oracle's ORB restatement (CPU only): ORBextractor tables against
+the numbers derived in SURVEY.md section 8 (a9), fixed-point resize / blur against independent numpy
+formulations, fastAtan2 accuracy, quadtree invariants, rBRIEF rotation behaviour, the Hamming
+matcher and an end-to-end ORB-mode step on rendered stereo with ground truth."""
+import numpy as np
+
+from conftest import rand_image
+
+
+def test_orbextractor_tables(oracle):
+    sc, inv, quota, umax = oracle.orb_setup(2000, 1.2, 8)
+    assert quota.tolist() == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert umax.tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    assert np.allclose(sc, 1.2 ** np.arange(8), rtol=1e-6) and np.allclose(inv * sc, 1, rtol=1e-6)
+    img = np.zeros((376, 1241), np.uint8)
+    sizes = [oracle.orb_pyramid_level(img, l).shape[::-1] for l in range(8)]
+    assert sizes == [(1241, 376), (1034, 313), (862, 261), (718, 218), (598, 181), (499, 151), (416, 126), (346, 105)]
+    assert oracle.gauss7_kernel() == [18, 34, 49, 55, 49, 34, 18]
+
+
+def _resize_numpy(src, dw, dh):
+    """Independent vectorised restatement of cv::resize INTER_LINEAR 8-bit (11-bit coefficients)."""
+    sh, sw = src.shape
+    def taps(d, s):
+        scale = 1.0 / (float(d) / s)
+        f = ((np.arange(d) + 0.5) * scale - 0.5).astype(np.float32)
+        i = np.floor(f).astype(np.int64)
+        fr = (f - i.astype(np.float32)).astype(np.float32)
+        return i, fr
+    sx, fx = taps(dw, sw)
+    fx = np.where((sx < 0) | (sx >= sw - 1), np.float32(0), fx)
+    sx = np.clip(sx, 0, sw - 1)
+    a0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(np.int64)
+    a1 = np.rint(fx * np.float32(2048)).astype(np.int64)
+    sy, fy = taps(dh, sh)
+    b0 = np.rint((np.float32(1) - fy) * np.float32(2048)).astype(np.int64)
+    b1 = np.rint(fy * np.float32(2048)).astype(np.int64)
+    y0, y1 = np.clip(sy, 0, sh - 1), np.clip(sy + 1, 0, sh - 1)
+    s = src.astype(np.int64)
+    sx1 = np.minimum(sx + 1, sw - 1)
+    rows = s[:, sx] * a0 + s[:, sx1] * a1
+    r0, r1 = rows[y0], rows[y1]
+    out = (((b0[:, None] * (r0 >> 4)) >> 16) + ((b1[:, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+def test_resize_matches_numpy_restatement(oracle):
+    for (h, w, dh, dw, seed) in [(376, 1241, 313, 1034, 1), (105, 416, 88, 347, 2), (50, 64, 50, 64, 3), (64, 80, 17, 31, 4)]:
+        img = rand_image(h, w, seed, blocks=False)
+        got = oracle.resize_linear(img, dw, dh)
+        assert np.array_equal(got, _resize_numpy(img, dw, dh))
+    img = rand_image(40, 50, 9, blocks=False)
+    assert np.array_equal(oracle.resize_linear(img, 50, 40), img)            # identity scale is exact
+    # a level is resized from the PREVIOUS level
+    l1 = oracle.orb_pyramid_level(rand_image(100, 160, 5), 1)
+    l2 = oracle.orb_pyramid_level(rand_image(100, 160, 5), 2)
+    assert np.array_equal(l2, _resize_numpy(l1, l2.shape[1], l2.shape[0]))
+
+
+def test_fast_atan2_accuracy(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(400):
+        y, x = rng.normal(size=2) * rng.uniform(0.1, 1e4)
+        ref = np.degrees(np.arctan2(y, x)) % 360.0
+        got = oracle.fast_atan2(y, x)
+        assert min(abs(got - ref), 360 - abs(got - ref)) < 0.02          # OpenCV documents ~0.3 deg; this fit is tighter
+    assert oracle.fast_atan2(0.0, 1.0) == 0.0 and abs(oracle.fast_atan2(1.0, 0.0) - 90) < 1e-3
+    assert abs(oracle.fast_atan2(0.0, -1.0) - 180) < 1e-3 and abs(oracle.fast_atan2(-1.0, 0.0) - 270) < 1e-3
+
+
+def test_gauss_blur_matches_numpy(oracle):
+    k = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+    for (h, w, seed) in [(40, 56, 1), (105, 346, 2)]:
+        img = rand_image(h, w, seed, blocks=False)
+        p = np.pad(img.astype(np.int64), 3, mode="reflect")
+        rows = sum(k[i] * p[:, i:i + w] for i in range(7))
+        out = sum(k[i] * rows[i:i + h] for i in range(7))
+        ref = np.minimum((out + (1 << 15)) >> 16, 255).astype(np.uint8)
+        assert np.array_equal(oracle.gauss_blur7(img), ref)
+    assert (oracle.gauss_blur7(np.full((20, 20), 255, np.uint8)) == 255).all()          # 257^2/65536 saturates
+
+
+def test_orb_extract_invariants(oracle):
+    img = rand_image(376, 1241, 3)
+    kps, desc, per = oracle.orb_extract(img)
+    sc, inv, quota, umax = oracle.orb_setup()
+    assert per.sum() == len(kps) and 1500 < len(kps) <= 2100
+    assert (per >= np.minimum(quota, per)).all() and (per <= quota + 3).all()      # stops once size >= N
+    # level blocks in order, per-level attributes
+    assert (np.diff(kps["octave"]) >= 0).all()
+    for l in range(8):
+        m = kps["octave"] == l
+        assert m.sum() == per[l]
+        assert (kps["size"][m] == float(int(31 * sc[l]))).all()
+        # level coordinates are integers >= 19 from the border before scaling
+        xl, yl = kps["x"][m] / sc[l], kps["y"][m] / sc[l]
+        assert np.abs(xl - np.rint(xl)).max() < 1e-3 and xl.min() >= 19 - 1e-3 and yl.min() >= 19 - 1e-3
+    assert ((kps["angle"] >= 0) & (kps["angle"] < 360)).all() and (kps["response"] >= 7).all()
+    assert desc.shape == (len(kps), 32) and 40 < np.unpackbits(desc, axis=1).mean() * 100 < 60
+    # deterministic
+    k2, d2, _ = oracle.orb_extract(img)
+    assert k2.tobytes() == kps.tobytes() and d2.tobytes() == desc.tobytes()
+    # no texture -> no keypoints; tiny images are handled
+    assert len(oracle.orb_extract(np.full((120, 160), 80, np.uint8))[0]) == 0
+    assert len(oracle.orb_extract(rand_image(60, 70, 1))[0]) >= 0
+
+
+def test_orb_descriptor_follows_rotation(oracle):
+    """Rotating the image by 180 degrees rotates the keypoint angle by 180 and keeps the descriptor
+    (intensity centroid + steered BRIEF), up to resampling-free exactness for this rotation."""
+    img = rand_image(200, 260, 7)
+    rot = np.ascontiguousarray(img[::-1, ::-1])
+    k1, d1, _ = oracle.orb_extract(img, nlevels=1, nfeatures=300)
+    k2, d2, _ = oracle.orb_extract(rot, nlevels=1, nfeatures=300)
+    pos2 = {(int(k["x"]), int(k["y"])): i for i, k in enumerate(k2)}
+    hits = 0
+    for i, k in enumerate(k1):
+        j = pos2.get((259 - int(k["x"]), 199 - int(k["y"])))
+        if j is None:
+            continue
+        hits += 1
+        da = (k2[j]["angle"] - k["angle"]) % 360
+        assert abs(da - 180) < 0.05
+        assert np.unpackbits(d1[i] ^ d2[j]).sum() <= 16       # cvRound of rotated offsets may flip a few tests
+    assert hits > 50
+
+
+def test_hamming_matcher(oracle):
+    rng = np.random.default_rng(1)
+    t = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    q = t[rng.permutation(300)[:120]].copy()
+    q[5, 0] ^= 1                                                # one bit off
+    t[200] = t[7]                                               # duplicate: first minimum wins
+    idx, dist = oracle.match_hamming(q, t)
+    x = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+    assert np.array_equal(idx, x.argmin(1)) and np.array_equal(dist, x.min(1).astype(np.float32))
+    assert dist[5] in (0.0, 1.0)
+
+
+def test_orb_step_recovers_synthetic_motion(oracle, synth):
+    seq = synth.StereoSequence(width=1241, height=376, n_frames=2, seed=20200710)
+    fr = [tuple(x.numpy() for x in seq.render(t)) for t in range(2)]
+    kL, dL, _ = oracle.orb_extract(fr[0][0])
+    kR, dR, _ = oracle.orb_extract(fr[0][1])
+    k2, d2, _ = oracle.orb_extract(fr[1][0])
+    prm = oracle.make_params(*seq.proj(), min_t2=0.05 ** 2, max_t2=10.0 ** 2)       # minmove / maxmove
+    res, pose = oracle.orb_track_step(prm, kL, dL, kR, dR, k2, d2, np.eye(4))
+    assert res["ok"] == 1 and res["n_tracked"] >= 50
+    gt = seq.relative_gt(1).numpy()
+    assert np.abs(res["tvec"] - gt[:3, 3]).max() < 0.08
+    t2l, t1l, t1r = oracle.orb_robust_match(kL, dL, kR, dR, k2, d2)
+    assert len(t2l) == res["n_tracked"] and (np.abs(t1l[:, 1] - t1r[:, 1]) < 3).all()
+    assert np.median(t1l[:, 0] - t1r[:, 0]) > 5                 # brute-force matches: mostly true stereo pairs
