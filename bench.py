@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-timing-marks", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the pose stage in stream order")
+    ap.add_argument("--mode", choices=["lk", "orb"], default="lk",
+                    help="lk = BASELINE config #2 (FAST+LK, the quoted metric); orb = config #3 (ORB extractor + "
+                         "descriptor match path, the reference's shipped default track_mode)")
     ap.add_argument("--frames-cache", default="", help="torch file to load/save the rendered S0 frames "
                     "(keeps profiler traces free of the renderer's torch kernels)")
     return ap.parse_args()
@@ -90,7 +93,10 @@ def main():
             torch.save({"L": L.cpu(), "R": R.cpu(), "seed": seed}, cache)
     Lv, Rv = L[:, :, :W], R[:, :, :W]
     P1, P2 = seq.proj()
-    ctx = pkg.Context(W, H, device=local_rank, max_batch=B, P1=P1, P2=P2)
+    mode_kw = {}
+    if args.mode == "orb":       # config/default.yaml:75,87-93: ORB_stereof2f_pnp, minmove 0.05, maxmove 10
+        mode_kw = dict(track_mode=pkg.MODE_ORB, min_move2=0.05 ** 2, max_move2=10.0 ** 2)
+    ctx = pkg.Context(W, H, device=local_rank, max_batch=B, P1=P1, P2=P2, **mode_kw)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)            # launches, events and the RCCL gather share one stream
     ctx.set_overlap(not args.no_overlap)          # pose stage of step k runs beside the front end of step k+1
@@ -138,8 +144,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "S0 synthetic KITTI-like stereo sequence 1241x376 (config #2 stand-in), "
-                                   "FAST+LK track_mode LK_stereof2f_pnp, batched frame pairs, frames resident in HBM",
+            "config": {"workload": ("S0 synthetic KITTI-like stereo sequence 1241x376 (config #2 stand-in), "
+                                    "FAST+LK track_mode LK_stereof2f_pnp, batched frame pairs, frames resident in HBM")
+                       if args.mode == "lk" else
+                       ("S0 synthetic KITTI-like stereo sequence 1241x376 (config #3 stand-in), ORB extractor + "
+                        "descriptor match path track_mode ORB_stereof2f_pnp, batched frame pairs, frames resident in HBM"),
                        "pairs_per_step_per_gpu": B, "mean_keypoints_per_pair": round(pts_total / B, 1),
                        "pairs_ok_last_step": n_ok, "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
                        "parallelism": f"sequence-per-GPU x{world}, RCCL gather of poses only" if world > 1 else "1 GPU"},
@@ -155,7 +164,7 @@ def main():
         else:
             out["roofline"] = None
         # ---- cpu_baseline: the oracle (CPU restatement of the reference path) on a bounded sample
-        if args.cpu_pairs > 0 and world == 1:
+        if args.cpu_pairs > 0 and world == 1 and args.mode == "lk":
             O = entry.load_oracle()
             O.build()
             n = min(args.cpu_pairs, B)

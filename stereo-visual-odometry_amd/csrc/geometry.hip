@@ -297,6 +297,7 @@ __global__ __launch_bounds__(64) void pnp_ransac_kernel(PnpArgs a)
 struct FinalizeArgs {
     const PnpRecord *pnp; const int *n_prev, *n_cur, *n_tracked;   // per pair
     int n_pairs;
+    int mode;                      // SVO_MODE_LK checks "< 30 FAST corners" first (src/tracking.cpp:261)
     int num_features_tracking; double inlier_rate, min_move2, max_move2;
     svo_step_result *res;
 };
@@ -313,7 +314,7 @@ __global__ void finalize_kernel(FinalizeArgs a)
     for (int i = 0; i < 9; i++) r.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
     for (int i = 0; i < 16; i++) { r.T_rel_inv[i] = (i % 5 == 0) ? 1.0 : 0.0; r.pose[i] = 0; }
     int fail = 0;
-    if (r.n_cur_kps < 30) fail = SVO_FAIL_FEW_KEYPOINTS;                     // src/tracking.cpp:261
+    if (a.mode == SVO_MODE_LK && r.n_cur_kps < 30) fail = SVO_FAIL_FEW_KEYPOINTS;     // src/tracking.cpp:261
     else {
         const int m = a.n_tracked[p];
         r.n_tracked = m;
@@ -426,7 +427,7 @@ void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const i
 {
     FinalizeArgs f{};
     f.pnp = (const PnpRecord *)ctx->pnp_ws; f.n_prev = n_prev; f.n_cur = n_cur; f.n_tracked = ctx->m_out;
-    f.n_pairs = n_pairs; f.num_features_tracking = ctx->cfg.num_features_tracking;
+    f.n_pairs = n_pairs; f.mode = ctx->cfg.track_mode; f.num_features_tracking = ctx->cfg.num_features_tracking;
     f.inlier_rate = ctx->cfg.inlier_rate; f.min_move2 = ctx->cfg.min_move2; f.max_move2 = ctx->cfg.max_move2;
     f.res = ctx->d_results;
     hipLaunchKernelGGL(finalize_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, f);

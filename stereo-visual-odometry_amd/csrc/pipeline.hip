@@ -28,6 +28,7 @@ static void mark(svo_ctx *ctx, const char *name)
     ctx->marks.emplace_back(name, ev);
 }
 
+static const char *kTOrb = "orb_extract", *kTMatch = "orb_match";
 static const char *kT0 = "start", *kTPyr = "pyramid", *kTFast = "fast", *kTLk = "lk", *kTCompact = "compact",
                   *kTTri = "triangulate", *kTPnp = "pnp", *kTFin = "finalize";
 
@@ -36,6 +37,13 @@ static const char *kT0 = "start", *kTPyr = "pyramid", *kTFast = "fast", *kTLk = 
 static int ingest_frames(svo_ctx *ctx, const uint8_t *L, const uint8_t *R, int pitch, int64_t frame_stride,
                          int f0, int n_new)
 {
+    if (ctx->cfg.track_mode == SVO_MODE_ORB) {
+        // Detect_MyORBFeatures (src/tracking.cpp:502-532): ORBextractor on the left AND right image;
+        // frame f -> feature slots 2f (left), 2f+1 (right)
+        int rc = orb_extract_batch(ctx, L, R, pitch, frame_stride, 2 * f0, 2 * n_new, ctx->stream);
+        mark(ctx, kTOrb);
+        return rc;
+    }
     const PyrGeom &g = ctx->geom;
     PyrArgs p{};
     // left and right images interleave into consecutive slots 2f, 2f+1: one launch set for both
@@ -57,6 +65,8 @@ static int ingest_frames(svo_ctx *ctx, const uint8_t *L, const uint8_t *R, int p
     return SVO_OK;
 }
 
+static int run_back(svo_ctx *ctx, int n_pairs, const double *pose0_host, svo_step_result *results_dev);
+
 // Tracks `n_pairs` pairs; pair p = (frame slot fp0 + p*fstep, frame slot fc0 + p*fstep).
 // Front half on the context's stream: circular LK, compaction, triangulation.  Back half (pose
 // solver, gates, chain, optional copy of the records to `results_dev`) on `back_stream`, which is
@@ -66,6 +76,24 @@ static int run_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, con
 {
     const PyrGeom &g = ctx->geom;
     const int cap = ctx->cfg.max_keypoints;
+    if (ctx->cfg.track_mode == SVO_MODE_ORB) {
+        // ORB_StereoF2F_PnP_Track (src/tracking.cpp:168-249): Hamming matches + filter instead of LK
+        if (ctx->back_pending) {
+            SVO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_back, 0));
+            ctx->back_pending = false;
+        }
+        orb_match_pairs(ctx, n_pairs, fp0, fc0, fstep, ctx->stream);
+        mark(ctx, kTMatch);
+        launch_triangulate_batch(ctx, n_pairs, cap, ctx->cmp[0], ctx->cmp[1], ctx->m_out, 0);
+        // n_prev / n_cur = left keypoint counts of the two frames (feature slots 2f)
+        const int np = fstep == 1 ? n_pairs : 1;
+        SVO_HIP(hipMemcpy2DAsync(ctx->kp_n_snap, sizeof(int), ctx->orb_n + 2 * fp0, 2 * sizeof(int), sizeof(int), np,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+        SVO_HIP(hipMemcpy2DAsync(ctx->kp_n_snap + n_pairs, sizeof(int), ctx->orb_n + 2 * fc0, 2 * sizeof(int), sizeof(int), np,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+        mark(ctx, kTTri);
+        return run_back(ctx, n_pairs, pose0_host, results_dev);
+    }
     auto S = [&](int slot) { return ctx->bslots + (size_t)slot * g.slot_bytes; };
     LkArgs a{};
     a.g = g; a.ncalls = 4;
@@ -110,7 +138,13 @@ static int run_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, con
         SVO_HIP(hipMemcpyAsync(ctx->kp_n_snap + 1, ctx->kp_n + fc0, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
     }
     mark(ctx, kTTri);
+    return run_back(ctx, n_pairs, pose0_host, results_dev);
+}
 
+// Pose stage: solvePnPRansac(X, t2_left) (:299 / :200), gates, frame_pose_ chain, optional copy of the
+// records; on the side stream in overlap mode.
+static int run_back(svo_ctx *ctx, int n_pairs, const double *pose0_host, svo_step_result *results_dev)
+{
     hipStream_t bs = ctx->stream;
     const bool side = ctx->overlap && results_dev != nullptr;
     if (side) {
@@ -118,7 +152,6 @@ static int run_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, con
         SVO_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_front, 0));
         bs = ctx->side_stream;
     }
-    // solvePnPRansac(X, t2_left) (:299), gates, frame_pose_ chain
     launch_pnp_batch(ctx, n_pairs, ctx->cmp[3], ctx->m_out, 0, bs);
     if (!side) mark(ctx, kTPnp);
     launch_finalize_chain(ctx, n_pairs, ctx->kp_n_snap, ctx->kp_n_snap + n_pairs, pose0_host, bs);
@@ -184,7 +217,8 @@ int pipeline_add_frame(svo_ctx *ctx, const uint8_t *left, const uint8_t *right, 
     if (ctx->online_frames == 0) {
         // StereoInit_f2f (:78-92): detect only
         int *h_n = (int *)ctx->h_pinned;
-        SVO_HIP(hipMemcpyAsync(h_n, ctx->kp_n + cur, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        const int *src_n = ctx->cfg.track_mode == SVO_MODE_ORB ? ctx->orb_n + 2 * cur : ctx->kp_n + cur;
+        SVO_HIP(hipMemcpyAsync(h_n, src_n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         SVO_HIP(hipStreamSynchronize(ctx->stream));
         res->ok = 1; res->n_cur_kps = *h_n;
         for (int i = 0; i < 9; i++) res->R[i] = (i % 4 == 0) ? 1.0 : 0.0;

@@ -37,6 +37,7 @@ private:
     bool Track();
     bool LK_StereoF2F_PnP_Track();
     bool ORB_StereoF2F_PnP_Track();
+    bool TrackOnGpu();
     void Readparameter();
     bool EnsureContext(int width, int height);
 

@@ -59,8 +59,19 @@ bool Tracking::EnsureContext(int width, int height)
     cfg.confidence = confidence_;
     cfg.feature_match_error = feature_match_error_;
     cfg.inlier_rate = inlier_rate_;
-    cfg.min_move2 = 0.0005 * 0.0005;                             // LK mode, src/tracking.cpp:311
-    cfg.max_move2 = 100.0;
+    if (track_mode_ == "ORB_stereof2f_pnp") {
+        // the shipped default (config/default.yaml:75): ORBextractor(nFeatures, fScaleFactor, nLevels,
+        // fIniThFAST, fMinThFAST) (src/tracking.cpp:20) and the configured minmove / maxmove gate (:215)
+        cfg.track_mode = SVO_MODE_ORB;
+        cfg.orb_nfeatures = nFeatures_; cfg.orb_scale_factor = fScaleFactor_; cfg.orb_nlevels = nLevels_;
+        cfg.orb_ini_th = fIniThFAST_; cfg.orb_min_th = fMinThFAST_;
+        cfg.min_move2 = minmove_ * minmove_;
+        cfg.max_move2 = maxmove_ * maxmove_;
+    } else {
+        cfg.track_mode = SVO_MODE_LK;
+        cfg.min_move2 = 0.0005 * 0.0005;                         // LK mode, src/tracking.cpp:311
+        cfg.max_move2 = 100.0;
+    }
     memcpy(cfg.P1, sensors_->projMatr1_, sizeof(cfg.P1));
     memcpy(cfg.P2, sensors_->projMatr2_, sizeof(cfg.P2));
     int rc = svo_create(&cfg, 0, &ctx_);
@@ -106,8 +117,6 @@ static bool feed(svo_ctx *ctx, Frame::Ptr f, svo_step_result *res, int *rc_out)
 
 bool Tracking::StereoInit_f2f()
 {
-    if (track_mode_ == "ORB_stereof2f_pnp")
-        LZB_LOG("WARNING", "track_mode ORB_stereof2f_pnp is not built yet; initialising the FAST+LK path");
     if (!EnsureContext(current_frame_->left_img_.cols, current_frame_->left_img_.rows)) return false;
     svo_reset(ctx_);
     int rc;
@@ -124,7 +133,11 @@ bool Tracking::Track()
     return false;                               // any other string: Track() is always false (:127)
 }
 
-bool Tracking::LK_StereoF2F_PnP_Track()
+// Both modes are one svo_add_frame call; the context was created for the configured track_mode.
+bool Tracking::LK_StereoF2F_PnP_Track() { return TrackOnGpu(); }
+bool Tracking::ORB_StereoF2F_PnP_Track() { return TrackOnGpu(); }
+
+bool Tracking::TrackOnGpu()
 {
     if (!EnsureContext(current_frame_->left_img_.cols, current_frame_->left_img_.rows)) return false;
     int rc;
@@ -135,14 +148,6 @@ bool Tracking::LK_StereoF2F_PnP_Track()
         Px_ = frame_pose_.m[3]; Py_ = frame_pose_.m[7]; Pz_ = frame_pose_.m[11];
     }
     return ok;
-}
-
-bool Tracking::ORB_StereoF2F_PnP_Track()
-{
-    // SURVEY.md section 8 rows a8-a14 (BASELINE config #3): next to be built; fail loudly rather than
-    // silently running something else
-    LZB_LOG("ERROR", "track_mode ORB_stereof2f_pnp: the ORB path is not built yet (use LK_stereof2f_pnp)");
-    return false;
 }
 
 }  // namespace lzb_vio

@@ -74,3 +74,97 @@ def test_match_hamming_parity(pkg, oracle, tc):
     i0, d0 = ctx.match_hamming(q[:0], t)
     assert len(i0) == 0
     ctx.close()
+
+
+POSE_TOL, TIGHT = 1e-4, 1e-9
+
+
+def relfro(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+def _oracle_orb_sequence(oracle, seq, frames, minmove=0.05, maxmove=10.0):
+    prm = oracle.make_params(*seq.proj(), min_t2=minmove ** 2, max_t2=maxmove ** 2)
+    feats = [(oracle.orb_extract(L)[:2], oracle.orb_extract(R)[:2]) for L, R in frames]
+    pose = np.eye(4)
+    out = []
+    for t in range(1, len(frames)):
+        (kL, dL), (kR, dR) = feats[t - 1]
+        (k2, d2), _ = feats[t]
+        res, pose = oracle.orb_track_step(prm, kL, dL, kR, dR, k2, d2, pose)
+        out.append((res, pose.copy()))
+    return out, feats
+
+
+def _check_orb_step(g, r):
+    assert int(g["ok"]) == r["ok"] and int(g["fail_stage"]) == r["fail_stage"]
+    assert int(g["n_prev_kps"]) == r["n_prev_kps"] and int(g["n_cur_kps"]) == r["n_cur_kps"]
+    assert int(g["n_tracked"]) == r["n_tracked"]
+    if r["fail_stage"] != 2:
+        assert int(g["n_inliers"]) == r["n_inliers"]
+        Tg = np.hstack([g["R"].reshape(3, 3), g["tvec"][:, None]])
+        Tr = np.hstack([r["R"], r["tvec"][:, None]])
+        assert relfro(Tg, Tr) <= POSE_TOL and relfro(Tg, Tr) <= TIGHT
+
+
+def test_orb_mode_online_and_batch_parity(pkg, oracle, tc, synth):
+    """Tracking::ORB_StereoF2F_PnP_Track end to end (shipped default track_mode of config/default.yaml)."""
+    seq = synth.StereoSequence(width=832, height=256, n_frames=4, seed=5)
+    frames = [tuple(x.numpy() for x in seq.render(t)) for t in range(4)]
+    h, w = frames[0][0].shape
+    P1s, P2s = seq.proj()
+    ref, feats = _oracle_orb_sequence(oracle, seq, frames)
+    assert all(r["ok"] for r, _ in ref) and ref[0][0]["n_tracked"] > 20
+    kw = dict(P1=P1s, P2=P2s, track_mode=pkg.MODE_ORB, min_move2=0.05 ** 2, max_move2=10.0 ** 2)
+    c = pkg.Context(w, h, device=0, **kw)
+    rc, g0 = c.add_frame(*frames[0])
+    assert rc == 0 and g0["n_cur_kps"] == len(feats[0][0][0])
+    for t in range(1, 4):
+        fr = frames[t] if t % 2 else tuple(tc.from_numpy(x).cuda() for x in frames[t])
+        rc, g = c.add_frame(*fr)
+        r, pose = ref[t - 1]
+        assert rc == (0 if r["ok"] else r["fail_stage"])
+        _check_orb_step(g, r)
+        assert relfro(c.get_pose(), pose) <= TIGHT
+    c.close()
+    # batched
+    c = pkg.Context(w, h, device=0, max_batch=3, **kw)
+    L = tc.stack([tc.from_numpy(f[0]) for f in frames]).cuda()
+    R = tc.stack([tc.from_numpy(f[1]) for f in frames]).cuda()
+    res = c.track_batch(L, R)
+    for p in range(3):
+        _check_orb_step(res[p], ref[p][0])
+        assert relfro(res[p]["pose"].reshape(4, 4), ref[p][1]) <= TIGHT
+    # overlap mode gives the same records
+    c.set_overlap(True)
+    dres = tc.zeros((3, pkg.STEP_DTYPE.itemsize), dtype=tc.uint8, device="cuda")
+    c.track_batch(L, R, results=dres)
+    c.track_batch(L, R, results=dres)
+    c.sync()
+    assert np.frombuffer(dres.cpu().numpy().tobytes(), dtype=pkg.STEP_DTYPE).tobytes() == res.tobytes()
+    c.close()
+
+
+def test_orb_mode_failure_stages(pkg, oracle, tc, synth):
+    seq = synth.StereoSequence(width=832, height=256, n_frames=2, seed=6)
+    frames = [tuple(x.numpy() for x in seq.render(t)) for t in range(2)]
+    h, w = frames[0][0].shape
+    P1s, P2s = seq.proj()
+    flat = np.full((h, w), 60, np.uint8)
+    # too few matches (stage 2): the current frame has no features at all
+    c = pkg.Context(w, h, device=0, P1=P1s, P2=P2s, track_mode=pkg.MODE_ORB, min_move2=0.05 ** 2, max_move2=100.0)
+    c.add_frame(*frames[0])
+    rc, g = c.add_frame(flat, flat)
+    assert rc == 2 and g["n_tracked"] == 0 and g["n_cur_kps"] == 0
+    rc, g = c.add_frame(*frames[1])                      # last frame has no features either
+    assert rc == 2 and g["n_prev_kps"] == 0
+    c.close()
+    # translation gate with the configured minmove (stage 5): minmove larger than the motion
+    ref, _ = _oracle_orb_sequence(oracle, seq, frames, minmove=3.0, maxmove=10.0)
+    c = pkg.Context(w, h, device=0, P1=P1s, P2=P2s, track_mode=pkg.MODE_ORB, min_move2=9.0, max_move2=100.0)
+    c.add_frame(*frames[0])
+    rc, g = c.add_frame(*frames[1])
+    assert ref[0][0]["fail_stage"] == 5 and rc == 5
+    _check_orb_step(g, ref[0][0])
+    assert np.array_equal(c.get_pose(), np.eye(4))
+    c.close()

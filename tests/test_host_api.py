@@ -155,3 +155,16 @@ def test_run_kitti_stereo_drop_in(host_built, pkg, small_seq, tmp_path):
     assert np.abs(poses - np.array(ref)).max() < 1e-6
     gt = np.linalg.inv(seq.poses_wc()[0].numpy()) @ seq.poses_wc()[len(frames) - 1].numpy()
     assert np.abs(poses[-1][:, 3] - gt[:3, 3]).max() < 0.25
+    # the shipped default track_mode (ORB_stereof2f_pnp) through the same binary
+    _write_yaml(tmp_path / "orb.yaml", str(tmp_path), fx=seq.fx, fy=seq.fy, cx=seq.cx, cy=seq.cy, mode="ORB_stereof2f_pnp")
+    r = subprocess.run([os.path.join(host_built, "run_kitti_stereo"), str(tmp_path / "orb.yaml"),
+                        str(tmp_path / "poses_orb.txt")], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    poses_orb = np.loadtxt(tmp_path / "poses_orb.txt").reshape(-1, 3, 4)
+    c = pkg.Context(w, h, device=0, P1=P1, P2=P2, track_mode=pkg.MODE_ORB, min_move2=0.05 ** 2, max_move2=10.0 ** 2)
+    ref = []
+    for L, R in frames:
+        c.add_frame(L, R)
+        ref.append(c.get_pose()[:3])
+    c.close()
+    assert np.abs(poses_orb - np.array(ref)).max() < 1e-6
