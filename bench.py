@@ -157,9 +157,14 @@ def main():
         if lk_ms:
             alg_bytes = pts_total * 4 * LK_BYTES_PER_POINT_CALL       # 4 fused calls per launch
             achieved = alg_bytes / (lk_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the rocprofv3 PMC passes of this command (profiles/), if present
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_lk_traffic.json")
+            if os.path.exists(tpath) and B == 256:
+                traffic = json.load(open(tpath)).get("traffic_bytes")
             out["roofline"] = {"bound": "hbm", "kernel": "lk_kernel (4-call circular chain, one launch per step)",
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "launch_ms": round(lk_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
         else:
             out["roofline"] = None

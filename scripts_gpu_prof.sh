@@ -1,19 +1,21 @@
 #!/bin/bash
-# rocprofv3 round: kernel stats + PMC passes for the svo kernels only.  Summaries -> gpurun_out/prof_*
+# rocprofv3 round for the default bench command (LK mode, 256 pairs/step): kernel stats + PMC passes.
+# Summaries -> gpurun_out/prof_*; copy the ones to be judged into profiles/.
 mkdir -p gpurun_out
 CACHE=/tmp/s0_frames.pt
 python bench.py --steps 2 --warmup 1 --cpu-pairs 0 --frames-cache $CACHE > gpurun_out/bench_cache.log 2>&1; echo "cache exit=$?"
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 -L > $R/gpurun_out/counters_list.txt 2>&1
-rocprofv3 --kernel-trace --stats --kernel-include-regex "svo::" --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-pairs 0 --no-timing-marks --frames-cache $CACHE > $R/gpurun_out/prof_stats.log 2>&1; echo "stats exit=$?"
-f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/prof_kernel_stats.csv && cat "$f"
+rocprofv3 --kernel-trace --stats --kernel-include-regex "svo::" --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 10 --warmup 2 --cpu-pairs 0 --frames-cache $CACHE > $R/gpurun_out/prof_stats.log 2>&1; echo "stats exit=$?"
+tail -1 $R/gpurun_out/prof_stats.log > $R/gpurun_out/prof_bench_line.json
+f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/prof_kernel_stats.csv && cat "$f" | cut -c1-160
 i=0
 for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $PMC --kernel-include-regex "svo::" --output-format csv -d /tmp/prof_pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --no-timing-marks --frames-cache $CACHE > $R/gpurun_out/prof_pmc$i.log 2>&1; echo "pmc$i exit=$?"
+  rocprofv3 --pmc $PMC --kernel-include-regex "svo::" --output-format csv -d /tmp/prof_pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --no-timing-marks --no-overlap --frames-cache $CACHE > $R/gpurun_out/prof_pmc$i.log 2>&1; echo "pmc$i exit=$?"
   f=$(find /tmp/prof_pmc$i -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python3 $R/scripts_pmc_summary.py "$f" > $R/gpurun_out/prof_pmc$i.txt && cat $R/gpurun_out/prof_pmc$i.txt
+  [ -n "$f" ] && python3 $R/scripts_pmc_summary.py "$f" > $R/gpurun_out/prof_pmc$i.txt
 done
+cat $R/gpurun_out/prof_pmc*.txt | grep lk_kernel

@@ -31,22 +31,27 @@ __global__ __launch_bounds__(256) void orb_copy0_kernel(OrbGeom g, const uint8_t
     slots[(int64_t)b * slot_stride + g.origin[0] + (int64_t)y * g.pitch[0] + x] = img[(int64_t)b * img_stride + (int64_t)y * pitch + x];
 }
 
-// frame (kPad wide, only 19 are ever read) of level l by reflect-101 from the level's interior
+// frame (kPad wide, only 19 are ever read) of level l by reflect-101 from the level's interior:
+// workgroups < 2*kPad take one top/bottom frame row each, the others four interior rows
 __global__ __launch_bounds__(256) void orb_border_kernel(OrbGeom g, uint8_t *slots, int64_t slot_stride, int l)
 {
-    const int b = blockIdx.z;
+    const int b = blockIdx.y;
     const int w = g.w[l], h = g.h[l], pitch = g.pitch[l];
     uint8_t *lvl = slots + (int64_t)b * slot_stride + g.origin[l];
-    const int py = blockIdx.y - kPad;
-    int px = blockIdx.x * 256 + threadIdx.x;
-    if (py >= 0 && py < h) {
-        if (px >= 2 * kPad) return;
-        px = px < kPad ? px - kPad : w + (px - kPad);
+    const int gidx = blockIdx.x;
+    if (gidx < 2 * kPad) {
+        const int py = gidx < kPad ? gidx - kPad : h + (gidx - kPad);
+        const uint8_t *src = lvl + (int64_t)refl101(py, h) * pitch;
+        uint8_t *dst = lvl + (int64_t)py * pitch;
+        for (int px = (int)threadIdx.x - kPad; px < w + kPad; px += 256) dst[px] = src[refl101(px, w)];
     } else {
-        if (px >= w + 2 * kPad) return;
-        px -= kPad;
+        const int py = (gidx - 2 * kPad) * 4 + (threadIdx.x >> 6);
+        if (py >= h) return;
+        const int t = threadIdx.x & 63;
+        const int px = t < kPad ? t - kPad : w + (t - kPad);
+        uint8_t *row = lvl + (int64_t)py * pitch;
+        row[px] = row[refl101(px, w)];
     }
-    lvl[(int64_t)py * pitch + px] = lvl[(int64_t)refl101(py, h) * pitch + refl101(px, w)];
 }
 
 // cv::resize(level l-1 -> level l, INTER_LINEAR), 8-bit fixed point (11-bit coefficients)
@@ -770,8 +775,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     for (int l = 0; l < L; l++) {
         if (l > 0)
             hipLaunchKernelGGL(orb_resize_kernel, dim3((g.w[l] + 255) / 256, g.h[l], n_img), blk, 0, st, g, slots, g.slot_bytes, l);
-        hipLaunchKernelGGL(orb_border_kernel, dim3((g.w[l] + 2 * kPad + 255) / 256, g.h[l] + 2 * kPad, n_img), blk, 0, st, g,
-                           slots, g.slot_bytes, l);
+        hipLaunchKernelGGL(orb_border_kernel, dim3(2 * kPad + (g.h[l] + 3) / 4, n_img), blk, 0, st, g, slots, g.slot_bytes, l);
     }
     float4 *cell_cand = ctx->orb_cell_cand + (size_t)slot0 * g.cells_total * kCellCap;
     int *cell_cnt = ctx->orb_cell_cnt + (size_t)slot0 * g.cells_total;

@@ -41,23 +41,28 @@ __global__ __launch_bounds__(256) void pyr_copy0_kernel(PyrArgs a)
     }
 }
 
-// frame of level l: every padded position outside the interior copies its reflect-101 source
+// frame of level l: every padded position outside the interior copies its reflect-101 source.
+// Workgroup g < 2*kPad handles one full top/bottom frame row; the others handle four interior
+// rows each (64 lanes = the 2 x 32 side bytes of a row), so no workgroup is launched for nothing.
 __global__ __launch_bounds__(256) void pyr_border_kernel(PyrArgs a, int l)
 {
-    const int b = blockIdx.z;
+    const int b = blockIdx.y;
     const int w = a.g.w[l], h = a.g.h[l], pitch = a.g.pitch[l];
     uint8_t *lvl = a.slots + (int64_t)b * a.slot_stride + a.g.origin[l];
-    const int py = blockIdx.y - kPad;                      // padded row
-    int px = blockIdx.x * 256 + threadIdx.x;               // index into the row's frame bytes
-    if (py >= 0 && py < h) {
-        // interior row: only the 2 * kPad side bytes
-        if (px >= 2 * kPad) return;
-        px = px < kPad ? px - kPad : w + (px - kPad);
+    const int gidx = blockIdx.x;
+    if (gidx < 2 * kPad) {
+        const int py = gidx < kPad ? gidx - kPad : h + (gidx - kPad);
+        const uint8_t *src = lvl + (int64_t)refl101(py, h) * pitch;
+        uint8_t *dst = lvl + (int64_t)py * pitch;
+        for (int px = (int)threadIdx.x - kPad; px < w + kPad; px += 256) dst[px] = src[refl101(px, w)];
     } else {
-        if (px >= w + 2 * kPad) return;
-        px -= kPad;
+        const int py = (gidx - 2 * kPad) * 4 + (threadIdx.x >> 6);
+        if (py >= h) return;
+        const int t = threadIdx.x & 63;
+        const int px = t < kPad ? t - kPad : w + (t - kPad);
+        uint8_t *row = lvl + (int64_t)py * pitch;
+        row[px] = row[refl101(px, w)];
     }
-    lvl[(int64_t)py * pitch + px] = lvl[(int64_t)refl101(py, h) * pitch + refl101(px, w)];
 }
 
 // level l (>= 1) interior from level l-1: thread -> 4 consecutive output pixels
@@ -121,7 +126,7 @@ void launch_pyramid(const PyrArgs &a, int batch, hipStream_t st)
             dim3 g((a.g.w[l] + 1023) / 1024, a.g.h[l], batch);
             hipLaunchKernelGGL(pyr_down_kernel, g, blk, 0, st, a, l);
         }
-        dim3 gb((a.g.w[l] + 2 * kPad + 255) / 256, a.g.h[l] + 2 * kPad, batch);
+        dim3 gb(2 * kPad + (a.g.h[l] + 3) / 4, batch, 1);
         hipLaunchKernelGGL(pyr_border_kernel, gb, blk, 0, st, a, l);
     }
 }
