@@ -5,7 +5,8 @@
 // Two launches per batch of images:
 //   fast_score_kernel : one 64x16 pixel tile per 256-thread workgroup.  The raw tile (+4 halo)
 //       is staged in LDS once; the segment test + corner score are evaluated for the tile plus
-//       a 1-pixel ring (the NMS neighbours), NMS is done out of LDS, the suppressed score map
+//       a 1-pixel ring (the NMS neighbours) in three passes over compacted LDS position lists
+//       (quick reject -> arc test -> score), NMS is done out of LDS, the suppressed score map
 //       (u8, 0 = no keypoint) goes to HBM with 64-byte coalesced row stores, and per-row
 //       keypoint counts are accumulated with one integer atomic per (row, tile).
 //   fast_emit_kernel  : one wave per image row; its output offset is the sum of the row counts
@@ -44,35 +45,41 @@ __device__ __forceinline__ bool has_arc9(unsigned m16)
     return (e & 0xFFFFu) != 0;
 }
 
-// Returns 0 for a non-corner, else cornerScore<16> (>= thr) -- or 1 when scores are not needed.
-// Any 9-arc of the 16-circle contains at least one pixel of every opposite pair (k, k+8), so a
-// pixel whose pairs (0,8) and (4,12) cannot both be "brighter" or both be "darker" is rejected
-// after 4 loads (the same high-speed test cv::FAST performs); the wave only pays for the full
-// test when one of its lanes survives.
-__device__ __forceinline__ int fast_score_at(const uint8_t *c, int thr, bool want_score, bool valid)
+// The segment test runs as three passes of decreasing population, each over a DENSE list so no
+// wave pays for work only a few of its lanes need (the kernel is VALU bound, not HBM bound):
+//   quick : every position -- any 9-arc of the 16-circle contains at least one pixel of each
+//           opposite pair (k, k+8), so a pixel whose pairs (0,8) and (4,12) cannot both be
+//           "brighter" or both be "darker" is rejected after 4 loads (cv::FAST's high-speed test);
+//   arc   : survivors of quick -- the full 16-pixel contiguous-arc test;
+//   score : corners only -- cornerScore<16>.
+__device__ __forceinline__ bool fast_quick(const uint8_t *c, int thr)
 {
     constexpr int P = kRawW;
     const int v = c[0];
-    bool alive = valid;
-    {
-        const int d0 = v - c[3 * P], d8 = v - c[-3 * P], d4 = v - c[3], d12 = v - c[-3];
-        const bool dk = (d0 > thr || d8 > thr) && (d4 > thr || d12 > thr);
-        const bool br = (d0 < -thr || d8 < -thr) && (d4 < -thr || d12 < -thr);
-        alive = alive && (dk || br);
-    }
-    if (!__any(alive)) return 0;
+    const int d0 = v - c[3 * P], d8 = v - c[-3 * P], d4 = v - c[3], d12 = v - c[-3];
+    const bool dk = (d0 > thr || d8 > thr) && (d4 > thr || d12 > thr);
+    const bool br = (d0 < -thr || d8 < -thr) && (d4 < -thr || d12 < -thr);
+    return dk || br;
+}
+
+__device__ __forceinline__ bool fast_arc(const uint8_t *c, int thr)
+{
     int d[16];
-    load_circle(c, d, v);
+    load_circle(c, d, c[0]);
     unsigned dark = 0, bright = 0;          // d > thr: pixel darker than centre; d < -thr: brighter
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         dark |= (unsigned)(d[k] > thr) << k;
         bright |= (unsigned)(d[k] < -thr) << k;
     }
-    const bool corner = alive && (has_arc9(dark) || has_arc9(bright));
-    if (!want_score) return corner ? 1 : 0;
-    if (!__any(corner)) return 0;
-    // min / max over every 9-arc d[s..s+8] by doubling
+    return has_arc9(dark) || has_arc9(bright);
+}
+
+// cornerScore<16> of a corner (>= thr): min / max over every 9-arc d[s..s+8] by doubling
+__device__ __forceinline__ int fast_corner_score(const uint8_t *c, int thr)
+{
+    int d[16];
+    load_circle(c, d, c[0]);
     int mn[16], mx[16], t1[16], t2[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) { t1[i] = min(d[i], d[(i + 1) & 15]); t2[i] = max(d[i], d[(i + 1) & 15]); }
@@ -86,20 +93,36 @@ __device__ __forceinline__ int fast_score_at(const uint8_t *c, int thr, bool wan
         a0 = max(a0, min(t1[i], d[(i + 8) & 15]));
         bmin = min(bmin, max(t2[i], d[(i + 8) & 15]));
     }
-    int b0 = min(-a0, bmin);
-    return corner ? -b0 - 1 : 0;
+    const int b0 = min(-a0, bmin);
+    return -b0 - 1;
+}
+
+// append the positions of the lanes with `flag` to an LDS list (order inside the list is free:
+// results are scattered back by position)
+__device__ __forceinline__ void list_push(bool flag, int pos, uint16_t *list, int *count)
+{
+    const unsigned long long m = __ballot(flag);
+    if (m == 0) return;
+    const int lane = threadIdx.x;                       // blockDim.x == 64: x is the lane
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (flag) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
 }
 
 __global__ __launch_bounds__(256) void fast_score_kernel(FastArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t raw[kRawH * kRawW];
-    __shared__ uint8_t sc[kScH * kScW];
+    __shared__ __attribute__((aligned(4))) uint8_t sc[(kScH * kScW + 3) & ~3];
+    __shared__ uint16_t cand[kScH * kScW], corners[kScH * kScW];
+    __shared__ int n_cand, n_corner;
     const int b = blockIdx.z;
     const uint8_t *img = a.img + (int64_t)b * a.img_stride;
     uint8_t *score = a.score + (int64_t)b * a.score_stride;
     int *rowcount = a.rowcount + (int64_t)b * a.rowcount_stride;
     const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
     const int tid = threadIdx.y * 64 + threadIdx.x;
+    if (tid == 0) { n_cand = 0; n_corner = 0; }
 
     // stage raw tile + halo (72 x 24 bytes); out-of-image bytes are never used by a valid centre.
     // x0 - 4 is a multiple of 4, so with a 4-byte aligned image the tile is 18 dwords per row.
@@ -125,20 +148,40 @@ __global__ __launch_bounds__(256) void fast_score_kernel(FastArgs a)
             raw[i] = v;
         }
     }
+    for (int i = tid; i < (int)sizeof(sc) / 4; i += 256) ((uint32_t *)sc)[i] = 0;
     __syncthreads();
 
-    // scores for the tile and its 1-pixel ring (every lane takes part: wave votes inside)
+    // quick test over the tile and its 1-pixel ring (the NMS neighbours)
     for (int i0 = 0; i0 < kScH * kScW; i0 += 256) {
         const int i = i0 + tid;
         const bool in = i < kScH * kScW;
         const int ii = in ? i : 0;
-        int sy = ii / kScW, sx = ii - sy * kScW;
-        int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
+        const int sy = ii / kScW, sx = ii - sy * kScW;
+        const int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
         const bool valid = in && gx >= 3 && gx < a.w - 3 && gy >= 3 && gy < a.h - 3;
-        int s = fast_score_at(&raw[(sy + kHalo - 1) * kRawW + sx + kHalo - 1], a.thr, a.nms != 0, valid);
-        if (in) sc[i] = (uint8_t)s;
+        const bool alive = valid && fast_quick(&raw[(sy + kHalo - 1) * kRawW + sx + kHalo - 1], a.thr);
+        list_push(alive, ii, cand, &n_cand);
     }
     __syncthreads();
+    const int nc = n_cand;
+    for (int i0 = 0; i0 < nc; i0 += 256) {
+        const int i = i0 + tid;
+        const int pos = i < nc ? cand[i] : 0;
+        const int sy = pos / kScW, sx = pos - sy * kScW;
+        const bool corner = i < nc && fast_arc(&raw[(sy + kHalo - 1) * kRawW + sx + kHalo - 1], a.thr);
+        if (a.nms) list_push(corner, pos, corners, &n_corner);
+        else if (corner) sc[pos] = 1;
+    }
+    __syncthreads();
+    if (a.nms) {
+        const int nk = n_corner;
+        for (int i = tid; i < nk; i += 256) {
+            const int pos = corners[i];
+            const int sy = pos / kScW, sx = pos - sy * kScW;
+            sc[pos] = (uint8_t)fast_corner_score(&raw[(sy + kHalo - 1) * kRawW + sx + kHalo - 1], a.thr);
+        }
+        __syncthreads();
+    }
 
 #pragma unroll
     for (int j = 0; j < kTileH / 4; j++) {
@@ -195,7 +238,7 @@ __global__ __launch_bounds__(256) void fast_emit_kernel(FastArgs a)
 
 void launch_fast(const FastArgs &a, int batch, hipStream_t st)
 {
-    hipMemsetAsync(a.rowcount, 0, sizeof(int) * (size_t)a.rowcount_stride * batch, st);
+    (void)hipMemsetAsync(a.rowcount, 0, sizeof(int) * (size_t)a.rowcount_stride * batch, st);
     dim3 g1((a.w + kTileW - 1) / kTileW, (a.h + kTileH - 1) / kTileH, batch), b1(64, 4, 1);
     hipLaunchKernelGGL(fast_score_kernel, g1, b1, 0, st, a);
     dim3 g2((a.h + 3) / 4, batch, 1), b2(256, 1, 1);

@@ -41,7 +41,7 @@
 namespace svo {
 
 constexpr int kSlots = 4;                                 // points per wave
-constexpr int kTileIRows = 24, kTileIDw = 8;              // 24 rows x 32 bytes (28 used)
+constexpr int kTileIDw = 8;                               // I tile: 24 rows x 32 bytes (28 used)
 constexpr int kTileJRows = 32, kTileJDw = 10;             // 32 rows x 40 bytes
 constexpr int kSlotDw = kTileJRows * kTileJDw;            // 320 dwords: the I tile (192) and the J tile
                                                           // of a slot alias (I is dead once the patch is in VGPRs)

@@ -227,204 +227,294 @@ __global__ __launch_bounds__(256) void orb_gather_kernel(OrbGeom g, const float4
     if (threadIdx.x == 0) lvl_cnt[b * g.nlevels + l] = min(total, cand_cap);
 }
 
-// ---- DistributeOctTree: array-based std::list, one lane per (level, image) ---------------------
-struct QNode { int ulx, uly, brx, bry, begin, count, prev, next, seq; };   // flags: count == 1 -> bNoMore
-constexpr int kQNodes = 4096;
+// ---- DistributeOctTree: one wavefront per (level, image) ----------------------------------------
+// The tree, its std::list order and the candidate keys live in LDS.  Control flow is wave-uniform
+// (the list walk, largest-first expansion and termination rules of ORBextractor.cpp:487-715 are
+// serial by definition), while everything that touches keys is done by the 64 lanes together:
+// DivideNode is a stable in-place 4-way partition of the node's key range (ballot ranks), the
+// "sort by size" of the last phase is a rank sort, and the final best-response pick runs one leaf
+// per lane.  A key is two words: x | y << 16 (cell-space pixel coordinates) and
+// candidate index | response << 24 (FAST cornerness <= 255); the partition is stable, so a node's
+// keys stay in candidate order and "first maximum" == smallest index among the maxima.
+constexpr int kNodeCap = 640;     // live nodes: <= quota + 3 leaves, + 4 children in flight
+constexpr int kLdsKeys = 4096;    // candidates partitioned in LDS; larger inputs use global scratch
 
-struct QTree {
-    QNode *nodes; int *idx; int *tmp; int *free_list;
-    int n_free, n_alloc, head, tail, size, seq;
-    const float4 *keys;
-    bool overflow;
+struct QBox { short ulx, uly, brx, bry; };
+struct QLds {
+    uint2 keys[kLdsKeys];
+    QBox box[kNodeCap];
+    int begin[kNodeCap], count[kNodeCap], seq[kNodeCap];
+    short prev[kNodeCap], next[kNodeCap], free_list[kNodeCap];
+    unsigned long long ea[kNodeCap], eb[kNodeCap];   // (count << 40 | seq << 12 | id) of nodes still to expand
 };
+struct QState { int n_free, n_alloc, head, tail, size, seq; bool overflow; };
 
-__device__ inline int qt_new(QTree &t)
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ inline int qt_new(QLds &L, QState &t, int lane)
 {
     int id;
-    if (t.n_free > 0) id = t.free_list[--t.n_free];
-    else if (t.n_alloc < kQNodes) id = t.n_alloc++;
-    else { t.overflow = true; id = kQNodes - 1; }
-    t.nodes[id].seq = t.seq++;
+    if (t.n_free > 0) id = rfl(L.free_list[--t.n_free]);
+    else if (t.n_alloc < kNodeCap) id = t.n_alloc++;
+    else { t.overflow = true; id = kNodeCap - 1; }
+    if (lane == 0) L.seq[id] = t.seq;
+    t.seq++;
     return id;
 }
-__device__ inline void qt_push_front(QTree &t, int id)
+__device__ inline void qt_push_front(QLds &L, QState &t, int id, int lane)
 {
-    t.nodes[id].next = t.head; t.nodes[id].prev = -1;
-    if (t.head >= 0) t.nodes[t.head].prev = id; else t.tail = id;
+    if (lane == 0) { L.next[id] = (short)t.head; L.prev[id] = -1; if (t.head >= 0) L.prev[t.head] = (short)id; }
+    if (t.head < 0) t.tail = id;
     t.head = id; t.size++;
 }
-__device__ inline void qt_push_back(QTree &t, int id)
+__device__ inline void qt_push_back(QLds &L, QState &t, int id, int lane)
 {
-    t.nodes[id].prev = t.tail; t.nodes[id].next = -1;
-    if (t.tail >= 0) t.nodes[t.tail].next = id; else t.head = id;
+    if (lane == 0) { L.prev[id] = (short)t.tail; L.next[id] = -1; if (t.tail >= 0) L.next[t.tail] = (short)id; }
+    if (t.tail < 0) t.head = id;
     t.tail = id; t.size++;
 }
-__device__ inline void qt_erase(QTree &t, int id)
+__device__ inline void qt_erase(QLds &L, QState &t, int id, int lane)
 {
-    const int p = t.nodes[id].prev, n = t.nodes[id].next;
-    if (p >= 0) t.nodes[p].next = n; else t.head = n;
-    if (n >= 0) t.nodes[n].prev = p; else t.tail = p;
-    t.size--;
-    t.free_list[t.n_free++] = id;
-}
-// ExtractorNode::DivideNode: stable 4-way partition of the node's key range (in place via tmp)
-__device__ inline void qt_divide(QTree &t, int id, int ch[4])
-{
-    const QNode P = t.nodes[id];
-    const int halfX = (int)ceilf((float)(P.brx - P.ulx) / 2), halfY = (int)ceilf((float)(P.bry - P.uly) / 2);
-    const int midx = P.ulx + halfX, midy = P.uly + halfY;
-    int cnt[4] = {0, 0, 0, 0};
-    for (int k = 0; k < P.count; k++) {
-        const float4 kp = t.keys[t.idx[P.begin + k]];
-        const int q = kp.x < (float)midx ? (kp.y < (float)midy ? 0 : 2) : (kp.y < (float)midy ? 1 : 3);
-        t.tmp[k] = q; cnt[q]++;
+    const int p = rfl(L.prev[id]), n = rfl(L.next[id]);
+    if (lane == 0) {
+        if (p >= 0) L.next[p] = (short)n;
+        if (n >= 0) L.prev[n] = (short)p;
+        L.free_list[t.n_free] = (short)id;
     }
-    int off[4] = {0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2]};
-    // stable scatter into tmp[count ..] then copy back
-    int pos[4] = {off[0], off[1], off[2], off[3]};
-    for (int k = 0; k < P.count; k++) { const int q = t.tmp[k]; t.tmp[P.count + pos[q]++] = t.idx[P.begin + k]; }
-    for (int k = 0; k < P.count; k++) t.idx[P.begin + k] = t.tmp[P.count + k];
-    const int ulx[4] = {P.ulx, midx, P.ulx, midx}, uly[4] = {P.uly, P.uly, midy, midy};
-    const int brx[4] = {midx, P.brx, midx, P.brx}, bry[4] = {midy, midy, P.bry, P.bry};
+    if (p < 0) t.head = n;
+    if (n < 0) t.tail = p;
+    t.size--; t.n_free++;
+}
+
+__device__ __forceinline__ int key_quadrant(uint2 k, int midx, int midy)
+{
+    return ((int)(k.x & 0xFFFFu) < midx ? 0 : 1) + ((int)(k.x >> 16) < midy ? 0 : 2);
+}
+// rank of this lane's key inside its quadrant for one 64-key chunk; adds the chunk's counts to c[]
+__device__ __forceinline__ int chunk_rank(bool valid, int q, int lane, int c[4])
+{
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned long long m = __ballot(valid && q == k);
+        if (q == k) r = c[k] + __popcll(m & lt);
+        c[k] += __popcll(m);
+    }
+    return r;
+}
+
+// ExtractorNode::DivideNode (ORBextractor.cpp:430-485): stable 4-way partition of the node's keys,
+// children created for the non-empty quadrants (ch[q] = node id or -1, cnt[q] = its key count)
+__device__ inline void qt_divide(QLds &L, QState &t, uint2 *keys, uint2 *gtmp, bool keys_global, int id, int ch[4],
+                                 int cnt[4], int cseq[4], int lane)
+{
+    const QBox P = L.box[id];
+    const int ulx = rfl(P.ulx), uly = rfl(P.uly), brx = rfl(P.brx), bry = rfl(P.bry);
+    const int beg = rfl(L.begin[id]), n = rfl(L.count[id]);
+    const int midx = ulx + ((brx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);   // ceil(d / 2)
+    cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+    if (n <= 64) {
+        const bool valid = lane < n;
+        const uint2 k = valid ? keys[beg + lane] : make_uint2(0, 0);
+        const int q = key_quadrant(k, midx, midy);
+        const int r = chunk_rank(valid, q, lane, cnt);
+        const int off = q == 0 ? 0 : (q == 1 ? cnt[0] : (q == 2 ? cnt[0] + cnt[1] : cnt[0] + cnt[1] + cnt[2]));
+        if (valid) keys[beg + off + r] = k;
+    } else if (n <= 512) {
+        uint2 k[8];
+        int q[8], r[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const bool valid = lane + 64 * c < n;
+            k[c] = valid ? keys[beg + lane + 64 * c] : make_uint2(0, 0);
+            q[c] = key_quadrant(k[c], midx, midy);
+            r[c] = chunk_rank(valid, q[c], lane, cnt);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int off = q[c] == 0 ? 0 : (q[c] == 1 ? cnt[0] : (q[c] == 2 ? cnt[0] + cnt[1] : cnt[0] + cnt[1] + cnt[2]));
+            if (lane + 64 * c < n) keys[beg + off + r[c]] = k[c];
+        }
+    } else {
+        for (int base = 0; base < n; base += 64) {
+            const bool valid = base + lane < n;
+            const uint2 k = valid ? keys[beg + base + lane] : make_uint2(0, 0);
+            chunk_rank(valid, key_quadrant(k, midx, midy), lane, cnt);
+        }
+        int run[4] = {0, 0, 0, 0};
+        const int o1 = cnt[0], o2 = cnt[0] + cnt[1], o3 = cnt[0] + cnt[1] + cnt[2];
+        for (int base = 0; base < n; base += 64) {
+            const bool valid = base + lane < n;
+            const uint2 k = valid ? keys[beg + base + lane] : make_uint2(0, 0);
+            const int q = key_quadrant(k, midx, midy);
+            const int r = chunk_rank(valid, q, lane, run);
+            const int off = q == 0 ? 0 : (q == 1 ? o1 : (q == 2 ? o2 : o3));
+            if (valid) gtmp[off + r] = k;
+        }
+        __threadfence();
+        for (int i = lane; i < n; i += 64) keys[beg + i] = gtmp[i];
+    }
+    if (keys_global) __threadfence();
+    const int cbeg[4] = {beg, beg + cnt[0], beg + cnt[0] + cnt[1], beg + cnt[0] + cnt[1] + cnt[2]};
+    const int cul[4][2] = {{ulx, uly}, {midx, uly}, {ulx, midy}, {midx, midy}};
+    const int cbr[4][2] = {{midx, midy}, {brx, midy}, {midx, bry}, {brx, bry}};
+#pragma unroll
     for (int q = 0; q < 4; q++) {
-        ch[q] = -1;
+        ch[q] = -1; cseq[q] = 0;
         if (cnt[q] == 0) continue;
-        const int nid = qt_new(t);
-        QNode &c = t.nodes[nid];
-        c.ulx = ulx[q]; c.uly = uly[q]; c.brx = brx[q]; c.bry = bry[q];
-        c.begin = P.begin + off[q]; c.count = cnt[q];
+        cseq[q] = t.seq;
+        const int nid = qt_new(L, t, lane);
+        if (lane == 0) {
+            QBox c; c.ulx = (short)cul[q][0]; c.uly = (short)cul[q][1]; c.brx = (short)cbr[q][0]; c.bry = (short)cbr[q][1];
+            L.box[nid] = c; L.begin[nid] = cbeg[q]; L.count[nid] = cnt[q];
+        }
         ch[q] = nid;
     }
 }
 
-// sort key: (size, creation order) ascending -- CANONICAL (O1)
-__device__ inline bool exp_less(const int2 &a, const int2 &b, const QNode *nodes)
+__device__ __forceinline__ unsigned long long exp_key(int count, int seq, int id)
 {
-    return a.x != b.x ? a.x < b.x : nodes[a.y].seq < nodes[b.y].seq;
+    return ((unsigned long long)count << 40) | ((unsigned long long)seq << 12) | (unsigned long long)id;
 }
-__device__ inline void exp_sort(int2 *v, int n, const QNode *nodes)      // heapsort
+// ascending (size, creation order) -- CANONICAL (O1); keys are unique, so rank == final position
+__device__ inline void exp_sort(const unsigned long long *in, unsigned long long *out, int n, int lane)
 {
-    for (int start = n / 2 - 1; start >= 0; start--) {
-        int root = start;
-        for (;;) {
-            int child = 2 * root + 1;
-            if (child >= n) break;
-            if (child + 1 < n && exp_less(v[child], v[child + 1], nodes)) child++;
-            if (!exp_less(v[root], v[child], nodes)) break;
-            int2 t = v[root]; v[root] = v[child]; v[child] = t; root = child;
-        }
-    }
-    for (int end = n - 1; end > 0; end--) {
-        int2 t = v[0]; v[0] = v[end]; v[end] = t;
-        int root = 0;
-        for (;;) {
-            int child = 2 * root + 1;
-            if (child >= end) break;
-            if (child + 1 < end && exp_less(v[child], v[child + 1], nodes)) child++;
-            if (!exp_less(v[root], v[child], nodes)) break;
-            int2 t2 = v[root]; v[root] = v[child]; v[child] = t2; root = child;
-        }
+    for (int i = lane; i < n; i += 64) {
+        const unsigned long long me = in[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += in[j] < me;
+        out[rank] = me;
     }
 }
 
 struct OrbDistArgs {
     OrbGeom g;
     const float4 *lvl_cand; const int *lvl_cnt; int cand_cap;
-    // scratch per instance
-    QNode *nodes; int *idx; int *tmp; int *free_list; int2 *exp_a; int2 *exp_b;
-    // outputs: selected candidate indices in list order
-    int *sel; int *sel_cnt; int sel_cap;
+    uint2 *gkeys, *gtmp;                  // per-instance scratch, cand_cap entries each
+    int *sel; int *sel_cnt; int sel_cap;  // outputs: selected candidate indices in list order
     int *overflow;
 };
 
 __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
 {
-    if (threadIdx.x != 0) return;
+    __shared__ QLds L;
+    const int lane = threadIdx.x;
     const int l = blockIdx.x, b = blockIdx.y, inst = b * a.g.nlevels + l;
     const int nkeys = a.lvl_cnt[inst];
-    const float4 *keys = a.lvl_cand + (int64_t)inst * a.cand_cap;
+    const float4 *cand = a.lvl_cand + (int64_t)inst * a.cand_cap;
     int *sel = a.sel + (int64_t)inst * a.sel_cap;
     const int W = a.g.w[l], H = a.g.h[l];
     const int minX = 16, maxX = W - 16, minY = 16, maxY = H - 16, N = a.g.quota[l];
-    QTree t;
-    t.nodes = a.nodes + (int64_t)inst * kQNodes; t.idx = a.idx + (int64_t)inst * a.cand_cap;
-    t.tmp = a.tmp + (int64_t)inst * 2 * a.cand_cap; t.free_list = a.free_list + (int64_t)inst * kQNodes;
-    int2 *ea = a.exp_a + (int64_t)inst * kQNodes, *eb = a.exp_b + (int64_t)inst * kQNodes;
-    t.n_free = 0; t.n_alloc = 0; t.head = t.tail = -1; t.size = 0; t.seq = 0; t.keys = keys; t.overflow = false;
-    if (maxX <= minX || maxY <= minY || nkeys == 0) { a.sel_cnt[inst] = 0; return; }
+    const bool keys_global = nkeys > kLdsKeys;
+    uint2 *keys = keys_global ? a.gkeys + (int64_t)inst * a.cand_cap : L.keys;
+    uint2 *gtmp = a.gtmp + (int64_t)inst * a.cand_cap;
+    QState t;
+    t.n_free = 0; t.n_alloc = 0; t.head = t.tail = -1; t.size = 0; t.seq = 0; t.overflow = false;
+    if (maxX <= minX || maxY <= minY || nkeys == 0) { if (lane == 0) a.sel_cnt[inst] = 0; return; }
     const int nIni = (int)roundf((float)(maxX - minX) / (maxY - minY));
-    if (nIni <= 0) { a.sel_cnt[inst] = 0; return; }
+    if (nIni <= 0) { if (lane == 0) a.sel_cnt[inst] = 0; return; }
     const float hX = (float)(maxX - minX) / nIni;
-    // root nodes: count, then fill (stable)
-    int rbeg = 0;
-    for (int i = 0; i < nIni && i < 64; i++) t.tmp[i] = 0;
-    for (int k = 0; k < nkeys; k++) t.tmp[min((int)(keys[k].x / hX), nIni - 1)]++;
-    int root[64];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    // root nodes: stable binning of the candidates by column strip
+    int filled = 0;
     for (int i = 0; i < nIni && i < 64; i++) {
-        const int id = qt_new(t);
-        QNode &n = t.nodes[id];
-        n.ulx = (int)(hX * (float)i); n.uly = 0; n.brx = (int)(hX * (float)(i + 1)); n.bry = maxY - minY;
-        n.begin = rbeg; n.count = 0;
-        rbeg += t.tmp[i];
-        qt_push_back(t, id);
-        root[i] = id;
+        const int start = filled;
+        for (int base = 0; base < nkeys; base += 256) {
+            float4 c4[4];                                     // four loads in flight
+#pragma unroll
+            for (int u = 0; u < 4; u++) c4[u] = cand[min(base + 64 * u + lane, nkeys - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = base + 64 * u + lane;
+                const float4 c = c4[u];
+                const bool mine = k < nkeys && min((int)(c.x / hX), nIni - 1) == i;
+                const unsigned long long m = __ballot(mine);
+                if (mine) keys[filled + __popcll(m & lt)] = make_uint2((uint32_t)(int)c.x | ((uint32_t)(int)c.y << 16),
+                                                                       (uint32_t)k | ((uint32_t)(int)c.z << 24));
+                filled += __popcll(m);
+            }
+        }
+        const int id = qt_new(L, t, lane);
+        if (lane == 0) {
+            QBox bx; bx.ulx = (short)(int)(hX * (float)i); bx.uly = 0; bx.brx = (short)(int)(hX * (float)(i + 1));
+            bx.bry = (short)(maxY - minY);
+            L.box[id] = bx; L.begin[id] = start; L.count[id] = filled - start;
+        }
+        qt_push_back(L, t, id, lane);
     }
-    for (int k = 0; k < nkeys; k++) { QNode &n = t.nodes[root[min((int)(keys[k].x / hX), nIni - 1)]]; t.idx[n.begin + n.count++] = k; }
-    for (int i = t.head; i >= 0;) { const int nx = t.nodes[i].next; if (t.nodes[i].count == 0) qt_erase(t, i); i = nx; }
+    if (keys_global) __threadfence();
+    for (int i = t.head; i >= 0;) {
+        const int nx = rfl(L.next[i]);
+        if (rfl(L.count[i]) == 0) qt_erase(L, t, i, lane);
+        i = nx;
+    }
 
     bool finish = false;
     int n_exp = 0;
     while (!finish) {
-        int prevSize = t.size, nToExpand = 0, lit = t.head, ch[4];
+        int prevSize = t.size, nToExpand = 0, lit = t.head, ch[4], cn[4], cs[4];
         n_exp = 0;
         while (lit >= 0) {
-            if (t.nodes[lit].count == 1) { lit = t.nodes[lit].next; continue; }
-            qt_divide(t, lit, ch);
+            if (rfl(L.count[lit]) == 1) { lit = rfl(L.next[lit]); continue; }
+            qt_divide(L, t, keys, gtmp, keys_global, lit, ch, cn, cs, lane);
+#pragma unroll
             for (int q = 0; q < 4; q++)
                 if (ch[q] >= 0) {
-                    qt_push_front(t, ch[q]);
-                    if (t.nodes[ch[q]].count > 1) { nToExpand++; if (n_exp < kQNodes) ea[n_exp++] = make_int2(t.nodes[ch[q]].count, ch[q]); }
+                    qt_push_front(L, t, ch[q], lane);
+                    if (cn[q] > 1) {
+                        nToExpand++;
+                        if (n_exp < kNodeCap) { if (lane == 0) L.ea[n_exp] = exp_key(cn[q], cs[q], ch[q]); n_exp++; }
+                    }
                 }
-            const int nx = t.nodes[lit].next;
-            qt_erase(t, lit);
+            const int nx = rfl(L.next[lit]);
+            qt_erase(L, t, lit, lane);
             lit = nx;
+            if (t.overflow) break;
         }
+        if (t.overflow) break;
         if (t.size >= N || t.size == prevSize) finish = true;
         else if (t.size + nToExpand * 3 > N) {
             while (!finish) {
                 prevSize = t.size;
                 const int n_prev = n_exp;
-                for (int j = 0; j < n_prev; j++) eb[j] = ea[j];
                 n_exp = 0;
-                exp_sort(eb, n_prev, t.nodes);
+                exp_sort(L.ea, L.eb, n_prev, lane);
                 for (int j = n_prev - 1; j >= 0; j--) {
-                    qt_divide(t, eb[j].y, ch);
+                    const int nid = rfl((int)((uint32_t)L.eb[j] & 0xFFFu));
+                    qt_divide(L, t, keys, gtmp, keys_global, nid, ch, cn, cs, lane);
+#pragma unroll
                     for (int q = 0; q < 4; q++)
                         if (ch[q] >= 0) {
-                            qt_push_front(t, ch[q]);
-                            if (t.nodes[ch[q]].count > 1 && n_exp < kQNodes) ea[n_exp++] = make_int2(t.nodes[ch[q]].count, ch[q]);
+                            qt_push_front(L, t, ch[q], lane);
+                            if (cn[q] > 1 && n_exp < kNodeCap) { if (lane == 0) L.ea[n_exp] = exp_key(cn[q], cs[q], ch[q]); n_exp++; }
                         }
-                    qt_erase(t, eb[j].y);
-                    if (t.size >= N) break;
+                    qt_erase(L, t, nid, lane);
+                    if (t.size >= N || t.overflow) break;
                 }
-                if (t.size >= N || t.size == prevSize) finish = true;
+                if (t.size >= N || t.size == prevSize || t.overflow) finish = true;
             }
         }
-        if (t.overflow) break;
     }
+    // leaves in list order -> best response of each (one leaf per lane)
+    int *order = (int *)L.ea;
     int m = 0;
-    for (int i = t.head; i >= 0 && m < a.sel_cap; i = t.nodes[i].next) {
-        const QNode &n = t.nodes[i];
-        int best = t.idx[n.begin];
-        float maxR = keys[best].z;
-        for (int k = 1; k < n.count; k++) {
-            const int c = t.idx[n.begin + k];
-            if (keys[c].z > maxR) { best = c; maxR = keys[c].z; }
+    for (int i = t.head; i >= 0 && m < a.sel_cap; i = rfl(L.next[i])) { if (lane == 0) order[m] = i; m++; }
+    for (int j = lane; j < m; j += 64) {
+        const int id = order[j], beg = L.begin[id], n = L.count[id];
+        uint32_t best = 0;
+        for (int k = 0; k < n; k++) {
+            const uint32_t y = keys[beg + k].y;
+            const uint32_t sc = (y & 0xFF000000u) | (0xFFFFFFu - (y & 0xFFFFFFu));
+            best = max(best, sc);
         }
-        sel[m++] = best;
+        sel[j] = (int)(0xFFFFFFu - (best & 0xFFFFFFu));
     }
-    a.sel_cnt[inst] = m;
-    if (t.overflow) atomicOr(a.overflow, 1);
+    if (lane == 0) {
+        a.sel_cnt[inst] = m;
+        if (t.overflow) atomicOr(a.overflow, 1);
+    }
 }
 
 // ---- blur (7x7, sigma 2, reflect-101; integer kernel, (sum + 2^15) >> 16, saturated) -------------
@@ -721,12 +811,8 @@ int orb_alloc(svo_ctx *ctx)
     SVO_HIP(hipMalloc(&ctx->orb_cell_cnt, sizeof(int) * (size_t)g.cells_total * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_lvl_cand, sizeof(float4) * (size_t)kCandCap * L * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_lvl_cnt, sizeof(int) * (size_t)L * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_nodes, sizeof(QNode) * (size_t)kQNodes * L * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_idx, sizeof(int) * (size_t)kCandCap * L * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_qtmp, sizeof(int) * (size_t)2 * kCandCap * L * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_free, sizeof(int) * (size_t)kQNodes * L * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_exp_a, sizeof(int2) * (size_t)kQNodes * L * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_exp_b, sizeof(int2) * (size_t)kQNodes * L * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_qkeys, sizeof(uint2) * (size_t)kCandCap * L * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_qtmp, sizeof(uint2) * (size_t)kCandCap * L * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_sel, sizeof(int) * (size_t)kSelCap * L * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_sel_cnt, sizeof(int) * (size_t)L * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_overflow, sizeof(int)));
@@ -748,7 +834,7 @@ void orb_free(svo_ctx *c)
 {
     auto F = [](void *p) { if (p) (void)hipFree(p); };
     F(c->orb_slots); F(c->orb_blur); F(c->orb_tmp); F(c->orb_cell_cand); F(c->orb_cell_cnt); F(c->orb_lvl_cand);
-    F(c->orb_lvl_cnt); F(c->orb_nodes); F(c->orb_idx); F(c->orb_qtmp); F(c->orb_free); F(c->orb_exp_a); F(c->orb_exp_b);
+    F(c->orb_lvl_cnt); F(c->orb_qkeys); F(c->orb_qtmp);
     F(c->orb_sel); F(c->orb_sel_cnt); F(c->orb_overflow); F(c->orb_kps); F(c->orb_desc); F(c->orb_n);
     for (int k = 0; k < 2; k++) { F(c->orb_midx[k]); F(c->orb_mdist[k]); }
 }
@@ -790,9 +876,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
                        (int64_t)g.cells_total, lvl_cand, lvl_cnt, kCandCap, ctx->orb_overflow);
     OrbDistArgs d{};
     d.g = g; d.lvl_cand = lvl_cand; d.lvl_cnt = lvl_cnt; d.cand_cap = kCandCap;
-    d.nodes = (QNode *)ctx->orb_nodes + (size_t)slot0 * L * kQNodes; d.idx = ctx->orb_idx + (size_t)slot0 * L * kCandCap;
-    d.tmp = ctx->orb_qtmp + (size_t)slot0 * L * 2 * kCandCap; d.free_list = ctx->orb_free + (size_t)slot0 * L * kQNodes;
-    d.exp_a = (int2 *)ctx->orb_exp_a + (size_t)slot0 * L * kQNodes; d.exp_b = (int2 *)ctx->orb_exp_b + (size_t)slot0 * L * kQNodes;
+    d.gkeys = (uint2 *)ctx->orb_qkeys + (size_t)slot0 * L * kCandCap; d.gtmp = (uint2 *)ctx->orb_qtmp + (size_t)slot0 * L * kCandCap;
     d.sel = ctx->orb_sel + (size_t)slot0 * L * kSelCap; d.sel_cnt = ctx->orb_sel_cnt + (size_t)slot0 * L; d.sel_cap = kSelCap;
     d.overflow = ctx->orb_overflow;
     hipLaunchKernelGGL(orb_distribute_kernel, dim3(L, n_img), dim3(64), 0, st, d);

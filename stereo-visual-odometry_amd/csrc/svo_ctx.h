@@ -46,8 +46,7 @@ struct svo_ctx {
     uint8_t *orb_slots = nullptr, *orb_blur = nullptr; int *orb_tmp = nullptr;
     float4 *orb_cell_cand = nullptr; int *orb_cell_cnt = nullptr;
     float4 *orb_lvl_cand = nullptr; int *orb_lvl_cnt = nullptr;
-    void *orb_nodes = nullptr; int *orb_idx = nullptr, *orb_qtmp = nullptr, *orb_free = nullptr;
-    void *orb_exp_a = nullptr, *orb_exp_b = nullptr;
+    void *orb_qkeys = nullptr, *orb_qtmp = nullptr;      // quadtree key scratch (inputs larger than its LDS)
     int *orb_sel = nullptr, *orb_sel_cnt = nullptr, *orb_overflow = nullptr;
     void *orb_kps = nullptr; uint8_t *orb_desc = nullptr; int *orb_n = nullptr; int orb_kp_cap = 0, orb_cand_cap = 0;
     int *orb_midx[2] = {nullptr, nullptr}; float *orb_mdist[2] = {nullptr, nullptr};
