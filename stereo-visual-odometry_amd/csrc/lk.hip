@@ -216,10 +216,18 @@ __device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane 
 // Column words C_j = (J[r0][j] | J[r1][j] << 16) pair the two window rows, so a bilinear sample is
 //   val_k = dot2(C_k, (w00 | w10 << 16)) + dot2(C_k+1, (w01 | w11 << 16)) + 2^8
 // (signed 16-bit weights: w11 == -1 needs no special case).
+__device__ __forceinline__ int dot2_z(uint32_t a, uint32_t b)      // a . b + 0, no v_mov of the zero
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void mismatch_slot(const uint32_t *tileJ, const PixLane &pl, int cx, int cy,
                                               uint32_t Wa, uint32_t Wb, const uint32_t (&IvP)[4],
                                               const uint32_t (&IxP)[4], const uint32_t (&IyP)[4], int &pb1, int &pb2)
 {
+    // (ds_read_u8_d16 / _d16_hi straight into register halves would spare the perms, but with
+    //  SRAM-ECC on -- gfx950 -- a d16 load zeroes the other half instead of preserving it)
     uint32_t a0, b0, a1, b1;                 // row 0 / row 1: bytes 0-3 (a), 4-7 (b)
     load8(tileJ + (cy + pl.row) * kTileJDw, cx + pl.seg * 7, a0, b0);
     load8(tileJ + (cy + pl.row + 1) * kTileJDw, cx + pl.seg * 7, a1, b1);
@@ -229,18 +237,18 @@ __device__ __forceinline__ void mismatch_slot(const uint32_t *tileJ, const PixLa
         C[j] = perm_b32(a1, a0, 0x0c040c00u + 0x00010001u * j);
         C[4 + j] = perm_b32(b1, b0, 0x0c040c00u + 0x00010001u * j);
     }
-    uint32_t v[8];
-    v[7] = 0;
+    int d[7];
 #pragma unroll
-    for (int k = 0; k < 7; k++)
-        v[k] = (uint32_t)(dot2(C[k + 1], Wb, dot2_k(C[k], Wa, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5));
-    pb1 = 0; pb2 = 0;
+    for (int k = 0; k < 7; k++) d[k] = dot2(C[k + 1], Wb, dot2_k(C[k], Wa, 1 << (W_BITS - 5 - 1)));
+    // J samples d >> 9 (0 <= d < 2^22): bytes 1-2 of two sums side by side, then one packed shift
+    const u16x2 one = {1, 1};
 #pragma unroll
     for (int m = 0; m < 4; m++) {
-        const uint32_t vp = m < 3 ? perm_b32(v[2 * m + 1], v[2 * m], 0x05040100u) : v[6];
+        const uint32_t vp = m < 3 ? as_u32(as_u16x2(perm_b32((uint32_t)d[2 * m + 1], (uint32_t)d[2 * m], 0x06050201u)) >> one)
+                                  : (uint32_t)(d[6] >> (W_BITS - 5));
         const uint32_t dp = as_u32(as_u16x2(vp) - as_u16x2(IvP[m]));      // packed J - I (13-bit magnitudes)
-        pb1 = dot2(dp, IxP[m], pb1);
-        pb2 = dot2(dp, IyP[m], pb2);
+        pb1 = m == 0 ? dot2_z(dp, IxP[m]) : dot2(dp, IxP[m], pb1);
+        pb2 = m == 0 ? dot2_z(dp, IyP[m]) : dot2(dp, IyP[m], pb2);
     }
 }
 
