@@ -28,7 +28,7 @@
 //
 // Exactness: all pixel arithmetic is upstream's fixed point (14-bit weights, 5 fractional bits);
 // the five sums A11,A12,A22,b1,b2 are accumulated as exact integers (per-lane int32 partials,
-// 16-bit halves reduced separately, recombined through one exact double) and converted to float
+// 16-bit halves reduced separately, recombined with one fused multiply-add) and converted to float
 // once -- the canonical recipe of oracle/lk.c, so status bytes and point coordinates are
 // bit-identical to the oracle.  FP contraction is off.
 //
@@ -70,10 +70,12 @@ __device__ __forceinline__ int dot2_k(uint32_t a, uint32_t b, int k)
 __device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 
-// exact (float)(hi * 65536 + lo) with round-to-nearest-even, via one exact double
+// exact (float)(hi * 65536 + lo) with round-to-nearest-even: |hi|, |lo| < 2^24 convert exactly
+// and one fused multiply-add rounds the exact sum once (f64 conversions issue at a fraction of
+// the f32 rate, and this runs every iteration)
 __device__ __forceinline__ float wide_to_f32(int hi, int lo)
 {
-    return (float)((double)hi * 65536.0 + (double)lo);
+    return __builtin_fmaf((float)hi, 65536.f, (float)lo);
 }
 struct Weights { int w00, w01, w10, w11; };
 // iw00 = cvRound((1-a)(1-b) 2^14) ...: the 2^14 scale is folded into the b factors first; scaling
@@ -391,10 +393,16 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
             }
             const float dlx = (A12 * b2f - A22 * b1f) * D;
             const float dly = (A12 * b1f - A11 * b2f) * D;
+            // "delta.ddot(delta) <= epsilon" is a double comparison upstream; float decides it unless
+            // the sum lands within 1e-4 relative of epsilon (float error here < 2e-7 relative)
+            const float dd = dlx * dlx + dly * dly;
+            bool conv = dd <= 0.9999e-4f;
+            if (__any(it_on && !conv && dd < 1.0001e-4f))
+                conv = (double)dlx * (double)dlx + (double)dly * (double)dly <= 0.01 * 0.01;
             if (it_on) {
                 qx += dlx; qy += dly;
                 nx = qx + half; ny = qy + half;
-                if ((double)dlx * (double)dlx + (double)dly * (double)dly <= 0.01 * 0.01) it_on = false;
+                if (conv) it_on = false;
                 // "std::abs(delta.x + prevDelta.x) < 0.01" compares a float with the double 0.01; the
                 // largest float below 0.01 is 0.01f itself, so "<= 0.01f" in float is the same predicate
                 else if (j > 0 && fabsf(dlx + pdx) <= 0.01f && fabsf(dly + pdy) <= 0.01f) {
