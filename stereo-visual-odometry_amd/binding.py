@@ -174,10 +174,13 @@ class Context:
 
     # ---- stage API --------------------------------------------------------------------------
     def _img(self, img):
-        p, mem = _ptr(img)
-        pitch = img.strides[0] if isinstance(img, np.ndarray) else img.stride(0)
+        """(pointer, row pitch in bytes, memory kind) of a u8 image; rows may be padded (pitch >= width)."""
         assert tuple(img.shape) == (self.height, self.width), (img.shape, self.height, self.width)
-        return p, int(pitch), mem
+        if isinstance(img, np.ndarray):
+            assert img.dtype == np.uint8 and img.strides[1] == 1
+            return C.c_void_p(img.ctypes.data), int(img.strides[0]), MEM_HOST
+        assert img.element_size() == 1 and img.stride(1) == 1
+        return C.c_void_p(img.data_ptr()), int(img.stride(0)), (MEM_DEVICE if img.is_cuda else MEM_HOST)
 
     def fast_detect(self, img, threshold=20, nonmax=True, cap=None):
         cap = cap or self.cfg.max_keypoints

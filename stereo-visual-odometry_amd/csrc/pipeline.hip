@@ -192,6 +192,27 @@ int pipeline_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t
     return SVO_OK;
 }
 
+// Host image -> device staging: the rows are gathered into a pinned mirror with the staging pitch
+// and go over PCIe as ONE copy (a pitched 2-D copy from pageable memory is issued row by row and
+// costs ~5 ms per KITTI pair).
+int stage_host_image(svo_ctx *ctx, const uint8_t *img, int pitch, int stage_idx, const uint8_t **dptr, int *dpitch)
+{
+    const int w = ctx->cfg.width, h = ctx->cfg.height, sp = ctx->stage_pitch;
+    const size_t bytes = (size_t)sp * h;
+    uint8_t *hs = ctx->h_stage + (size_t)stage_idx * bytes;
+    uint8_t *dst = ctx->stage_img + (size_t)stage_idx * bytes;
+    if (ctx->h_stage_busy[stage_idx]) {
+        SVO_HIP(hipEventSynchronize(ctx->ev_stage[stage_idx]));
+        ctx->h_stage_busy[stage_idx] = false;
+    }
+    for (int y = 0; y < h; y++) memcpy(hs + (size_t)y * sp, img + (size_t)y * pitch, (size_t)w);
+    SVO_HIP(hipMemcpyAsync(dst, hs, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SVO_HIP(hipEventRecord(ctx->ev_stage[stage_idx], ctx->stream));
+    ctx->h_stage_busy[stage_idx] = true;
+    *dptr = dst; *dpitch = sp;
+    return SVO_OK;
+}
+
 int pipeline_add_frame(svo_ctx *ctx, const uint8_t *left, const uint8_t *right, int pitch, int mem,
                        svo_step_result *res)
 {
@@ -202,10 +223,10 @@ int pipeline_add_frame(svo_ctx *ctx, const uint8_t *left, const uint8_t *right, 
     const uint8_t *dL = left, *dR = right;
     int dp = pitch;
     if (mem == SVO_MEM_HOST) {
-        uint8_t *sL = ctx->stage_img, *sR = ctx->stage_img + (size_t)ctx->stage_pitch * ctx->cfg.height;
-        SVO_HIP(hipMemcpy2DAsync(sL, ctx->stage_pitch, left, pitch, ctx->cfg.width, ctx->cfg.height, hipMemcpyHostToDevice, ctx->stream));
-        SVO_HIP(hipMemcpy2DAsync(sR, ctx->stage_pitch, right, pitch, ctx->cfg.width, ctx->cfg.height, hipMemcpyHostToDevice, ctx->stream));
-        dL = sL; dR = sR; dp = ctx->stage_pitch;
+        int rcs = stage_host_image(ctx, left, pitch, 0, &dL, &dp);
+        if (rcs) return rcs;
+        rcs = stage_host_image(ctx, right, pitch, 1, &dR, &dp);
+        if (rcs) return rcs;
     }
     // two-frame ring in frame slots 0 / 1
     const int cur = ctx->online_frames == 0 ? 0 : (ctx->online_cur ^ 1);

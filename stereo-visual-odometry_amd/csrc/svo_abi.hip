@@ -93,6 +93,8 @@ static void free_all(svo_ctx *c)
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     orb_free(c);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (int k = 0; k < 2; k++) if (c->ev_stage[k]) (void)hipEventDestroy(c->ev_stage[k]);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
 }
@@ -131,6 +133,8 @@ extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
     ctx->slot_built.assign(cfg->num_slots, 0);
     ctx->stage_pitch = align_up(w, 256);
     CK(hipMalloc(&ctx->stage_img, (size_t)ctx->stage_pitch * h * 2));
+    CK(hipHostMalloc(&ctx->h_stage, (size_t)ctx->stage_pitch * h * 2, hipHostMallocDefault));
+    for (int k = 0; k < 2; k++) CK(hipEventCreateWithFlags(&ctx->ev_stage[k], hipEventDisableTiming));
     ctx->spitch = align_up(w, 64);
     ctx->score_stride = (int64_t)ctx->spitch * h;
     CK(hipMalloc(&ctx->score, (size_t)ctx->score_stride * n_img));
@@ -270,11 +274,7 @@ static int resolve_image(svo_ctx *ctx, const uint8_t *img, int pitch, int mem, i
     SVO_ARG(pitch >= ctx->cfg.width, "pitch < width");
     if (mem == SVO_MEM_DEVICE) { *dptr = img; *dpitch = pitch; return SVO_OK; }
     SVO_ARG(mem == SVO_MEM_HOST, "mem must be SVO_MEM_HOST or SVO_MEM_DEVICE");
-    uint8_t *dst = ctx->stage_img + (size_t)stage_idx * ctx->stage_pitch * ctx->cfg.height;
-    SVO_HIP(hipMemcpy2DAsync(dst, ctx->stage_pitch, img, pitch, ctx->cfg.width, ctx->cfg.height,
-                             hipMemcpyHostToDevice, ctx->stream));
-    *dptr = dst; *dpitch = ctx->stage_pitch;
-    return SVO_OK;
+    return svo::stage_host_image(ctx, img, pitch, stage_idx, dptr, dpitch);
 }
 
 extern "C" int svo_fast_detect(svo_ctx *ctx, const uint8_t *img, int pitch, int mem, int threshold,

@@ -19,6 +19,9 @@ struct svo_ctx {
     std::vector<char> slot_built;
     uint8_t *stage_img = nullptr;     // device staging for host images (2 images, aligned pitch)
     int stage_pitch = 0;
+    uint8_t *h_stage = nullptr;       // pinned mirror of stage_img: rows gathered on the host, one H2D copy per image
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    bool h_stage_busy[2] = {false, false};
     // ---- FAST scratch + outputs, n_img images
     uint8_t *score = nullptr; int spitch = 0; int64_t score_stride = 0;
     int *rowcount = nullptr; int64_t rowcount_stride = 0;
@@ -93,6 +96,7 @@ void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n
 // orb.hip
 int orb_alloc(svo_ctx *ctx);
 void orb_free(svo_ctx *ctx);
+int stage_host_image(svo_ctx *ctx, const uint8_t *img, int pitch, int stage_idx, const uint8_t **dptr, int *dpitch);
 int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int pitch, int64_t img_stride, int slot0,
                       int n_img, hipStream_t st);
 int orb_match_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipStream_t st);
