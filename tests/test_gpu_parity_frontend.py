@@ -185,3 +185,28 @@ def test_lk_parity_kitti_size(pkg, oracle, torch_cuda, synth):
     for k in range(4):
         assert got[k].tobytes() == res["tracks"][k].tobytes()
     ctx.close()
+
+
+def test_lk_parity_hd_stress_size(pkg, oracle, torch_cuda, synth):
+    """BASELINE config #4 size (1920x1080, about 2000 features): FAST at a raised threshold, the
+    2000 strongest corners (ties: row-major first), circular LK -- bit-exact."""
+    w, h = 1920, 1080
+    seq = synth.StereoSequence(width=w, height=h, n_frames=2, seed=1, supersample=1)
+    fr = [tuple(x.numpy() for x in seq.render(t)) for t in range(2)]
+    (L0, R0), (L1, R1) = fr
+    ctx = _ctx(pkg, w, h, max_keypoints=1 << 16)
+    kp = ctx.fast_detect(L0, threshold=20)
+    ref_kp = oracle.fast(L0, thr=20)
+    assert kp.tobytes() == ref_kp.tobytes() and len(kp) >= 2000
+    order = np.argsort(-kp["response"], kind="stable")[:2000]
+    sel = ref_kp[np.sort(order)]
+    for s, im in enumerate((L0, R0, L1, R1)):
+        ctx.build_pyramid(s, im)
+    pts = np.stack([sel["x"], sel["y"]], 1).astype(np.float32)
+    prm = oracle.make_params(*seq.proj())
+    res, _, _ = oracle.lk_track_step(prm, L0, R0, L1, R1, sel, np.eye(4), want_tracks=True, threads=8)
+    got = ctx.circular_match((0, 1, 2, 3), pts)
+    assert got[0].shape[0] == res["n_tracked"] and res["n_tracked"] > 300
+    for k in range(4):
+        assert got[k].tobytes() == res["tracks"][k].tobytes()
+    ctx.close()
