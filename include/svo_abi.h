@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 2
+#define SVO_ABI_VERSION 3
 
 /* status codes */
 #define SVO_OK                 0
@@ -190,6 +190,25 @@ int svo_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t *rig
  * reuses the shared buffers. */
 int svo_set_overlap(svo_ctx *ctx, int on);
 int svo_wait_results(svo_ctx *ctx);
+
+/* Host-resident frame batches: image ingest off the critical path (replaces
+ * the per-frame cv::imread -> Tracking::AddFrame hand-over of reference src/System.cpp:46-58,75-104
+ * for the batched runner).
+ *   svo_host_alloc / svo_host_free : page-locked host memory, so decoder threads write straight
+ *       into DMA-able buffers;
+ *   svo_upload_frames : ASYNCHRONOUS host-to-device copy of n_frames stereo frames (frame f at
+ *       base + f*frame_stride, rows `pitch` apart) into the context's device frame buffer `buf`
+ *       (0 or 1) on the context's copy stream -- it runs beside the kernels of the batch that
+ *       lives in the other buffer.  The host memory must stay untouched until svo_wait_upload;
+ *   svo_track_uploaded : svo_track_batch on the frames of buffer `buf` (ordered after their upload
+ *       on the device, no host wait). */
+int svo_host_alloc(svo_ctx *ctx, size_t bytes, void **out);
+int svo_host_free(svo_ctx *ctx, void *p);
+int svo_upload_frames(svo_ctx *ctx, int buf, const uint8_t *left_frames, const uint8_t *right_frames,
+                      int pitch, int64_t frame_stride, int n_frames);
+int svo_wait_upload(svo_ctx *ctx, int buf);
+int svo_track_uploaded(svo_ctx *ctx, int buf, int n_frames, const double *pose0,
+                       svo_step_result *results, int results_mem);
 
 /* Kernel-level timing of the last svo_track_batch / svo_add_frame, measured with HIP events on
  * the context's stream: fills up to `cap` (name, milliseconds) pairs, returns the count.

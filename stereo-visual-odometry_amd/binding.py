@@ -87,6 +87,11 @@ def load_library():
     lib.svo_default_config.restype = None
     lib.svo_track_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_int]
+    lib.svo_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.svo_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.svo_upload_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]
+    lib.svo_wait_upload.argtypes = [C.c_void_p, C.c_int]
+    lib.svo_track_uploaded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     _LIB = lib
     return lib
 
@@ -362,4 +367,40 @@ class Context:
         self._check(self.lib.svo_track_batch(self.h, C.c_void_p(left_frames.data_ptr()),
                                              C.c_void_p(right_frames.data_ptr()), int(pitch), int(fstride),
                                              int(F), p0, rp, rmem))
+        return out
+
+    # ---- host-resident frame batches (svo_upload_frames / svo_track_uploaded) -----------------
+    def host_frames(self, n_frames, pitch=None):
+        """(n_frames, height, pitch) uint8 numpy view over page-locked host memory (svo_host_alloc);
+        release it with host_free(view)."""
+        pitch = pitch or self.width
+        nbytes = int(n_frames) * self.height * int(pitch)
+        p = C.c_void_p()
+        self._check(self.lib.svo_host_alloc(self.h, nbytes, C.byref(p)))
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        view = np.frombuffer(buf, dtype=np.uint8).reshape(int(n_frames), self.height, int(pitch))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[view.ctypes.data] = p
+        return view
+
+    def host_free(self, view):
+        p = self._pinned.pop(view.ctypes.data)
+        self._check(self.lib.svo_host_free(self.h, p))
+
+    def upload_frames(self, buf, left, right):
+        """left/right: (F, height, pitch) uint8 host arrays (ideally from host_frames); asynchronous."""
+        assert left.shape == right.shape and left.strides == right.strides and left.strides[2] == 1
+        self._check(self.lib.svo_upload_frames(self.h, int(buf), C.c_void_p(left.ctypes.data), C.c_void_p(right.ctypes.data),
+                                               int(left.strides[1]), int(left.strides[0]), int(left.shape[0])))
+
+    def wait_upload(self, buf):
+        self._check(self.lib.svo_wait_upload(self.h, int(buf)))
+
+    def track_uploaded(self, buf, n_frames, pose0=None):
+        p0 = None
+        if pose0 is not None:
+            pose0 = np.ascontiguousarray(pose0, np.float64).reshape(16)
+            p0 = C.c_void_p(pose0.ctypes.data)
+        out = np.zeros(int(n_frames) - 1, dtype=STEP_DTYPE)
+        self._check(self.lib.svo_track_uploaded(self.h, int(buf), int(n_frames), p0, C.c_void_p(out.ctypes.data), MEM_HOST))
         return out

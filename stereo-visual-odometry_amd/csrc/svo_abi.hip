@@ -91,6 +91,12 @@ static void free_all(svo_ctx *c)
     if (c->ev_front) (void)hipEventDestroy(c->ev_front);
     if (c->ev_back) (void)hipEventDestroy(c->ev_back);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    for (int k = 0; k < 2; k++) {
+        F(c->fb[k]);
+        if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]);
+        if (c->ev_fb_free[k]) (void)hipEventDestroy(c->ev_fb_free[k]);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     orb_free(c);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -620,4 +626,91 @@ extern "C" int svo_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const u
     if (!ctx) return SVO_ERR_ARG;
     return pipeline_track_batch(ctx, left_frames, right_frames, pitch, frame_stride, n_frames, pose0,
                                 results, results_mem);
+}
+
+// ---- host-resident frame batches ---------------------------------------------------------------
+extern "C" int svo_host_alloc(svo_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(out && bytes > 0, "null output / zero size");
+    SVO_HIP(hipSetDevice(ctx->device));
+    SVO_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return SVO_OK;
+}
+
+extern "C" int svo_host_free(svo_ctx *ctx, void *p)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    if (p) SVO_HIP(hipHostFree(p));
+    return SVO_OK;
+}
+
+static int frame_buffers(svo_ctx *ctx)
+{
+    if (ctx->copy_stream) return SVO_OK;
+    const size_t per_cam = (size_t)ctx->stage_pitch * ctx->cfg.height * (size_t)(ctx->cfg.max_batch + 1);
+    for (int k = 0; k < 2; k++) {
+        SVO_HIP(hipMalloc(&ctx->fb[k], 2 * per_cam));
+        SVO_HIP(hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming));
+        SVO_HIP(hipEventCreateWithFlags(&ctx->ev_fb_free[k], hipEventDisableTiming));
+    }
+    SVO_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    return SVO_OK;
+}
+
+extern "C" int svo_upload_frames(svo_ctx *ctx, int buf, const uint8_t *left_frames, const uint8_t *right_frames,
+                                 int pitch, int64_t frame_stride, int n_frames)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(buf == 0 || buf == 1, "buf must be 0 or 1");
+    SVO_ARG(left_frames && right_frames, "null frames");
+    SVO_ARG(n_frames >= 1 && n_frames <= ctx->cfg.max_batch + 1, "n_frames must be in [1, max_batch + 1]");
+    SVO_ARG(pitch >= ctx->cfg.width && frame_stride >= (int64_t)pitch * ctx->cfg.height, "bad pitch / frame_stride");
+    SVO_HIP(hipSetDevice(ctx->device));
+    int rc = frame_buffers(ctx);
+    if (rc) return rc;
+    const int w = ctx->cfg.width, h = ctx->cfg.height, sp = ctx->stage_pitch;
+    const size_t fbytes = (size_t)sp * h, per_cam = fbytes * (size_t)(ctx->cfg.max_batch + 1);
+    // the batch that last read this buffer must have been ingested
+    if (ctx->fb_used[buf]) SVO_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_fb_free[buf], 0));
+    const uint8_t *src[2] = {left_frames, right_frames};
+    for (int cam = 0; cam < 2; cam++) {
+        uint8_t *dst = ctx->fb[buf] + cam * per_cam;
+        if (pitch == sp && frame_stride == (int64_t)fbytes) {
+            SVO_HIP(hipMemcpyAsync(dst, src[cam], fbytes * (size_t)n_frames, hipMemcpyHostToDevice, ctx->copy_stream));
+        } else {
+            for (int f = 0; f < n_frames; f++)
+                SVO_HIP(hipMemcpy2DAsync(dst + f * fbytes, sp, src[cam] + f * frame_stride, pitch, w, h,
+                                         hipMemcpyHostToDevice, ctx->copy_stream));
+        }
+    }
+    SVO_HIP(hipEventRecord(ctx->ev_up[buf], ctx->copy_stream));
+    ctx->fb_frames[buf] = n_frames;
+    return SVO_OK;
+}
+
+extern "C" int svo_wait_upload(svo_ctx *ctx, int buf)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(buf == 0 || buf == 1, "buf must be 0 or 1");
+    SVO_ARG(ctx->fb_frames[buf] > 0, "nothing uploaded into this buffer");
+    SVO_HIP(hipEventSynchronize(ctx->ev_up[buf]));
+    return SVO_OK;
+}
+
+extern "C" int svo_track_uploaded(svo_ctx *ctx, int buf, int n_frames, const double *pose0,
+                                  svo_step_result *results, int results_mem)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(buf == 0 || buf == 1, "buf must be 0 or 1");
+    SVO_ARG(n_frames >= 2 && n_frames <= ctx->fb_frames[buf], "n_frames exceeds what was uploaded");
+    SVO_HIP(hipSetDevice(ctx->device));
+    const size_t fbytes = (size_t)ctx->stage_pitch * ctx->cfg.height, per_cam = fbytes * (size_t)(ctx->cfg.max_batch + 1);
+    SVO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_up[buf], 0));
+    int rc = pipeline_track_batch(ctx, ctx->fb[buf], ctx->fb[buf] + per_cam, ctx->stage_pitch, (int64_t)fbytes, n_frames,
+                                  pose0, results, results_mem);
+    if (rc < 0) return rc;
+    SVO_HIP(hipEventRecord(ctx->ev_fb_free[buf], ctx->stream));
+    ctx->fb_used[buf] = true;
+    return rc;
 }

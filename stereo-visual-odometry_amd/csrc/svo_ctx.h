@@ -59,6 +59,12 @@ struct svo_ctx {
     //      the caller's stream already ingests / tracks batch k+1
     bool overlap = false;
     hipStream_t side_stream = nullptr;
+    // ---- host-frame batches (svo_upload_frames): two device frame buffers filled on copy_stream
+    uint8_t *fb[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_fb_free[2] = {nullptr, nullptr};
+    bool fb_used[2] = {false, false};
+    int fb_frames[2] = {0, 0};
     hipEvent_t ev_front = nullptr, ev_back = nullptr;
     bool back_pending = false;
     unsigned pose0_ring = 0;

@@ -19,6 +19,12 @@ public:
     bool Step();
     bool Step_ros(Frame::Ptr new_frame);
 
+    // additive: batched runner.  Frames are decoded by `decode_threads`
+    // threads into page-locked memory while the GPU tracks the previous batch of `batch_size` frame
+    // pairs; poses come out exactly as Run() would produce them.  Run() uses it when the YAML has
+    // batch_size > 1 (additive keys batch_size / decode_threads; absent = the reference's per-frame loop).
+    void RunBatched(int batch_size, int decode_threads);
+
     // additive: write one KITTI-format pose row (12 numbers of [R|t]) per frame
     bool SetPoseFile(const std::string &path);
     Tracking::Ptr GetTracking() { return tracking_; }
@@ -30,6 +36,8 @@ private:
     void Shutdown();
     void Reset();
     void WritePose();
+    void WritePoseRow(const double *pose16);
+    bool ReadStereo(int index, cv::Mat &left, cv::Mat &right);
 
     std::string config_file_path_;
     Parameter::Ptr init_parameter_ = nullptr;

@@ -32,6 +32,14 @@ public:
     const svo_step_result &LastResult() const { return last_; }
     void SetFillFeatures(bool on) { fill_features_ = on; }   // populate Frame::features_left_ (costs a D2H)
 
+    // additive: batched tracking of host-resident frames.  The context is
+    // (re)created for `max_batch` frame pairs per launch; frames travel with svo_upload_frames and
+    // TrackUploaded runs svo_track_uploaded on device buffer `buf`, appends the n_frames - 1 step
+    // records and advances frame_pose_ exactly as n_frames - 1 AddFrame calls would.
+    bool EnsureBatchContext(int width, int height, int max_batch) { return EnsureContext(width, height, max_batch); }
+    svo_ctx *Context() { return ctx_; }
+    bool TrackUploaded(int buf, int n_frames, std::vector<svo_step_result> &out);
+
 private:
     bool StereoInit_f2f();
     bool Track();
@@ -39,7 +47,7 @@ private:
     bool ORB_StereoF2F_PnP_Track();
     bool TrackOnGpu();
     void Readparameter();
-    bool EnsureContext(int width, int height);
+    bool EnsureContext(int width, int height, int max_batch = 1);
 
     TrackingStatus status_ = TrackingStatus::INITING;
     Frame::Ptr current_frame_ = nullptr, last_frame_ = nullptr;
@@ -50,7 +58,7 @@ private:
     double Px_ = 0, Py_ = 0, Pz_ = 0;
 
     svo_ctx *ctx_ = nullptr;
-    int ctx_w_ = 0, ctx_h_ = 0;
+    int ctx_w_ = 0, ctx_h_ = 0, ctx_batch_ = 0;
     svo_step_result last_;
     bool fill_features_ = false;
 

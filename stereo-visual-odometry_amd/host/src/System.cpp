@@ -1,8 +1,10 @@
 // System.cpp -- facade + KITTI dataset reader (reference src/System.cpp).  The reference's dead
 // 0.5x resize (:93-97) is dropped; PNG decode replaces cv::imread.
 #include "lzb_vio/System.h"
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
+#include <thread>
 #include <zlib.h>
 
 namespace lzb_vio {
@@ -136,13 +138,24 @@ bool System::SetPoseFile(const std::string &path)
 
 void System::WritePose()
 {
-    if (!pose_file_) return;
     Pose4x4 P = tracking_->GetPose();
-    for (int i = 0; i < 12; i++) fprintf(pose_file_, "%.9e%c", P.m[i], i == 11 ? '\n' : ' ');
+    WritePoseRow(P.m);
+}
+
+void System::WritePoseRow(const double *pose16)
+{
+    if (!pose_file_) return;
+    for (int i = 0; i < 12; i++) fprintf(pose_file_, "%.9e%c", pose16[i], i == 11 ? '\n' : ' ');
 }
 
 void System::Run()
 {
+    const int batch = Config::Has("batch_size") ? Config::Get<int>("batch_size") : 1;
+    if (batch > 1) {
+        RunBatched(batch, Config::Has("decode_threads") ? Config::Get<int>("decode_threads") : 8);
+        Shutdown();
+        return;
+    }
     while (1) {
         if (Step() == false) break;
     }
@@ -170,27 +183,120 @@ bool System::Step_ros(Frame::Ptr new_frame)
     return success;
 }
 
-Frame::Ptr System::NextFrame_kitti()
+// <dataset_path>/image_0/%06d.png + image_1/%06d.png (src/System.cpp:77-85); .pgm accepted too
+bool System::ReadStereo(int index, cv::Mat &left, cv::Mat &right)
 {
     char name[32];
-    cv::Mat image_left, image_right;
     const char *ext[2] = {"png", "pgm"};
     for (int cam = 0; cam < 2; cam++) {
         bool ok = false;
         for (int e = 0; e < 2 && !ok; e++) {
-            snprintf(name, sizeof(name), "/image_%d/%06d.%s", cam, current_image_index_, ext[e]);
-            ok = ReadImageGray(dataset_path_ + name, cam == 0 ? image_left : image_right);
+            snprintf(name, sizeof(name), "/image_%d/%06d.%s", cam, index, ext[e]);
+            ok = ReadImageGray(dataset_path_ + name, cam == 0 ? left : right);
         }
-        if (!ok) {
-            LZB_LOG("WARNING", "cannot find images at index %d", current_image_index_);
-            return nullptr;
-        }
+        if (!ok) return false;
+    }
+    return true;
+}
+
+Frame::Ptr System::NextFrame_kitti()
+{
+    cv::Mat image_left, image_right;
+    if (!ReadStereo(current_image_index_, image_left, image_right)) {
+        LZB_LOG("WARNING", "cannot find images at index %d", current_image_index_);
+        return nullptr;
     }
     auto new_frame = Frame::CreateFrame();
     new_frame->left_img_ = image_left;
     new_frame->right_img_ = image_right;
     current_image_index_++;
     return new_frame;
+}
+
+// ---- batched runner ------------------------------------------------------------------------------
+// Chunk c holds frames [c*B, c*B + B]: B pairs plus a one-frame halo (the last frame of a chunk is
+// the first of the next, copied rather than decoded again).  While the GPU tracks chunk c the
+// decoder threads fill the other page-locked buffer with chunk c+1.
+void System::RunBatched(int B, int decode_threads)
+{
+    cv::Mat l0, r0;
+    if (!ReadStereo(0, l0, r0)) { LZB_LOG("WARNING", "cannot find images at index %d", 0); return; }
+    const int w = l0.cols, h = l0.rows;
+    if (r0.cols != w || r0.rows != h) { LZB_LOG("ERROR", "left/right size mismatch at index %d", 0); return; }
+    if (!tracking_->EnsureBatchContext(w, h, B)) return;
+    svo_ctx *ctx = tracking_->Context();
+    const int pitch = (w + 255) / 256 * 256;                // the library's staging pitch: one copy per camera
+    const size_t fbytes = (size_t)pitch * h;
+    uint8_t *pin[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    for (int k = 0; k < 2; k++)
+        for (int cam = 0; cam < 2; cam++)
+            if (svo_host_alloc(ctx, fbytes * (size_t)(B + 1), (void **)&pin[k][cam]) != SVO_OK) {
+                LZB_LOG("ERROR", "svo_host_alloc: %s", svo_last_error(ctx));
+                return;
+            }
+    const int T = decode_threads < 1 ? 1 : decode_threads;
+    // decodes frames first .. first+count-1 into slots slot0.. of buffer k; returns how many
+    // consecutive frames (from `first`) were read
+    auto decode = [&](int k, int slot0, int first, int count) -> int {
+        std::vector<char> ok((size_t)count, 0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T && t < count; t++)
+            pool.emplace_back([&, t]() {
+                cv::Mat l, r;
+                for (int i = t; i < count; i += T) {
+                    if (!ReadStereo(first + i, l, r) || l.cols != w || l.rows != h || r.cols != w || r.rows != h) continue;
+                    for (int y = 0; y < h; y++) {
+                        memcpy(pin[k][0] + (size_t)(slot0 + i) * fbytes + (size_t)y * pitch, l.ptr(y), (size_t)w);
+                        memcpy(pin[k][1] + (size_t)(slot0 + i) * fbytes + (size_t)y * pitch, r.ptr(y), (size_t)w);
+                    }
+                    ok[(size_t)i] = 1;
+                }
+            });
+        for (auto &th : pool) th.join();
+        int n = 0;
+        while (n < count && ok[(size_t)n]) n++;
+        return n;
+    };
+    auto upload = [&](int k, int n) {
+        int rc = svo_upload_frames(ctx, k, pin[k][0], pin[k][1], pitch, (int64_t)fbytes, n);
+        if (rc != SVO_OK) LZB_LOG("ERROR", "svo_upload_frames: %s", svo_last_error(ctx));
+        return rc == SVO_OK;
+    };
+
+    int k = 0, next = 0;
+    int cur_n = decode(0, 0, 0, B + 1);
+    next = cur_n;
+    current_image_index_ = cur_n > 0 ? 1 : 0;
+    if (cur_n > 0) WritePose();                             // frame 0: StereoInit_f2f, pose = identity
+    std::vector<svo_step_result> recs;
+    bool ok = cur_n >= 2 && upload(0, cur_n);
+    while (ok) {
+        int nn = 0;
+        std::thread bg;
+        if (cur_n == B + 1)                                 // a full chunk: there may be more frames
+            bg = std::thread([&]() {
+                for (int cam = 0; cam < 2; cam++)
+                    memcpy(pin[k ^ 1][cam], pin[k][cam] + (size_t)B * fbytes, fbytes);
+                nn = 1 + decode(k ^ 1, 1, next, B);
+            });
+        recs.clear();
+        auto t1 = std::chrono::steady_clock::now();
+        ok = tracking_->TrackUploaded(k, cur_n, recs);
+        auto t2 = std::chrono::steady_clock::now();
+        if (bg.joinable()) bg.join();
+        if (!ok) break;
+        if (getenv("LZB_VIO_VERBOSE"))
+            LZB_LOG("INFO", "VO cost time: %f seconds for %d pairs", std::chrono::duration<double>(t2 - t1).count(), cur_n - 1);
+        for (const auto &r : recs) { WritePoseRow(r.pose); current_image_index_++; }
+        if (nn < 2) break;
+        next += nn - 1;
+        if (!upload(k ^ 1, nn)) break;
+        k ^= 1;
+        cur_n = nn;
+    }
+    svo_sync(ctx);
+    for (int q = 0; q < 2; q++)
+        for (int cam = 0; cam < 2; cam++) svo_host_free(ctx, pin[q][cam]);
 }
 
 void System::Shutdown() {}

@@ -46,12 +46,13 @@ void Tracking::Readparameter()
 void Tracking::Set_vo(System *slam) { system_ = slam; }
 
 // The HIP context is sized by the first frame (the reference learns the size from cv::imread too).
-bool Tracking::EnsureContext(int width, int height)
+bool Tracking::EnsureContext(int width, int height, int max_batch)
 {
-    if (ctx_ && width == ctx_w_ && height == ctx_h_) return true;
+    if (ctx_ && width == ctx_w_ && height == ctx_h_ && max_batch <= ctx_batch_) return true;
     if (ctx_) { svo_destroy(ctx_); ctx_ = nullptr; }
     svo_config cfg;
     svo_default_config(&cfg, width, height);
+    cfg.max_batch = max_batch;
     cfg.fast_threshold = 20;                                     // hard-coded, src/tracking.cpp:99
     cfg.num_features_tracking = num_features_tracking_;
     cfg.iterations = iterationsCount_;
@@ -80,7 +81,7 @@ bool Tracking::EnsureContext(int width, int height)
         ctx_ = nullptr;
         return false;
     }
-    ctx_w_ = width; ctx_h_ = height;
+    ctx_w_ = width; ctx_h_ = height; ctx_batch_ = max_batch;
     return true;
 }
 
@@ -148,6 +149,25 @@ bool Tracking::TrackOnGpu()
         Px_ = frame_pose_.m[3]; Py_ = frame_pose_.m[7]; Pz_ = frame_pose_.m[11];
     }
     return ok;
+}
+
+// Batched equivalent of n_frames - 1 AddFrame calls on frames already in device buffer `buf`.
+bool Tracking::TrackUploaded(int buf, int n_frames, std::vector<svo_step_result> &out)
+{
+    if (!ctx_ || n_frames < 2) return false;
+    const size_t first = out.size();
+    out.resize(first + (size_t)(n_frames - 1));
+    int rc = svo_track_uploaded(ctx_, buf, n_frames, frame_pose_.m, out.data() + first, SVO_MEM_HOST);
+    if (rc < 0) {
+        LZB_LOG("ERROR", "svo_track_uploaded: %s", svo_last_error(ctx_));
+        out.resize(first);
+        return false;
+    }
+    last_ = out.back();
+    memcpy(frame_pose_.m, last_.pose, sizeof(frame_pose_.m));
+    Px_ = frame_pose_.m[3]; Py_ = frame_pose_.m[7]; Pz_ = frame_pose_.m[11];
+    status_ = TrackingStatus::TRACKING_GOOD;
+    return true;
 }
 
 }  // namespace lzb_vio

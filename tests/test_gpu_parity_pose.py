@@ -273,3 +273,29 @@ def test_failure_stages_parity(pkg, oracle, tc, small_seq):
     assert r["fail_stage"] == 3 and rc == 3
     _check_step(g, r)
     c.close()
+
+
+def test_host_frame_batches_match_track_batch(pkg, oracle, tc, small_seq):
+    """svo_upload_frames + svo_track_uploaded (page-locked host frames, copy stream) == svo_track_batch
+    on HBM-resident frames, for both device buffers and for a padded host pitch."""
+    seq, frames = small_seq
+    h, w = frames[0][0].shape
+    P1, P2 = seq.proj()
+    c = pkg.Context(w, h, device=0, max_batch=8, P1=P1, P2=P2)
+    L = tc.from_numpy(np.stack([f[0] for f in frames])).cuda()
+    R = tc.from_numpy(np.stack([f[1] for f in frames])).cuda()
+    ref = c.track_batch(L, R)
+    for buf, pitch in ((0, (w + 255) // 256 * 256), (1, w + 3)):
+        hl, hr = c.host_frames(len(frames), pitch), c.host_frames(len(frames), pitch)
+        for i, (l, r) in enumerate(frames):
+            hl[i, :, :w] = l
+            hr[i, :, :w] = r
+        c.upload_frames(buf, hl, hr)
+        got = c.track_uploaded(buf, len(frames))
+        c.wait_upload(buf)
+        c.host_free(hl)
+        c.host_free(hr)
+        assert got.tobytes() == ref.tobytes()
+    with pytest.raises(pkg.SvoError):
+        c.track_uploaded(0, len(frames) + 1)
+    c.close()

@@ -155,6 +155,17 @@ def test_run_kitti_stereo_drop_in(host_built, pkg, small_seq, tmp_path):
     assert np.abs(poses - np.array(ref)).max() < 1e-6
     gt = np.linalg.inv(seq.poses_wc()[0].numpy()) @ seq.poses_wc()[len(frames) - 1].numpy()
     assert np.abs(poses[-1][:, 3] - gt[:3, 3]).max() < 0.25
+    # batched runner (additive YAML keys): chunks of 2 pairs with a one-frame halo, threaded decode
+    for bs in (2, 8):
+        with open(tmp_path / "cfg.yaml", encoding="utf-8") as f:
+            txt = f.read()
+        with open(tmp_path / f"batch{bs}.yaml", "w", encoding="utf-8") as f:
+            f.write(txt + f"batch_size: {bs}\ndecode_threads: 3\n")
+        r = subprocess.run([os.path.join(host_built, "run_kitti_stereo"), str(tmp_path / f"batch{bs}.yaml"),
+                            str(tmp_path / f"poses_b{bs}.txt")], capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()
+        poses_b = np.loadtxt(tmp_path / f"poses_b{bs}.txt").reshape(-1, 3, 4)
+        assert poses_b.shape == poses.shape and np.abs(poses_b - poses).max() < 1e-7
     # the shipped default track_mode (ORB_stereof2f_pnp) through the same binary
     _write_yaml(tmp_path / "orb.yaml", str(tmp_path), fx=seq.fx, fy=seq.fy, cx=seq.cx, cy=seq.cy, mode="ORB_stereof2f_pnp")
     r = subprocess.run([os.path.join(host_built, "run_kitti_stereo"), str(tmp_path / "orb.yaml"),
