@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
     __shared__ uint8_t raw[kCellMax * kCellMax];
     __shared__ uint8_t V[kCellMax * kCellMax];
     __shared__ uint8_t keep[kCellMax * kCellMax];
-    __shared__ int s_any, s_found;
+    __shared__ uint16_t list[kCellMax * kCellMax];
+    __shared__ int s_any, s_found, s_nlist;
     const int b = blockIdx.z, cell = blockIdx.x;
     const int W = g.w[l], H = g.h[l], pitch = g.pitch[l];
     const int minBX = 16, minBY = 16, maxBX = W - 16, maxBY = H - 16;
@@ -138,17 +139,45 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
     const int x0 = (int)iniX, y0 = (int)iniY, cw = (int)maxX - x0, ch = (int)maxY - y0;
     if (skip || cw < 7 || ch < 7) { if (tid == 0) *cnt = 0; return; }
     const uint8_t *img = slots + (int64_t)b * slot_stride + g.origin[l];
-    if (tid == 0) { s_any = 0; s_found = 0; }
+    if (tid == 0) { s_any = 0; s_found = 0; s_nlist = 0; }
     for (int i = tid; i < cw * ch; i += 256) {
         int y = i / cw, x = i - y * cw;
         raw[y * kCellMax + x] = img[(int64_t)(y0 + y) * pitch + x0 + x];
     }
     __syncthreads();
+    // Cornerness only matters where it can reach minTh: a corner at threshold t needs one pixel
+    // of each opposite pair (0,8), (4,12) beyond t, so positions failing that 4-pixel test at minTh
+    // keep V = 0, and the full arc min/max runs over a compacted list of the survivors.
+    for (int i = tid; i < (cw * ch + 255) / 256 * 256; i += 256) {
+        bool alive = false;
+        int pos = 0;
+        if (i < cw * ch) {
+            const int y = i / cw, x = i - y * cw;
+            pos = y * kCellMax + x;
+            V[pos] = 0;
+            if (x >= 3 && x < cw - 3 && y >= 3 && y < ch - 3) {
+                const uint8_t *c = &raw[pos];
+                const int v = c[0], t = minTh;
+                const int d0 = v - c[3 * kCellMax], d8 = v - c[-3 * kCellMax], d4 = v - c[3], d12 = v - c[-3];
+                alive = ((d0 > t || d8 > t) && (d4 > t || d12 > t)) || ((d0 < -t || d8 < -t) && (d4 < -t || d12 < -t));
+            }
+        }
+        const unsigned long long m = __ballot(alive);
+        if (m) {
+            const int lane = tid & 63;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_nlist, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (alive) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+        }
+    }
+    __syncthreads();
     int any = 0;
-    for (int i = tid; i < cw * ch; i += 256) {
-        int y = i / cw, x = i - y * cw, v = 0;
-        if (x >= 3 && x < cw - 3 && y >= 3 && y < ch - 3) v = fast_cornerness(&raw[y * kCellMax + x], kCellMax);
-        V[y * kCellMax + x] = (uint8_t)v;
+    const int nlist = s_nlist;
+    for (int i = tid; i < nlist; i += 256) {
+        const int pos = list[i];
+        const int v = fast_cornerness(&raw[pos], kCellMax);
+        V[pos] = (uint8_t)v;
         any |= v >= iniTh;
     }
     if (any) s_any = 1;
@@ -518,30 +547,56 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
 }
 
 // ---- blur (7x7, sigma 2, reflect-101; integer kernel, (sum + 2^15) >> 16, saturated) -------------
-__global__ __launch_bounds__(256) void orb_blur_rows_kernel(OrbGeom g, const uint8_t *slots, int64_t slot_stride, int l,
-                                                            int *tmp, int64_t tmp_img_stride)
+// One pass: a thread owns 4 adjacent columns of a 28-row band.  A row's four 7-tap sums are two
+// v_dot4_u32_u8 each on byte windows cut from three aligned dwords (the level's stored reflect-101
+// frame IS the blur's border); the seven most recent row sums slide through registers for the
+// column pass (28-row band), so neither the int intermediate image nor a second launch exists.
+constexpr int kBlurRows = 28;     // 4 x 7: the row ring rotates with static indices
+__global__ __launch_bounds__(256) void orb_blur_kernel(OrbGeom g, const uint8_t *slots, int64_t slot_stride, int l,
+                                                       uint8_t *blur, int64_t blur_img_stride)
 {
-    const int b = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-    const int w = g.w[l];
-    if (x >= w) return;
-    const uint8_t *row = slots + (int64_t)b * slot_stride + g.origin[l] + (int64_t)y * g.pitch[l];
-    int s = 0;
+    const int b = blockIdx.z;
+    const int w = g.w[l], h = g.h[l], pitch = g.pitch[l];
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y0 = (blockIdx.y * 4 + threadIdx.y) * kBlurRows;
+    if (x0 >= w || y0 >= h) return;
+    const uint8_t *src = slots + (int64_t)b * slot_stride + g.origin[l] + x0 - 4;
+    uint8_t *dst = blur + (int64_t)b * blur_img_stride + g.blur_off[l] + x0;
+    const uint32_t k0123 = (uint32_t)g.gk[0] | ((uint32_t)g.gk[1] << 8) | ((uint32_t)g.gk[2] << 16) | ((uint32_t)g.gk[3] << 24);
+    const uint32_t k456 = (uint32_t)g.gk[4] | ((uint32_t)g.gk[5] << 8) | ((uint32_t)g.gk[6] << 16);
+    auto rowsum = [&](int yy, uint32_t (&out)[4]) {
+        const uint32_t *p = (const uint32_t *)(src + (int64_t)yy * pitch);
+        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];             // columns x0-4 .. x0+7
 #pragma unroll
-    for (int i = 0; i < 7; i++) s += g.gk[i] * row[refl101(x + i - 3, w)];
-    tmp[(int64_t)b * tmp_img_stride + g.blur_off[l] + (int64_t)y * w + x] = s;
-}
-__global__ __launch_bounds__(256) void orb_blur_cols_kernel(OrbGeom g, const int *tmp, int64_t tmp_img_stride, int l,
-                                                            uint8_t *blur, int64_t blur_img_stride)
-{
-    const int b = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-    const int w = g.w[l], h = g.h[l];
-    if (x >= w) return;
-    const int *t = tmp + (int64_t)b * tmp_img_stride + g.blur_off[l];
-    int s = 0;
+        for (int o = 0; o < 4; o++) {                               // taps of column x0+o: bytes o+1 .. o+7
+            const uint32_t lo = o == 3 ? d1 : __builtin_amdgcn_alignbyte(d1, d0, o + 1);
+            const uint32_t hi = o == 3 ? d2 : __builtin_amdgcn_alignbyte(d2, d1, o + 1);
+            out[o] = __builtin_amdgcn_udot4(lo, k0123, __builtin_amdgcn_udot4(hi, k456, 0u, false), false);
+        }
+    };
+    // ring of the seven most recent row sums: row y0-3+i lives in win[i % 7] (static indices: the
+    // band is walked in fully unrolled groups of seven rows)
+    uint32_t win[7][4];
 #pragma unroll
-    for (int i = 0; i < 7; i++) s += g.gk[i] * t[(int64_t)refl101(y + i - 3, h) * w + x];
-    s = (s + (1 << 15)) >> 16;
-    blur[(int64_t)b * blur_img_stride + g.blur_off[l] + (int64_t)y * w + x] = (uint8_t)(s > 255 ? 255 : s);
+    for (int r = 0; r < 6; r++) rowsum(y0 - 3 + r, win[r]);
+    const int rows = min(kBlurRows, h - y0);
+    for (int k = 0; k < kBlurRows / 7; k++) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const int yy = 7 * k + j;
+            if (yy >= rows) return;
+            rowsum(y0 + yy + 3, win[(j + 6) % 7]);              // row index yy + 6 in the ring
+            uint8_t *q = dst + (int64_t)(y0 + yy) * w;
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                uint32_t v = 1u << 15;
+#pragma unroll
+                for (int r = 0; r < 7; r++) v += win[(j + r) % 7][o] * (uint32_t)g.gk[r];
+                v >>= 16;
+                if (x0 + o < w) q[o] = (uint8_t)(v > 255u ? 255u : v);
+            }
+        }
+    }
 }
 
 // ---- orientation + descriptor + final keypoint record -------------------------------------------
@@ -806,7 +861,6 @@ int orb_alloc(svo_ctx *ctx)
     SVO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), svo_bit_pattern_31, 1024));
     SVO_HIP(hipMalloc(&ctx->orb_slots, (size_t)g.slot_bytes * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_blur, (size_t)g.blur_total * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_tmp, sizeof(int) * (size_t)g.blur_total * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_cell_cand, sizeof(float4) * (size_t)g.cells_total * kCellCap * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_cell_cnt, sizeof(int) * (size_t)g.cells_total * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_lvl_cand, sizeof(float4) * (size_t)kCandCap * L * n_img));
@@ -833,7 +887,7 @@ int orb_alloc(svo_ctx *ctx)
 void orb_free(svo_ctx *c)
 {
     auto F = [](void *p) { if (p) (void)hipFree(p); };
-    F(c->orb_slots); F(c->orb_blur); F(c->orb_tmp); F(c->orb_cell_cand); F(c->orb_cell_cnt); F(c->orb_lvl_cand);
+    F(c->orb_slots); F(c->orb_blur); F(c->orb_cell_cand); F(c->orb_cell_cnt); F(c->orb_lvl_cand);
     F(c->orb_lvl_cnt); F(c->orb_qkeys); F(c->orb_qtmp);
     F(c->orb_sel); F(c->orb_sel_cnt); F(c->orb_overflow); F(c->orb_kps); F(c->orb_desc); F(c->orb_n);
     for (int k = 0; k < 2; k++) { F(c->orb_midx[k]); F(c->orb_mdist[k]); }
@@ -880,14 +934,10 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     d.sel = ctx->orb_sel + (size_t)slot0 * L * kSelCap; d.sel_cnt = ctx->orb_sel_cnt + (size_t)slot0 * L; d.sel_cap = kSelCap;
     d.overflow = ctx->orb_overflow;
     hipLaunchKernelGGL(orb_distribute_kernel, dim3(L, n_img), dim3(64), 0, st, d);
-    int *tmp = ctx->orb_tmp + (size_t)slot0 * g.blur_total;
     uint8_t *blur = ctx->orb_blur + (size_t)slot0 * g.blur_total;
-    for (int l = 0; l < L; l++) {
-        hipLaunchKernelGGL(orb_blur_rows_kernel, dim3((g.w[l] + 255) / 256, g.h[l], n_img), blk, 0, st, g, slots, g.slot_bytes, l,
-                           tmp, g.blur_total);
-        hipLaunchKernelGGL(orb_blur_cols_kernel, dim3((g.w[l] + 255) / 256, g.h[l], n_img), blk, 0, st, g, tmp, g.blur_total, l,
-                           blur, g.blur_total);
-    }
+    for (int l = 0; l < L; l++)
+        hipLaunchKernelGGL(orb_blur_kernel, dim3((g.w[l] + 255) / 256, (g.h[l] + 4 * kBlurRows - 1) / (4 * kBlurRows), n_img),
+                           dim3(64, 4), 0, st, g, slots, g.slot_bytes, l, blur, g.blur_total);
     OrbDescArgs e{};
     e.g = g; e.slots = slots; e.slot_stride = g.slot_bytes; e.blur = blur; e.blur_img_stride = g.blur_total;
     e.lvl_cand = lvl_cand; e.cand_cap = kCandCap; e.sel = d.sel; e.sel_cnt = d.sel_cnt; e.sel_cap = kSelCap;

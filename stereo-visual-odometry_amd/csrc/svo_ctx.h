@@ -46,7 +46,7 @@ struct svo_ctx {
     // ---- ORB path (allocated on first use: orb_alloc)
     bool orb_ready = false;
     svo::OrbGeom orb_geom;
-    uint8_t *orb_slots = nullptr, *orb_blur = nullptr; int *orb_tmp = nullptr;
+    uint8_t *orb_slots = nullptr, *orb_blur = nullptr;
     float4 *orb_cell_cand = nullptr; int *orb_cell_cnt = nullptr;
     float4 *orb_lvl_cand = nullptr; int *orb_lvl_cnt = nullptr;
     void *orb_qkeys = nullptr, *orb_qtmp = nullptr;      // quadtree key scratch (inputs larger than its LDS)
