@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--mode", choices=["lk", "orb"], default="lk",
                     help="lk = BASELINE config #2 (FAST+LK, the quoted metric); orb = config #3 (ORB extractor + "
                          "descriptor match path, the reference's shipped default track_mode)")
+    ap.add_argument("--shard", choices=["sequences", "pairs"], default="sequences",
+                    help="N > 1: one independent sequence per GPU (default, BASELINE config #5), or ONE sequence cut "
+                         "into contiguous chunks of frame pairs with a one-frame halo, relative motions gathered "
+                         "and chained on rank 0 (SURVEY.md 8e granularity 2)")
     ap.add_argument("--frames-cache", default="", help="torch file to load/save the rendered S0 frames "
                     "(keeps profiler traces free of the renderer's torch kernels)")
     return ap.parse_args()
@@ -75,8 +79,10 @@ def main():
     F = B + 1
     dev = torch.device("cuda", local_rank)
     # ---- synthetic S0 frames, resident in HBM before the timed region -----------------------
-    seed = mg.sequence_seed(rank, world)
-    seq = synth.StereoSequence(width=W, height=H, n_frames=F, seed=seed, device=dev)
+    by_pairs = args.shard == "pairs"
+    seed = mg.sequence_seed(0, 1) if by_pairs else mg.sequence_seed(rank, world)
+    first_frame = mg.shard_pairs(world * B + 1, world, rank)[0] if by_pairs else 0
+    seq = synth.StereoSequence(width=W, height=H, n_frames=first_frame + F, seed=seed, device=dev)
     cache = args.frames_cache if world == 1 else ""
     if cache and os.path.exists(cache):
         blob = torch.load(cache)
@@ -86,7 +92,7 @@ def main():
         L = torch.zeros((F, H, PITCH), dtype=torch.uint8, device=dev)
         R = torch.zeros((F, H, PITCH), dtype=torch.uint8, device=dev)
         for f in range(F):
-            l, r = seq.render(f)
+            l, r = seq.render(first_frame + f)
             L[f, :, :W] = l
             R[f, :, :W] = r
         if cache:
@@ -102,10 +108,16 @@ def main():
     ctx.set_overlap(not args.no_overlap)          # pose stage of step k runs beside the front end of step k+1
     results = torch.zeros((B, pkg.STEP_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     pose_off = pkg.STEP_DTYPE.fields["pose"][1]
+    trel_off, ok_off = pkg.STEP_DTYPE.fields["T_rel_inv"][1], pkg.STEP_DTYPE.fields["ok"][1]
 
     def step():
         ctx.track_batch(Lv, Rv, results=results)
-        if world > 1:      # the only inter-GPU traffic: 16 doubles per pair to rank 0 (RCCL gather)
+        if by_pairs:       # chunks of ONE sequence: gather 17 doubles per pair, chain on rank 0
+            ctx.wait_results()
+            g = mg.gather_relative(mg.field_view(results, trel_off, B, 16), mg.int_field(results, ok_off, B), rank, world, dst=0)
+            if rank == 0:
+                ctx.chain_relative(g[0], g[1])
+        elif world > 1:    # the only inter-GPU traffic: 16 doubles per pair to rank 0 (RCCL gather)
             ctx.wait_results()
             mg.gather_poses(mg.poses_view(results, pose_off, B), rank, world, dst=0)
 
@@ -151,7 +163,9 @@ def main():
                         "descriptor match path track_mode ORB_stereof2f_pnp, batched frame pairs, frames resident in HBM"),
                        "pairs_per_step_per_gpu": B, "mean_keypoints_per_pair": round(pts_total / B, 1),
                        "pairs_ok_last_step": n_ok, "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
-                       "parallelism": f"sequence-per-GPU x{world}, RCCL gather of poses only" if world > 1 else "1 GPU"},
+                       "parallelism": ((f"one sequence in {world} chunks of frame pairs (1-frame halo), RCCL gather of "
+                                        f"relative motions, prefix product on rank 0") if by_pairs else
+                                       (f"sequence-per-GPU x{world}, RCCL gather of poses only" if world > 1 else "1 GPU"))},
         }
         lk_ms = stage_ms.get("lk")
         if lk_ms:

@@ -210,6 +210,15 @@ int svo_wait_upload(svo_ctx *ctx, int buf);
 int svo_track_uploaded(svo_ctx *ctx, int buf, int n_frames, const double *pose0,
                        svo_step_result *results, int results_mem);
 
+/* Serial prefix product of n inverse relative motions (svo_step_result.T_rel_inv, row-major 4x4),
+ * skipping pairs with ok == 0:  poses_out[p] = pose0 * prod_{q <= p, ok[q]} T[q]  -- the
+ * `frame_pose_ = frame_pose_ * T.inv()` recurrence of reference src/tracking.cpp:318 for frame
+ * pairs that were tracked as independent chunks (other launches, contexts or GPUs: SURVEY.md 8e
+ * granularity 2).  pose0 is a HOST pointer (NULL = identity); T_rel_inv, ok and poses_out live where
+ * `mem` says.  The call returns when poses_out is complete. */
+int svo_chain_relative(svo_ctx *ctx, const double *T_rel_inv, const int32_t *ok, int n,
+                       const double *pose0, double *poses_out, int mem);
+
 /* Kernel-level timing of the last svo_track_batch / svo_add_frame, measured with HIP events on
  * the context's stream: fills up to `cap` (name, milliseconds) pairs, returns the count.
  * Enabled by svo_enable_timing(ctx, 1); adds event records between stages. */

@@ -87,6 +87,7 @@ def load_library():
     lib.svo_default_config.restype = None
     lib.svo_track_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_int]
+    lib.svo_chain_relative.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     lib.svo_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
     lib.svo_host_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.svo_upload_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]
@@ -403,4 +404,26 @@ class Context:
             p0 = C.c_void_p(pose0.ctypes.data)
         out = np.zeros(int(n_frames) - 1, dtype=STEP_DTYPE)
         self._check(self.lib.svo_track_uploaded(self.h, int(buf), int(n_frames), p0, C.c_void_p(out.ctypes.data), MEM_HOST))
+        return out
+
+    def chain_relative(self, T_rel_inv, ok, pose0=None):
+        """poses[p] = pose0 * prod_{q<=p, ok[q]} T[q] (svo_chain_relative).  numpy arrays or torch cuda
+        tensors: T (n, 16) float64, ok (n,) int32.  Returns (n, 16) of the same kind."""
+        p0 = None
+        if pose0 is not None:
+            pose0 = np.ascontiguousarray(pose0, np.float64).reshape(16)
+            p0 = C.c_void_p(pose0.ctypes.data)
+        if isinstance(T_rel_inv, np.ndarray):
+            T = np.ascontiguousarray(T_rel_inv, np.float64).reshape(-1, 16)
+            okc = np.ascontiguousarray(ok, np.int32)
+            out = np.zeros_like(T)
+            tp, op_, up, mem = C.c_void_p(T.ctypes.data), C.c_void_p(okc.ctypes.data), C.c_void_p(out.ctypes.data), MEM_HOST
+        else:
+            import torch
+            T = T_rel_inv.reshape(-1, 16).contiguous()
+            okc = ok.to(torch.int32).contiguous()
+            assert T.is_cuda and okc.is_cuda and T.dtype == torch.float64
+            out = torch.zeros_like(T)
+            tp, op_, up, mem = C.c_void_p(T.data_ptr()), C.c_void_p(okc.data_ptr()), C.c_void_p(out.data_ptr()), MEM_DEVICE
+        self._check(self.lib.svo_chain_relative(self.h, tp, op_, int(T.shape[0]), p0, up, mem))
         return out

@@ -382,6 +382,73 @@ __global__ void chain_kernel(svo_step_result *res, int n_pairs, const double *po
     }
 }
 
+// The same product for relative motions gathered from independently tracked chunks (other
+// launches, contexts or GPUs): lanes (i, j) of one wave hold P[i][j]; row elements travel by quad
+// broadcast, the T matrices are staged through LDS 64 pairs at a time.  Same association order
+// as chain_kernel (k ascending, separate multiply and add).
+template <int K>
+__device__ __forceinline__ double quad_bcast_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), K * 0x55, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), K * 0x55, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void chain_relative_kernel(const double *T, const int *ok, int n, const double *pose0,
+                                                            double *out)
+{
+    __shared__ double sT[64 * 16];
+    __shared__ int sOk[64];
+    const int lane = threadIdx.x, i = (lane >> 2) & 3, j = lane & 3;
+    double P = pose0[i * 4 + j];
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = min(64, n - base);
+        __syncthreads();
+        for (int e = lane; e < cnt * 16; e += 64) sT[e] = T[(int64_t)base * 16 + e];
+        if (lane < cnt) sOk[lane] = ok[base + lane];
+        __syncthreads();
+        for (int p = 0; p < cnt; p++) {
+            const double p0 = quad_bcast_f64<0>(P), p1 = quad_bcast_f64<1>(P), p2 = quad_bcast_f64<2>(P), p3 = quad_bcast_f64<3>(P);
+            if (sOk[p]) {
+                const double *t = sT + p * 16 + j;
+                double s = 0;
+                s += p0 * t[0]; s += p1 * t[4]; s += p2 * t[8]; s += p3 * t[12];
+                P = s;
+            }
+            if (lane < 16) out[(int64_t)(base + p) * 16 + lane] = P;
+        }
+    }
+}
+
+int stage_chain_relative(svo_ctx *ctx, const double *T, const int32_t *ok, int n, const double *pose0_host, double *out,
+                         int mem)
+{
+    SVO_ARG(T && ok && out && n >= 0, "null pointer / negative count");
+    SVO_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE, "bad mem");
+    if (n == 0) return SVO_OK;
+    double p0[16];
+    for (int q = 0; q < 16; q++) p0[q] = pose0_host ? pose0_host[q] : (q % 5 == 0 ? 1.0 : 0.0);
+    double *d_p0 = nullptr, *dT = nullptr, *dOut = nullptr;
+    int *dOk = nullptr;
+    SVO_HIP(hipMalloc(&d_p0, sizeof(p0)));
+    SVO_HIP(hipMemcpyAsync(d_p0, p0, sizeof(p0), hipMemcpyHostToDevice, ctx->stream));
+    if (mem == SVO_MEM_HOST) {
+        SVO_HIP(hipMalloc(&dT, sizeof(double) * 16 * (size_t)n));
+        SVO_HIP(hipMalloc(&dOut, sizeof(double) * 16 * (size_t)n));
+        SVO_HIP(hipMalloc(&dOk, sizeof(int) * (size_t)n));
+        SVO_HIP(hipMemcpyAsync(dT, T, sizeof(double) * 16 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        SVO_HIP(hipMemcpyAsync(dOk, ok, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    hipLaunchKernelGGL(chain_relative_kernel, dim3(1), dim3(64), 0, ctx->stream, mem == SVO_MEM_HOST ? dT : T,
+                       mem == SVO_MEM_HOST ? dOk : (const int *)ok, n, d_p0, mem == SVO_MEM_HOST ? dOut : out);
+    SVO_HIP(hipGetLastError());
+    if (mem == SVO_MEM_HOST)
+        SVO_HIP(hipMemcpyAsync(out, dOut, sizeof(double) * 16 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));       // p0 (stack) and the temporaries are released below
+    (void)hipFree(d_p0); (void)hipFree(dT); (void)hipFree(dOut); (void)hipFree(dOk);
+    return SVO_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // workspace layout inside ctx->pnp_ws: [PnpRecord x items][mask bytes x items*cap][pose0 16 doubles]
 static size_t ws_off_mask(int n_items) { return ((sizeof(PnpRecord) * (size_t)n_items) + 255) / 256 * 256; }

@@ -714,3 +714,11 @@ extern "C" int svo_track_uploaded(svo_ctx *ctx, int buf, int n_frames, const dou
     ctx->fb_used[buf] = true;
     return rc;
 }
+
+extern "C" int svo_chain_relative(svo_ctx *ctx, const double *T_rel_inv, const int32_t *ok, int n, const double *pose0,
+                                  double *poses_out, int mem)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_HIP(hipSetDevice(ctx->device));
+    return stage_chain_relative(ctx, T_rel_inv, ok, n, pose0, poses_out, mem);
+}

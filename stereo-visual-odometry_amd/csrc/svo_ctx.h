@@ -102,6 +102,7 @@ void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n
 // orb.hip
 int orb_alloc(svo_ctx *ctx);
 void orb_free(svo_ctx *ctx);
+int stage_chain_relative(svo_ctx *ctx, const double *T, const int32_t *ok, int n, const double *pose0_host, double *out, int mem);
 int stage_host_image(svo_ctx *ctx, const uint8_t *img, int pitch, int stage_idx, const uint8_t **dptr, int *dpitch);
 int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int pitch, int64_t img_stride, int slot0,
                       int n_img, hipStream_t st);

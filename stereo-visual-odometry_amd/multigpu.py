@@ -20,6 +20,56 @@ def shard_sequences(n_sequences, world, rank):
     return [s for s in range(n_sequences) if s % world == rank]
 
 
+def shard_pairs(n_frames, world, rank):
+    """Frame-pair-granular sharding of ONE sequence (SURVEY.md 8e granularity 2 / 8f rank 1): the
+    n_frames - 1 consecutive pairs are cut into `world` contiguous chunks, chunk c -> rank c, with
+    a one-frame halo (a chunk needs the frame before its first pair).  Returns (first_frame,
+    n_chunk_frames): the rank tracks frames first_frame .. first_frame + n_chunk_frames - 1."""
+    n_pairs = n_frames - 1
+    base, extra = divmod(n_pairs, world)
+    first = rank * base + min(rank, extra)
+    mine = base + (1 if rank < extra else 0)
+    return first, (mine + 1 if mine > 0 else 0)
+
+
+def chain_relative(T_rel_inv, ok, pose0=None):
+    """Prefix product of per-pair inverse relative motions, skipping failed pairs -- the serial part
+    of Tracking's `frame_pose_ = frame_pose_ * T.inv()` (reference src/tracking.cpp:318) done once
+    for chunks that were tracked independently.  T_rel_inv: (n, 16) or (n, 4, 4) float64, ok: (n,)
+    integer flags.  Returns (n, 4, 4): the pose after each pair (same association order as the
+    reference: left to right)."""
+    T = T_rel_inv.reshape(-1, 4, 4).to(torch.float64)
+    P = torch.eye(4, dtype=torch.float64, device=T.device) if pose0 is None else pose0.reshape(4, 4).to(T)
+    out = torch.empty_like(T)
+    for i in range(T.shape[0]):
+        if int(ok[i]):
+            P = P @ T[i]
+        out[i] = P
+    return out
+
+
+def gather_relative(T_rel_inv, ok, rank, world, dst=0):
+    """Gathers every rank's (n, 16) relative motions + (n,) ok flags to dst as ONE (n, 17) float64
+    message per rank (chunks padded to the longest), returns (T (N, 16), ok (N,)) in sequence order
+    on dst, None elsewhere.  `lengths` need not match across ranks."""
+    n = torch.tensor([T_rel_inv.shape[0]], dtype=torch.int64, device=T_rel_inv.device)
+    if world == 1:
+        return T_rel_inv.reshape(-1, 16), ok
+    lens = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(lens, n)
+    nmax = int(max(int(x.item()) for x in lens))
+    msg = torch.zeros((nmax, 17), dtype=torch.float64, device=T_rel_inv.device)
+    msg[:T_rel_inv.shape[0], :16] = T_rel_inv.reshape(-1, 16)
+    msg[:T_rel_inv.shape[0], 16] = ok.to(torch.float64)
+    buf = [torch.empty_like(msg) for _ in range(world)] if rank == dst else None
+    dist.gather(msg, buf, dst=dst)
+    if rank != dst:
+        return None
+    parts = [buf[r][:int(lens[r].item())] for r in range(world)]
+    allm = torch.cat(parts, 0)
+    return allm[:, :16].contiguous(), allm[:, 16].to(torch.int64)
+
+
 def gather_poses(poses, rank, world, dst=0):
     """poses: (n, 16) float64 tensor of this rank.  Returns the list of all ranks' tensors on dst,
     None elsewhere.  One gather per call; with world == 1 it is the identity."""
@@ -37,6 +87,16 @@ def max_over_ranks(seconds, device, world):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def field_view(results_u8, offset, n, n_doubles):
+    """(n, n_doubles) float64 copy of a double field of n packed svo_step_result records."""
+    return results_u8[:n, offset:offset + 8 * n_doubles].contiguous().view(torch.float64).view(n, n_doubles)
+
+
+def int_field(results_u8, offset, n):
+    """(n,) int32 copy of an int field of n packed svo_step_result records."""
+    return results_u8[:n, offset:offset + 4].contiguous().view(torch.int32).view(n)
 
 
 def poses_view(results_u8, pose_offset, n):

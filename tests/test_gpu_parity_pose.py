@@ -299,3 +299,43 @@ def test_host_frame_batches_match_track_batch(pkg, oracle, tc, small_seq):
     with pytest.raises(pkg.SvoError):
         c.track_uploaded(0, len(frames) + 1)
     c.close()
+
+
+def test_pair_sharding_chains_to_the_whole_sequence(pkg, tc, small_seq):
+    """Chunks of frame pairs tracked independently (one-frame halo) + svo_chain_relative over the
+    gathered relative motions == the whole sequence tracked in one batch."""
+    import importlib
+    import conftest
+    mg = importlib.import_module(conftest.entry.PKG_NAME + ".multigpu")
+    seq, frames = small_seq
+    h, w = frames[0][0].shape
+    P1, P2 = seq.proj()
+    c = pkg.Context(w, h, device=0, max_batch=8, P1=P1, P2=P2)
+    L = tc.from_numpy(np.stack([f[0] for f in frames])).cuda()
+    R = tc.from_numpy(np.stack([f[1] for f in frames])).cuda()
+    whole = c.track_batch(L, R)
+    for world in (2, 3):
+        Ts, oks = [], []
+        for rank in range(world):
+            first, nf = mg.shard_pairs(len(frames), world, rank)
+            if nf < 2:
+                continue
+            r = c.track_batch(L[first:first + nf], R[first:first + nf])
+            Ts.append(r["T_rel_inv"])
+            oks.append(r["ok"])
+        T, ok = np.concatenate(Ts), np.concatenate(oks).astype(np.int32)
+        assert T.tobytes() == whole["T_rel_inv"].tobytes() and np.array_equal(ok, whole["ok"])
+        got = c.chain_relative(T, ok)
+        assert got.tobytes() == whole["pose"].reshape(-1, 16).tobytes()          # same association order
+        got_d = c.chain_relative(tc.from_numpy(T).cuda(), tc.from_numpy(ok).cuda())
+        assert got_d.cpu().numpy().tobytes() == got.tobytes()
+        ref = mg.chain_relative(tc.from_numpy(T), tc.from_numpy(ok)).numpy().reshape(-1, 16)
+        assert np.abs(ref - got).max() < 1e-12
+    # failed pairs are skipped, pose0 seeds the chain
+    ok2 = np.array([1, 0, 1], np.int32)
+    p0 = np.eye(4); p0[0, 3] = 5.0
+    got = c.chain_relative(whole["T_rel_inv"], ok2, pose0=p0).reshape(-1, 4, 4)
+    ref = p0 @ whole["T_rel_inv"][0].reshape(4, 4)
+    assert np.abs(got[0] - ref).max() < 1e-12 and np.array_equal(got[1], got[0])
+    assert np.abs(got[2] - ref @ whole["T_rel_inv"][2].reshape(4, 4)).max() < 1e-12
+    c.close()

@@ -46,6 +46,35 @@ def _worker(rank, world, port, out_dir):
             ok = ok and np.array_equal(got[r].numpy(), exp)
     else:
         ok = ok and got is None
+    # frame-pair-granular sharding of one sequence: chunk c -> rank c, relative motions gathered and
+    # chained on rank 0 == the serial prefix product over the whole sequence
+    n_frames = 12
+    rng = np.random.default_rng(5)
+    Tall = np.tile(np.eye(4), (n_frames - 1, 1, 1))
+    for i in range(n_frames - 1):
+        a = rng.normal(size=3) * 0.05
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        Tall[i, :3, :3] = np.eye(3) + K + K @ K / 2
+        Tall[i, :3, 3] = rng.normal(size=3)
+    okall = np.ones(n_frames - 1, np.int32)
+    okall[[3, 7]] = 0
+    first, nf = mg.shard_pairs(n_frames, world, rank)
+    Tm = torch.from_numpy(Tall[first:first + nf - 1].reshape(-1, 16).copy())
+    okm = torch.from_numpy(okall[first:first + nf - 1].copy())
+    g = mg.gather_relative(Tm, okm, rank, world, dst=0)
+    if rank == 0:
+        chained = mg.chain_relative(g[0], g[1]).numpy()
+        P, ref = np.eye(4), []
+        for i in range(n_frames - 1):
+            if okall[i]:
+                P = P @ Tall[i]
+            ref.append(P.copy())
+        ok = ok and chained.shape == (n_frames - 1, 4, 4) and np.array_equal(chained, np.array(ref))
+        ok = ok and np.array_equal(g[1].numpy(), okall)
+    else:
+        ok = ok and g is None
+    ok = ok and mg.shard_pairs(10, 3, 0) == (0, 4) and mg.shard_pairs(10, 3, 1) == (3, 4) and mg.shard_pairs(10, 3, 2) == (6, 4)
+    ok = ok and mg.shard_pairs(3, 4, 3) == (2, 0)
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
         f.write(f"{int(ok)} {mg.sequence_seed(rank, world)} {','.join(map(str, mine))}")
     dist.barrier()
