@@ -41,6 +41,9 @@ extern "C" {
 #define SVO_FAIL_INLIER_RATIO  3   /* src/tracking.cpp:491  (inliers / tracked < rate)     */
 #define SVO_FAIL_ROTATION_GATE 4   /* src/tracking.cpp:308  (|euler| >= 0.1 rad)           */
 #define SVO_FAIL_TRANSL_GATE   5   /* src/tracking.cpp:311  (|t|^2 outside the window)     */
+#define SVO_FAIL_CAPACITY      6   /* not a reference exit: a frame of the pair had more keypoints
+                                      than svo_config.max_keypoints (cv::FAST is uncapped); the
+                                      pair is reported failed instead of tracking a truncated set */
 
 #define SVO_MEM_HOST   0
 #define SVO_MEM_DEVICE 1

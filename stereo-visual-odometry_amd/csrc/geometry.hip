@@ -298,6 +298,7 @@ struct FinalizeArgs {
     const PnpRecord *pnp; const int *n_prev, *n_cur, *n_tracked;   // per pair
     int n_pairs;
     int mode;                      // SVO_MODE_LK checks "< 30 FAST corners" first (src/tracking.cpp:261)
+    int cap;                       // max_keypoints: a frame with more corners was truncated -> SVO_FAIL_CAPACITY
     int num_features_tracking; double inlier_rate, min_move2, max_move2;
     svo_step_result *res;
 };
@@ -314,7 +315,8 @@ __global__ void finalize_kernel(FinalizeArgs a)
     for (int i = 0; i < 9; i++) r.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
     for (int i = 0; i < 16; i++) { r.T_rel_inv[i] = (i % 5 == 0) ? 1.0 : 0.0; r.pose[i] = 0; }
     int fail = 0;
-    if (a.mode == SVO_MODE_LK && r.n_cur_kps < 30) fail = SVO_FAIL_FEW_KEYPOINTS;     // src/tracking.cpp:261
+    if (r.n_prev_kps > a.cap || r.n_cur_kps > a.cap) fail = SVO_FAIL_CAPACITY;         // never silently track a truncated set
+    else if (a.mode == SVO_MODE_LK && r.n_cur_kps < 30) fail = SVO_FAIL_FEW_KEYPOINTS;     // src/tracking.cpp:261
     else {
         const int m = a.n_tracked[p];
         r.n_tracked = m;
@@ -494,6 +496,7 @@ void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const i
 {
     FinalizeArgs f{};
     f.pnp = (const PnpRecord *)ctx->pnp_ws; f.n_prev = n_prev; f.n_cur = n_cur; f.n_tracked = ctx->m_out;
+    f.cap = ctx->cfg.max_keypoints;
     f.n_pairs = n_pairs; f.mode = ctx->cfg.track_mode; f.num_features_tracking = ctx->cfg.num_features_tracking;
     f.inlier_rate = ctx->cfg.inlier_rate; f.min_move2 = ctx->cfg.min_move2; f.max_move2 = ctx->cfg.max_move2;
     f.res = ctx->d_results;

@@ -339,3 +339,17 @@ def test_pair_sharding_chains_to_the_whole_sequence(pkg, tc, small_seq):
     assert np.abs(got[0] - ref).max() < 1e-12 and np.array_equal(got[1], got[0])
     assert np.abs(got[2] - ref @ whole["T_rel_inv"][2].reshape(4, 4)).max() < 1e-12
     c.close()
+
+
+def test_capacity_overflow_fails_the_pair_loudly(pkg, tc, small_seq):
+    """cv::FAST is uncapped; a frame with more corners than max_keypoints must not be tracked as a
+    truncated set: the pair reports SVO_FAIL_CAPACITY (6), ok = 0, and the pose chain skips it."""
+    seq, frames = small_seq
+    h, w = frames[0][0].shape
+    P1, P2 = seq.proj()
+    c = pkg.Context(w, h, device=0, max_keypoints=64, P1=P1, P2=P2)
+    c.add_frame(*frames[0])
+    rc, r = c.add_frame(*frames[1])
+    assert rc == 6 and int(r["ok"]) == 0 and int(r["fail_stage"]) == 6 and int(r["n_prev_kps"]) > 64
+    assert np.array_equal(c.get_pose(), np.eye(4))
+    c.close()
