@@ -128,79 +128,67 @@ struct PixLane { int row, seg; bool on; };
 
 // ---- phase A for one slot: this lane's 7 patch pixels from the staged I tile -------------------
 // Tile rows row..row+3 = image rows ipy+row-1..ipy+row+2, bytes j = 0..9 = image columns
-// ipx-1+seg*7+j; everything is packed u16/i16 pairs m = (column 2m, column 2m+1).
+// ipx-1+seg*7+j.  Everything is packed as COLUMN WORDS pairing two vertically adjacent rows
+// (low half = upper row): Q01/Q12/Q23[j] = rows (0,1)/(1,2)/(2,3) of tile column j.  The packed
+// Scharr passes then produce the derivative rows A (image row ipy+row) and B (ipy+row+1) side by
+// side in one register per column, which is exactly the operand the bilinear v_dot2 wants:
+//   val_k = dot2(D[k], (w00 | w10 << 16)) + dot2(D[k+1], (w01 | w11 << 16)) + rounding
+// so no lane ever realigns a pixel pair.
 // Outputs: packed patch (Iv, Ix, Iy as 4 pairs each; pair 3 has a zero high half) and the three
 // partial sums of Ix^2, Ix*Iy, Iy^2.
 template <bool EDGE>
-__device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane &pl, int offI, uint32_t W01u,
-                                           uint32_t W23u, int ipx, int ipy, int w, int h,
+__device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane &pl, int offI, uint32_t Wau,
+                                           uint32_t Wbu, int ipx, int ipy, int w, int h,
                                            uint32_t (&IvP)[4], uint32_t (&IxP)[4], uint32_t (&IyP)[4],
                                            int &pA11, int &pA12, int &pA22)
 {
     // (lane 63 carries no window pixel: zero weights make its I, Ix, Iy and sums vanish)
-    const uint32_t W01 = pl.on ? W01u : 0u, W23 = pl.on ? W23u : 0u;
-    uint32_t P[4][5];
+    const uint32_t Wa = pl.on ? Wau : 0u, Wb = pl.on ? Wbu : 0u;
+    uint32_t R[4][3];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        uint32_t lo, mid, hi;
-        load12(tileI + (pl.row + r) * kTileIDw, offI + pl.seg * 7, lo, mid, hi);
-        P[r][0] = pair01(lo); P[r][1] = pair23(lo); P[r][2] = pair01(mid); P[r][3] = pair23(mid);
-        P[r][4] = pair01(hi);
+    for (int r = 0; r < 4; r++) load12(tileI + (pl.row + r) * kTileIDw, offI + pl.seg * 7, R[r][0], R[r][1], R[r][2]);
+    uint32_t Q01[10], Q12[10], Q23[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+        const uint32_t sel = 0x0c040c00u + 0x00010001u * (j & 3);
+        Q01[j] = perm_b32(R[1][j >> 2], R[0][j >> 2], sel);
+        Q12[j] = perm_b32(R[2][j >> 2], R[1][j >> 2], sel);
+        Q23[j] = perm_b32(R[3][j >> 2], R[2][j >> 2], sel);
     }
-    // vertical Scharr passes for derivative rows A (image row ipy+row) and B (ipy+row+1)
-    uint32_t T0A[5], T1A[5], T0B[5], T1B[5];
+    // vertical Scharr passes, rows A | B packed
+    uint32_t T0[10], T1[10];
     const u16x2 k3 = {3, 3}, k10 = {10, 10};
 #pragma unroll
-    for (int m = 0; m < 5; m++) {
-        u16x2 p0 = as_u16x2(P[0][m]), p1 = as_u16x2(P[1][m]), p2 = as_u16x2(P[2][m]), p3 = as_u16x2(P[3][m]);
-        T0A[m] = as_u32((p0 + p2) * k3 + p1 * k10);
-        T1A[m] = as_u32(p2 - p0);
-        T0B[m] = as_u32((p1 + p3) * k3 + p2 * k10);
-        T1B[m] = as_u32(p3 - p1);
+    for (int j = 0; j < 10; j++) {
+        T0[j] = as_u32((as_u16x2(Q01[j]) + as_u16x2(Q23[j])) * k3 + as_u16x2(Q12[j]) * k10);
+        T1[j] = as_u32(as_u16x2(Q23[j]) - as_u16x2(Q01[j]));
     }
-    // horizontal passes: derivative positions c = 0..7 (image column ipx+seg*7+c) as pairs
-    uint32_t DXA[4], DYA[4], DXB[4], DYB[4];
+    // horizontal passes: derivative column c = 0..7 (image column ipx+seg*7+c) from tile columns c..c+2
+    uint32_t DX[8], DY[8];
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-        DXA[m] = as_u32(as_u16x2(T0A[m + 1]) - as_u16x2(T0A[m]));
-        DXB[m] = as_u32(as_u16x2(T0B[m + 1]) - as_u16x2(T0B[m]));
-        u16x2 qa = as_u16x2(alignbit16(T1A[m + 1], T1A[m]));
-        u16x2 qb = as_u16x2(alignbit16(T1B[m + 1], T1B[m]));
-        DYA[m] = as_u32((as_u16x2(T1A[m]) + as_u16x2(T1A[m + 1])) * k3 + qa * k10);
-        DYB[m] = as_u32((as_u16x2(T1B[m]) + as_u16x2(T1B[m + 1])) * k3 + qb * k10);
+    for (int c = 0; c < 8; c++) {
+        DX[c] = as_u32(as_u16x2(T0[c + 2]) - as_u16x2(T0[c]));
+        DY[c] = as_u32((as_u16x2(T1[c]) + as_u16x2(T1[c + 2])) * k3 + as_u16x2(T1[c + 1]) * k10);
     }
     // the derivative image's border is BORDER_CONSTANT 0: mask positions outside the image
     // (only possible when the window hangs over the edge: the EDGE instantiation)
     if (EDGE) {
         const int gyA = ipy + pl.row, gyB = gyA + 1;
-        const uint32_t rowA = (gyA >= 0 && gyA < h) ? 0xFFFFFFFFu : 0u;
-        const uint32_t rowB = (gyB >= 0 && gyB < h) ? 0xFFFFFFFFu : 0u;
+        const uint32_t rows = ((gyA >= 0 && gyA < h) ? 0x0000FFFFu : 0u) | ((gyB >= 0 && gyB < h) ? 0xFFFF0000u : 0u);
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int gx = ipx + pl.seg * 7 + 2 * m;
-            uint32_t cm = ((gx >= 0 && gx < w) ? 0x0000FFFFu : 0u) | ((gx + 1 >= 0 && gx + 1 < w) ? 0xFFFF0000u : 0u);
-            DXA[m] &= cm & rowA; DYA[m] &= cm & rowA;
-            DXB[m] &= cm & rowB; DYB[m] &= cm & rowB;
+        for (int c = 0; c < 8; c++) {
+            const int gx = ipx + pl.seg * 7 + c;
+            const uint32_t mk = (gx >= 0 && gx < w) ? rows : 0u;
+            DX[c] &= mk; DY[c] &= mk;
         }
     }
     int iv[8], ix[8], iy[8];
     iv[7] = ix[7] = iy[7] = 0;
 #pragma unroll
     for (int k = 0; k < 7; k++) {
-        const int m = k >> 1;
-        uint32_t dxa, dya, dxb, dyb, i1, i2;
-        if ((k & 1) == 0) {
-            dxa = DXA[m]; dya = DYA[m]; dxb = DXB[m]; dyb = DYB[m];
-            i1 = alignbit16(P[1][m + 1], P[1][m]);          // intensity bytes j = k+1, k+2
-            i2 = alignbit16(P[2][m + 1], P[2][m]);
-        } else {
-            dxa = alignbit16(DXA[m + 1], DXA[m]); dya = alignbit16(DYA[m + 1], DYA[m]);
-            dxb = alignbit16(DXB[m + 1], DXB[m]); dyb = alignbit16(DYB[m + 1], DYB[m]);
-            i1 = P[1][m + 1]; i2 = P[2][m + 1];
-        }
-        iv[k] = dot2(i2, W23, dot2_k(i1, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-        ix[k] = dot2(dxb, W23, dot2_k(dxa, W01, 1 << (W_BITS - 1))) >> W_BITS;
-        iy[k] = dot2(dyb, W23, dot2_k(dya, W01, 1 << (W_BITS - 1))) >> W_BITS;
+        iv[k] = dot2(Q12[k + 2], Wb, dot2_k(Q12[k + 1], Wa, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+        ix[k] = dot2(DX[k + 1], Wb, dot2_k(DX[k], Wa, 1 << (W_BITS - 1))) >> W_BITS;
+        iy[k] = dot2(DY[k + 1], Wb, dot2_k(DY[k], Wa, 1 << (W_BITS - 1))) >> W_BITS;
     }
     pA11 = 0; pA12 = 0; pA22 = 0;
 #pragma unroll
@@ -282,8 +270,8 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
         if (live && oob && level == 0) status = 0;
         bool lvl_on = live && !oob;
         const Weights wt = bilinear_weights(px - (float)ipx, py - (float)ipy);
-        const uint32_t W01 = (uint32_t)wt.w00 | ((uint32_t)wt.w01 << 16);
-        const uint32_t W23 = (uint32_t)wt.w10 | ((uint32_t)wt.w11 << 16);
+        const uint32_t WIa = ((uint32_t)wt.w00 & 0xFFFFu) | ((uint32_t)wt.w10 << 16);   // column tap k:   rows A | B
+        const uint32_t WIb = ((uint32_t)wt.w01 & 0xFFFFu) | ((uint32_t)wt.w11 << 16);   // column tap k+1
         const int x0 = (ipx - 1) & ~3;
         const int offI = (ipx - 1) - x0;
 
@@ -312,7 +300,7 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
             pA[s][0] = pA[s][1] = pA[s][2] = 0;
             if (!((m_on >> (4 * s)) & 1ull)) continue;
             const int offIs = __builtin_amdgcn_readlane(offI, 4 * s);
-            const uint32_t W01s = __builtin_amdgcn_readlane(W01, 4 * s), W23s = __builtin_amdgcn_readlane(W23, 4 * s);
+            const uint32_t W01s = __builtin_amdgcn_readlane(WIa, 4 * s), W23s = __builtin_amdgcn_readlane(WIb, 4 * s);
             const int ipxs = __builtin_amdgcn_readlane(ipx, 4 * s), ipys = __builtin_amdgcn_readlane(ipy, 4 * s);
             if (__builtin_expect(ipxs < 0 || ipxs + kWin >= w || ipys < 0 || ipys + kWin >= h, 0))
                 patch_slot<true>(lds + s * kSlotDw, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IvP[s], IxP[s], IyP[s],
