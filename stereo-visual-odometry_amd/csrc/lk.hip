@@ -409,7 +409,7 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
     outPt = make_float2(nx, ny);
 }
 
-__global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void lk_kernel(LkArgs a)
 {
     __shared__ uint32_t lds[4 * kLdsDwPerWave];
     const int b = blockIdx.y;
