@@ -5,5 +5,5 @@ python -m pytest tests -m gpu -q -x > gpurun_out/tests.log 2>&1; echo "tests exi
 tail -15 gpurun_out/tests.log
 python bench.py --steps 5 --warmup 2 --cpu-pairs 0 > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench exit=$?"
 tail -3 gpurun_out/bench.log; tail -5 gpurun_out/bench.err
-python bench.py --steps 3 --warmup 1 --cpu-pairs 0 --mode orb --batch 64 > gpurun_out/bench_orb.log 2> gpurun_out/bench_orb.err; echo "bench orb exit=$?"
+python bench.py --steps 3 --warmup 1 --cpu-pairs 0 --mode orb --batch 256 > gpurun_out/bench_orb.log 2> gpurun_out/bench_orb.err; echo "bench orb exit=$?"
 tail -3 gpurun_out/bench_orb.log; tail -5 gpurun_out/bench_orb.err

@@ -75,23 +75,22 @@ __device__ __forceinline__ bool fast_arc(const uint8_t *c, int thr)
     return has_arc9(dark) || has_arc9(bright);
 }
 
-// cornerScore<16> of a corner (>= thr): min / max over every 9-arc d[s..s+8] by doubling
+// cornerScore<16> of a corner (>= thr): min / max over every 9-arc d[s..s+8] with three-input ops
 __device__ __forceinline__ int fast_corner_score(const uint8_t *c, int thr)
 {
     int d[16];
     load_circle(c, d, c[0]);
-    int mn[16], mx[16], t1[16], t2[16];
+    int m3[16], x3[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) { t1[i] = min(d[i], d[(i + 1) & 15]); t2[i] = max(d[i], d[(i + 1) & 15]); }
-#pragma unroll
-    for (int i = 0; i < 16; i++) { mn[i] = min(t1[i], t1[(i + 2) & 15]); mx[i] = max(t2[i], t2[(i + 2) & 15]); }
-#pragma unroll
-    for (int i = 0; i < 16; i++) { t1[i] = min(mn[i], mn[(i + 4) & 15]); t2[i] = max(mx[i], mx[(i + 4) & 15]); }
+    for (int i = 0; i < 16; i++) {
+        m3[i] = min(min(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
+        x3[i] = max(max(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
+    }
     int a0 = thr, bmin = 255;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        a0 = max(a0, min(t1[i], d[(i + 8) & 15]));
-        bmin = min(bmin, max(t2[i], d[(i + 8) & 15]));
+        a0 = max(a0, min(min(m3[i], m3[(i + 3) & 15]), m3[(i + 6) & 15]));
+        bmin = min(bmin, max(max(x3[i], x3[(i + 3) & 15]), x3[(i + 6) & 15]));
     }
     const int b0 = min(-a0, bmin);
     return -b0 - 1;

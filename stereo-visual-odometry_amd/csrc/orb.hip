@@ -15,6 +15,7 @@
 // decision depends on the node count so far) and small (<= a few thousand keys, <= ~450 leaves);
 // 16 instances per frame run concurrently on different waves.
 #include <cstring>
+#include <vector>
 #include "svo_ctx.h"
 #include "orb_pattern.h"
 
@@ -26,13 +27,15 @@ __constant__ signed char c_pattern[1024];
 __global__ __launch_bounds__(256) void orb_copy0_kernel(OrbGeom g, const uint8_t *img, int pitch, int64_t img_stride,
                                                         uint8_t *slots, int64_t slot_stride)
 {
-    const int b = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= g.w[0]) return;
-    slots[(int64_t)b * slot_stride + g.origin[0] + (int64_t)y * g.pitch[0] + x] = img[(int64_t)b * img_stride + (int64_t)y * pitch + x];
+    const int b = blockIdx.z, y = blockIdx.y, x = (blockIdx.x * 256 + threadIdx.x) * 16;
+    const int w = g.w[0];
+    if (x >= w) return;
+    const uint8_t *src = img + (int64_t)b * img_stride + (int64_t)y * pitch + x;
+    uint8_t *dst = slots + (int64_t)b * slot_stride + g.origin[0] + (int64_t)y * g.pitch[0] + x;   // 16-byte aligned
+    if (x + 16 <= w && ((uintptr_t)src & 15) == 0) *(uint4 *)dst = *(const uint4 *)src;
+    else for (int q = 0; q < 16 && x + q < w; q++) dst[q] = src[q];
 }
 
-// frame (kPad wide, only 19 are ever read) of level l by reflect-101 from the level's interior:
-// workgroups < 2*kPad take one top/bottom frame row each, the others four interior rows
 __global__ __launch_bounds__(256) void orb_border_kernel(OrbGeom g, uint8_t *slots, int64_t slot_stride, int l)
 {
     const int b = blockIdx.y;
@@ -55,32 +58,53 @@ __global__ __launch_bounds__(256) void orb_border_kernel(OrbGeom g, uint8_t *slo
 }
 
 // cv::resize(level l-1 -> level l, INTER_LINEAR), 8-bit fixed point (11-bit coefficients)
-__global__ __launch_bounds__(256) void orb_resize_kernel(OrbGeom g, uint8_t *slots, int64_t slot_stride, int l)
+// cv::resize(INTER_LINEAR) of level l-1 into level l (ComputePyramid, ORBextractor.cpp:1061-1085).
+// The per-column (sx, alpha) and per-row (sy0, sy1, beta) tables are built once on the host
+// (orb_make_tables: upstream builds the same tables per call), so a thread is four byte loads and
+// the 11-bit fixed-point blend; four output pixels per thread, one dword store.
+constexpr int kResizeDw = 520;               // source dwords staged per row: 1024 output pixels at scale <= 2
+__global__ __launch_bounds__(256) void orb_resize_kernel(OrbGeom g, uint8_t *slots, int64_t slot_stride, int l,
+                                                         const int2 *xtab, const int4 *ytab)
 {
-    const int b = blockIdx.z, dy = blockIdx.y, dx = blockIdx.x * 256 + threadIdx.x;
-    const int dw = g.w[l], dh = g.h[l], sw = g.w[l - 1], sh = g.h[l - 1], sp = g.pitch[l - 1];
-    if (dx >= dw) return;
+    __shared__ uint32_t rows[2][kResizeDw];
+    const int b = blockIdx.z, dy = blockIdx.y, tid = threadIdx.x;
+    const int dw = g.w[l], sp = g.pitch[l - 1];
+    const int dx_first = blockIdx.x * 1024, dx_last = min(dx_first + 1023, dw - 1);
     uint8_t *slot = slots + (int64_t)b * slot_stride;
     const uint8_t *src = slot + g.origin[l - 1];
-    const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
-    const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
-    float fx = (float)((dx + 0.5) * scale_x - 0.5);
-    int sx = (int)floorf(fx);
-    fx -= sx;
-    if (sx < 0) { fx = 0; sx = 0; }
-    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
-    const int a0 = (short)__float2int_rn((1.f - fx) * 2048), a1 = (short)__float2int_rn(fx * 2048);
-    float fy = (float)((dy + 0.5) * scale_y - 0.5);
-    int sy = (int)floorf(fy);
-    fy -= sy;
-    const int b0 = (short)__float2int_rn((1.f - fy) * 2048), b1 = (short)__float2int_rn(fy * 2048);
-    const int y0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
-    const int y1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
-    const int sx1 = sx + 1 < sw ? sx + 1 : sx;
-    const uint8_t *S0 = src + (int64_t)y0 * sp, *S1 = src + (int64_t)y1 * sp;
-    const int r0 = S0[sx] * a0 + S0[sx1] * a1, r1 = S1[sx] * a0 + S1[sx1] * a1;
-    slot[g.origin[l] + (int64_t)dy * g.pitch[l] + dx] =
-        (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    const int4 yt = ytab[g.ytab_off[l] + dy];                  // y0, y1, b0, b1
+    const uint8_t *S0 = src + (int64_t)yt.x * sp, *S1 = src + (int64_t)yt.y * sp;
+    const int2 *xt = xtab + g.xtab_off[l];
+    // the two source row segments this block samples, as aligned dwords (the byte gathers of a
+    // 1.2x resample would otherwise be 16 scattered loads per thread)
+    const int s0 = (xt[dx_first].x & 0xFFFF) & ~3;
+    const int ndw = (((xt[dx_last].x >> 16) - s0) >> 2) + 1;
+    const bool staged = ndw <= kResizeDw;
+    if (staged) {
+        for (int i = tid; i < ndw; i += 256) {
+            rows[0][i] = *(const uint32_t *)(S0 + s0 + 4 * i);
+            rows[1][i] = *(const uint32_t *)(S1 + s0 + 4 * i);
+        }
+        __syncthreads();
+    }
+    const int dx0 = dx_first + tid * 4;
+    if (dx0 >= dw) return;
+    uint32_t out = 0;
+    auto blend = [&](const auto *R0, const auto *R1, int base) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (dx0 + q >= dw) break;
+            const int2 t = xt[dx0 + q];                         // sx | sx1 << 16, a0 | a1 << 16
+            const int sx = (t.x & 0xFFFF) - base, sx1 = (t.x >> 16) - base, a0 = (short)(t.y & 0xFFFF), a1 = t.y >> 16;
+            const int r0 = R0[sx] * a0 + R0[sx1] * a1, r1 = R1[sx] * a0 + R1[sx1] * a1;
+            out |= (uint32_t)((((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2) << (8 * q);
+        }
+    };
+    if (staged) blend((const uint8_t *)rows[0], (const uint8_t *)rows[1], s0);
+    else blend(S0, S1, 0);
+    uint8_t *d = slot + g.origin[l] + (int64_t)dy * g.pitch[l] + dx0;       // origin and pitch are 4-byte aligned
+    if (dx0 + 4 <= dw) *(uint32_t *)d = out;
+    else for (int q = 0; dx0 + q < dw; q++) d[q] = (uint8_t)(out >> (8 * q));
 }
 
 // ---- per-cell FAST ---------------------------------------------------------------------------
@@ -97,19 +121,20 @@ __device__ __forceinline__ int fast_cornerness(const uint8_t *c, int P)
     d[4] = v - c[3];           d[5] = v - c[-P + 3];      d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];
     d[8] = v - c[-3 * P];      d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-P - 3];
     d[12] = v - c[-3];         d[13] = v - c[P - 3];      d[14] = v - c[2 * P - 2];  d[15] = v - c[3 * P - 1];
-    int mn[16], mx[16], t1[16], t2[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) { t1[i] = min(d[i], d[(i + 1) & 15]); t2[i] = max(d[i], d[(i + 1) & 15]); }
-#pragma unroll
-    for (int i = 0; i < 16; i++) { mn[i] = min(t1[i], t1[(i + 2) & 15]); mx[i] = max(t2[i], t2[(i + 2) & 15]); }
-#pragma unroll
-    for (int i = 0; i < 16; i++) { t1[i] = min(mn[i], mn[(i + 4) & 15]); t2[i] = max(mx[i], mx[(i + 4) & 15]); }
-    int best = -255, bestn = -255;
+    // min / max over every 9-arc d[i..i+8] as three-input ops: triples, then triples of triples
+    int m3[16], x3[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        best = max(best, min(t1[i], d[(i + 8) & 15]));
-        bestn = max(bestn, -max(t2[i], d[(i + 8) & 15]));
+        m3[i] = min(min(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
+        x3[i] = max(max(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
     }
+    int best = -255, worst = 255;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        best = max(best, min(min(m3[i], m3[(i + 3) & 15]), m3[(i + 6) & 15]));
+        worst = min(worst, max(max(x3[i], x3[(i + 3) & 15]), x3[(i + 6) & 15]));
+    }
+    const int bestn = -worst;
     const int V = max(best, bestn) - 1;
     return V > 0 ? V : 0;
 }
@@ -650,14 +675,49 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     const float x = cand.x + 16.f, y = cand.y + 16.f;                // += minBorderX / minBorderY
     const int ix = __float2int_rn(x), iy = __float2int_rn(y);
     const int pitch = a.g.pitch[l], w = a.g.w[l];
-    const uint8_t *center = a.slots + (int64_t)b * a.slot_stride + a.g.origin[l] + (int64_t)iy * pitch + ix;
+    // Both gathers (749-pixel circular patch of the level, <= 39x39 footprint of the rotated pattern
+    // in the blurred level) go through LDS: the wave fetches the two windows as aligned dwords with
+    // all loads in flight at once, then reads single bytes from LDS.
+    __shared__ uint32_t s_raw[4][31 * 9], s_blr[4][39 * 11];
+    uint32_t *raw = s_raw[threadIdx.x >> 6], *blr = s_blr[threadIdx.x >> 6];
+    const uint8_t *lvl = a.slots + (int64_t)b * a.slot_stride + a.g.origin[l];     // 4-byte aligned rows
+    const int rx0 = (ix - 15) & ~3, roff = (ix - 15) - rx0;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        const int i = lane + 64 * t;
+        if (i < 31 * 9) {
+            const int r = i / 9, c = i - r * 9;
+            raw[i] = *(const uint32_t *)(lvl + (int64_t)(iy - 15 + r) * pitch + rx0 + 4 * c);
+        }
+    }
+    const uint8_t *bimg = a.blur + (int64_t)b * a.blur_img_stride + a.g.blur_off[l];
+    const int64_t bsize = (int64_t)w * a.g.h[l];
+    // rows of the tight blurred image are not aligned: align each row's start down, keep its offset
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        const int i = lane + 64 * t;
+        if (i < 39 * 11) {
+            const int r = i / 11, c = i - r * 11;
+            const int64_t o = (int64_t)(iy - 19 + r) * w + (ix - 19);        // byte offset of the row's first pixel
+            const int64_t oa = ((o + ((uintptr_t)bimg & 3)) & ~(int64_t)3) - ((uintptr_t)bimg & 3) + 4 * c;
+            uint32_t v = 0;
+            if (oa >= 0 && oa + 4 <= bsize) v = *(const uint32_t *)(bimg + oa);
+            else for (int q = 0; q < 4; q++) if (oa + q >= 0 && oa + q < bsize) v |= (uint32_t)bimg[oa + q] << (8 * q);
+            blr[i] = v;
+        }
+    }
+    wave_lds_fence();
     // IC_Angle: m10 = sum u * I, m01 = sum v * I over the circular patch (rows v = -15..15)
     int m10 = 0, m01 = 0;
     if (lane < 31) {
         const int v = lane - 15, d = a.g.umax[v < 0 ? -v : v];
-        const uint8_t *row = center + (int64_t)v * pitch;
+        const uint8_t *row = (const uint8_t *)(raw + lane * 9) + roff + 15;
         int s = 0, su = 0;
-        for (int u = -d; u <= d; ++u) { const int val = row[u]; s += val; su += u * val; }
+#pragma unroll
+        for (int u = -15; u <= 15; ++u) {
+            const int val = (u >= -d && u <= d) ? (int)row[u] : 0;
+            s += val; su += u * val;
+        }
         m10 = su; m01 = v * s;
     }
     m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
@@ -666,15 +726,20 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ang = angle * factorPI;
     const float ca = (float)cos((double)ang), sb = (float)sin((double)ang);
-    const uint8_t *bc = a.blur + (int64_t)b * a.blur_img_stride + a.g.blur_off[l] + (int64_t)iy * w + ix;
     if (lane < 32) {
         const signed char *pat = c_pattern + lane * 32;
+        const int balign = (int)((uintptr_t)bimg & 3);
+        auto sample = [&](int dyy, int dxx) -> int {
+            const int64_t o = (int64_t)(iy + dyy) * w + (ix - 19);            // row start in the tight image
+            const int off = (int)((o + balign) & 3);                             // its offset inside the staged dwords
+            return ((const uint8_t *)(blr + (dyy + 19) * 11))[off + dxx + 19];
+        };
         int val = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const float xa = (float)pat[4 * k], ya = (float)pat[4 * k + 1], xb = (float)pat[4 * k + 2], yb = (float)pat[4 * k + 3];
-            const int t0 = bc[__float2int_rn(xa * sb + ya * ca) * w + __float2int_rn(xa * ca - ya * sb)];
-            const int t1 = bc[__float2int_rn(xb * sb + yb * ca) * w + __float2int_rn(xb * ca - yb * sb)];
+            const int t0 = sample(__float2int_rn(xa * sb + ya * ca), __float2int_rn(xa * ca - ya * sb));
+            const int t1 = sample(__float2int_rn(xb * sb + yb * ca), __float2int_rn(xb * ca - yb * sb));
             val |= (t0 < t1) << k;
         }
         a.desc[((int64_t)b * a.out_cap + gidx) * 32 + lane] = (uint8_t)val;
@@ -843,7 +908,43 @@ int orb_make_geom(const svo_config &cfg, OrbGeom *g)
     g->slot_bytes = off;
     g->blur_total = boff;
     g->cells_total = coff;
+    int xo = 0, yo = 0;
+    for (int l = 0; l < nlevels; l++) { g->xtab_off[l] = xo; g->ytab_off[l] = yo; if (l > 0) { xo += g->w[l]; yo += g->h[l]; } }
+    g->xtab_total = xo; g->ytab_total = yo;
     return SVO_OK;
+}
+
+// cv::resize's coordinate / weight tables for every level l >= 1 (INTER_LINEAR, 11-bit weights;
+// scale = 1 / (dst / src): CANONICAL O3).  x: clamp as upstream's xofs/alpha loop does, y: rows
+// clamped to the source like upstream's vertical pass.
+void orb_make_tables(const OrbGeom &g, std::vector<int2> &xt, std::vector<int4> &yt)
+{
+    xt.assign((size_t)g.xtab_total, make_int2(0, 0));
+    yt.assign((size_t)g.ytab_total, make_int4(0, 0, 0, 0));
+    for (int l = 1; l < g.nlevels; l++) {
+        const int dw = g.w[l], dh = g.h[l], sw = g.w[l - 1], sh = g.h[l - 1];
+        const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
+        const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
+        for (int dx = 0; dx < dw; dx++) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = (int)floorf(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+            const int a0 = (short)lrintf((1.f - fx) * 2048), a1 = (short)lrintf(fx * 2048);
+            const int sx1 = sx + 1 < sw ? sx + 1 : sx;
+            xt[(size_t)g.xtab_off[l] + dx] = make_int2(sx | (sx1 << 16), (a0 & 0xFFFF) | (a1 << 16));
+        }
+        for (int dy = 0; dy < dh; dy++) {
+            float fy = (float)((dy + 0.5) * scale_y - 0.5);
+            int sy = (int)floorf(fy);
+            fy -= sy;
+            const int b0 = (short)lrintf((1.f - fy) * 2048), b1 = (short)lrintf(fy * 2048);
+            const int y0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+            const int y1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
+            yt[(size_t)g.ytab_off[l] + dy] = make_int4(y0, y1, b0, b1);
+        }
+    }
 }
 
 static const int kSelCap = 1024;      // quadtree leaves per (image, level)
@@ -859,6 +960,14 @@ int orb_alloc(svo_ctx *ctx)
     ctx->orb_cand_cap = 4 * ctx->cfg.max_keypoints;      // FAST candidates kept per (image, level)
     const int kCandCap = ctx->orb_cand_cap;
     SVO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), svo_bit_pattern_31, 1024));
+    {
+        std::vector<int2> xt; std::vector<int4> yt;
+        orb_make_tables(g, xt, yt);
+        SVO_HIP(hipMalloc(&ctx->orb_xtab, sizeof(int2) * (xt.size() + 1)));
+        SVO_HIP(hipMalloc(&ctx->orb_ytab, sizeof(int4) * (yt.size() + 1)));
+        if (!xt.empty()) SVO_HIP(hipMemcpy(ctx->orb_xtab, xt.data(), sizeof(int2) * xt.size(), hipMemcpyHostToDevice));
+        if (!yt.empty()) SVO_HIP(hipMemcpy(ctx->orb_ytab, yt.data(), sizeof(int4) * yt.size(), hipMemcpyHostToDevice));
+    }
     SVO_HIP(hipMalloc(&ctx->orb_slots, (size_t)g.slot_bytes * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_blur, (size_t)g.blur_total * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_cell_cand, sizeof(float4) * (size_t)g.cells_total * kCellCap * n_img));
@@ -887,7 +996,7 @@ int orb_alloc(svo_ctx *ctx)
 void orb_free(svo_ctx *c)
 {
     auto F = [](void *p) { if (p) (void)hipFree(p); };
-    F(c->orb_slots); F(c->orb_blur); F(c->orb_cell_cand); F(c->orb_cell_cnt); F(c->orb_lvl_cand);
+    F(c->orb_slots); F(c->orb_xtab); F(c->orb_ytab); F(c->orb_blur); F(c->orb_cell_cand); F(c->orb_cell_cnt); F(c->orb_lvl_cand);
     F(c->orb_lvl_cnt); F(c->orb_qkeys); F(c->orb_qtmp);
     F(c->orb_sel); F(c->orb_sel_cnt); F(c->orb_overflow); F(c->orb_kps); F(c->orb_desc); F(c->orb_n);
     for (int k = 0; k < 2; k++) { F(c->orb_midx[k]); F(c->orb_mdist[k]); }
@@ -904,17 +1013,18 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     dim3 blk(256);
     if (img2) {
         // left images -> even slots, right images -> odd slots
-        hipLaunchKernelGGL(orb_copy0_kernel, dim3((g.w[0] + 255) / 256, g.h[0], n_img / 2), blk, 0, st, g, img, pitch, img_stride,
+        hipLaunchKernelGGL(orb_copy0_kernel, dim3((g.w[0] + 4095) / 4096, g.h[0], n_img / 2), blk, 0, st, g, img, pitch, img_stride,
                            slots, 2 * g.slot_bytes);
-        hipLaunchKernelGGL(orb_copy0_kernel, dim3((g.w[0] + 255) / 256, g.h[0], n_img / 2), blk, 0, st, g, img2, pitch, img_stride,
+        hipLaunchKernelGGL(orb_copy0_kernel, dim3((g.w[0] + 4095) / 4096, g.h[0], n_img / 2), blk, 0, st, g, img2, pitch, img_stride,
                            slots + g.slot_bytes, 2 * g.slot_bytes);
     } else {
-        hipLaunchKernelGGL(orb_copy0_kernel, dim3((g.w[0] + 255) / 256, g.h[0], n_img), blk, 0, st, g, img, pitch, img_stride,
+        hipLaunchKernelGGL(orb_copy0_kernel, dim3((g.w[0] + 4095) / 4096, g.h[0], n_img), blk, 0, st, g, img, pitch, img_stride,
                            slots, g.slot_bytes);
     }
     for (int l = 0; l < L; l++) {
         if (l > 0)
-            hipLaunchKernelGGL(orb_resize_kernel, dim3((g.w[l] + 255) / 256, g.h[l], n_img), blk, 0, st, g, slots, g.slot_bytes, l);
+            hipLaunchKernelGGL(orb_resize_kernel, dim3((g.w[l] + 1023) / 1024, g.h[l], n_img), blk, 0, st, g, slots, g.slot_bytes, l,
+                               (const int2 *)ctx->orb_xtab, (const int4 *)ctx->orb_ytab);
         hipLaunchKernelGGL(orb_border_kernel, dim3(2 * kPad + (g.h[l] + 3) / 4, n_img), blk, 0, st, g, slots, g.slot_bytes, l);
     }
     float4 *cell_cand = ctx->orb_cell_cand + (size_t)slot0 * g.cells_total * kCellCap;

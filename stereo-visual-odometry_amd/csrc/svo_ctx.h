@@ -47,6 +47,7 @@ struct svo_ctx {
     bool orb_ready = false;
     svo::OrbGeom orb_geom;
     uint8_t *orb_slots = nullptr, *orb_blur = nullptr;
+    void *orb_xtab = nullptr, *orb_ytab = nullptr;       // cv::resize coordinate / weight tables
     float4 *orb_cell_cand = nullptr; int *orb_cell_cnt = nullptr;
     float4 *orb_lvl_cand = nullptr; int *orb_lvl_cnt = nullptr;
     void *orb_qkeys = nullptr, *orb_qtmp = nullptr;      // quadtree key scratch (inputs larger than its LDS)

@@ -34,6 +34,7 @@ struct OrbGeom {
     int gk[7];                           // integer 7-tap Gaussian, sigma 2, scale 256
     int nCols[kOrbMaxLevels], nRows[kOrbMaxLevels], wCell[kOrbMaxLevels], hCell[kOrbMaxLevels];
     int ncell[kOrbMaxLevels], cell_off[kOrbMaxLevels], cells_total;
+    int xtab_off[kOrbMaxLevels], ytab_off[kOrbMaxLevels], xtab_total, ytab_total;   // resize tables (levels >= 1)
 };
 
 __host__ __device__ inline int refl101(int i, int n)
