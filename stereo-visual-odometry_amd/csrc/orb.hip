@@ -163,10 +163,15 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
     if (maxX > maxBX) maxX = (float)maxBX;
     const int x0 = (int)iniX, y0 = (int)iniY, cw = (int)maxX - x0, ch = (int)maxY - y0;
     if (skip || cw < 7 || ch < 7) { if (tid == 0) *cnt = 0; return; }
+    // i / cw for 0 <= i < 66 * 66 without an integer division (a runtime divisor costs ~25 vector
+    // instructions, and every loop below needs one): (i + 0.5) / cw is never within 1e-3 of an
+    // integer, far above the float error, so the truncation is exact
+    const float inv_cw = 1.0f / (float)cw;
+    auto row_of = [&](int i) { return (int)(((float)i + 0.5f) * inv_cw); };
     const uint8_t *img = slots + (int64_t)b * slot_stride + g.origin[l];
     if (tid == 0) { s_any = 0; s_found = 0; s_nlist = 0; }
     for (int i = tid; i < cw * ch; i += 256) {
-        int y = i / cw, x = i - y * cw;
+        int y = row_of(i), x = i - y * cw;
         raw[y * kCellMax + x] = img[(int64_t)(y0 + y) * pitch + x0 + x];
     }
     __syncthreads();
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
         bool alive = false;
         int pos = 0;
         if (i < cw * ch) {
-            const int y = i / cw, x = i - y * cw;
+            const int y = row_of(i), x = i - y * cw;
             pos = y * kCellMax + x;
             V[pos] = 0;
             if (x >= 3 && x < cw - 3 && y >= 3 && y < ch - 3) {
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
     for (int pass = 0; pass < 2; pass++) {
         int found = 0;
         for (int i = tid; i < cw * ch; i += 256) {
-            int y = i / cw, x = i - y * cw, k = 0;
+            int y = row_of(i), x = i - y * cw, k = 0;
             if (x >= 3 && x < cw - 3 && y >= 3 && y < ch - 3) {
                 const uint8_t *p = &V[y * kCellMax + x];
                 const int s = p[0];
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
         for (int i0 = 0; i0 < cw * ch; i0 += 64) {
             const int i = i0 + tid;
             int y = 0, x = 0, k = 0;
-            if (i < cw * ch) { y = i / cw; x = i - y * cw; k = keep[y * kCellMax + x]; }
+            if (i < cw * ch) { y = row_of(i); x = i - y * cw; k = keep[y * kCellMax + x]; }
             const unsigned long long m = __ballot(k != 0);
             if (k) {
                 const int idx = n + __popcll(m & ((1ull << tid) - 1ull));
@@ -753,34 +758,72 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     }
 }
 
-// ---- BruteForce-Hamming match: one wave per query row, first minimum ------------------------------
+// ---- BruteForce-Hamming match: 16 query rows per workgroup, first minimum ----------------------
+// The scan is O(Nq * Nt) and, with one query per wave, was bound by L2 bandwidth (every wave
+// re-read the whole train set).  Here a workgroup stages train rows 256 at a time in LDS
+// (dword-transposed: conflict-free) and each of its four waves scores them against FOUR queries
+// held in registers, so a train row is fetched from L2 once per 16 queries.  A lane keeps
+// (distance << 16 | train index) per query; unsigned min == "first minimum" because a lane sees
+// its train rows in ascending order and the wave reduction is a min over the same keys.
+constexpr int kMatchQ = 4;                    // queries per wave
 __global__ __launch_bounds__(256) void orb_match_kernel(const uint8_t *q, const int *nq_p, int nq_fixed, int64_t q_stride,
                                                         const uint8_t *t, const int *nt_p, int nt_fixed, int64_t t_stride,
                                                         int *idx, float *dist, int64_t out_stride)
 {
-    const int b = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ uint32_t tile[8][256];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nq = nq_p ? nq_p[b] : nq_fixed, nt = nt_p ? nt_p[b] : nt_fixed;
-    if (i >= nq) return;
-    const uint4 *qr = (const uint4 *)(q + (int64_t)b * q_stride + (int64_t)i * 32);
-    const uint4 q0 = qr[0], q1 = qr[1];
-    int best = 1 << 30, bj = -1;
-    for (int j = lane; j < nt; j += 64) {
-        const uint4 *tr = (const uint4 *)(t + (int64_t)b * t_stride + (int64_t)j * 32);
-        const uint4 t0 = tr[0], t1 = tr[1];
-        const int d = __popc(q0.x ^ t0.x) + __popc(q0.y ^ t0.y) + __popc(q0.z ^ t0.z) + __popc(q0.w ^ t0.w) +
-                      __popc(q1.x ^ t1.x) + __popc(q1.y ^ t1.y) + __popc(q1.z ^ t1.z) + __popc(q1.w ^ t1.w);
-        if (d < best) { best = d; bj = j; }        // j ascends per lane: first minimum kept
-    }
-    // lexicographic (distance, index) minimum across the wave == first minimum overall
-    unsigned long long key = bj >= 0 ? (((unsigned long long)(unsigned)best << 32) | (unsigned)bj) : ~0ull;
+    const int i0 = blockIdx.x * (4 * kMatchQ);
+    if (i0 >= nq) return;                                            // uniform over the workgroup
+    const int iq = i0 + wave * kMatchQ;
+    uint32_t Q[kMatchQ][8];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const unsigned long long o = __shfl_xor(key, m, 64);
-        key = o < key ? o : key;
+    for (int k = 0; k < kMatchQ; k++) {
+        const int i = min(iq + k, nq - 1);                           // duplicates of the last row are not stored
+        const uint4 *qr = (const uint4 *)(q + (int64_t)b * q_stride + (int64_t)i * 32);
+        const uint4 a0 = qr[0], a1 = qr[1];
+        Q[k][0] = a0.x; Q[k][1] = a0.y; Q[k][2] = a0.z; Q[k][3] = a0.w;
+        Q[k][4] = a1.x; Q[k][5] = a1.y; Q[k][6] = a1.z; Q[k][7] = a1.w;
     }
-    if (lane == 0) {
-        idx[(int64_t)b * out_stride + i] = nt > 0 ? (int)(unsigned)key : -1;
-        dist[(int64_t)b * out_stride + i] = nt > 0 ? (float)(int)(key >> 32) : (float)(1 << 30);
+    uint32_t best[kMatchQ];
+#pragma unroll
+    for (int k = 0; k < kMatchQ; k++) best[k] = 0xFFFFFFFFu;
+    const uint8_t *tb = t + (int64_t)b * t_stride;
+    for (int j0 = 0; j0 < nt; j0 += 256) {
+        __syncthreads();
+        if (j0 + tid < nt) {
+            const uint4 *tr = (const uint4 *)(tb + (int64_t)(j0 + tid) * 32);
+            const uint4 t0 = tr[0], t1 = tr[1];
+            tile[0][tid] = t0.x; tile[1][tid] = t0.y; tile[2][tid] = t0.z; tile[3][tid] = t0.w;
+            tile[4][tid] = t1.x; tile[5][tid] = t1.y; tile[6][tid] = t1.z; tile[7][tid] = t1.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int r = lane + 64 * s, j = j0 + r;
+            if (j0 + 64 * s >= nt) break;                            // uniform
+            uint32_t T[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) T[w] = tile[w][r];
+#pragma unroll
+            for (int k = 0; k < kMatchQ; k++) {
+                uint32_t d = 0;
+#pragma unroll
+                for (int w = 0; w < 8; w++) d += __popc(Q[k][w] ^ T[w]);
+                const uint32_t key = j < nt ? ((d << 16) | (uint32_t)j) : 0xFFFFFFFFu;
+                best[k] = min(best[k], key);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kMatchQ; k++) {
+        uint32_t key = best[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, m, 64));
+        if (lane == 0 && iq + k < nq) {
+            idx[(int64_t)b * out_stride + iq + k] = nt > 0 ? (int)(key & 0xFFFFu) : -1;
+            dist[(int64_t)b * out_stride + iq + k] = nt > 0 ? (float)(int)(key >> 16) : (float)(1 << 30);
+        }
     }
 }
 
@@ -952,6 +995,10 @@ static const int kSelCap = 1024;      // quadtree leaves per (image, level)
 int orb_alloc(svo_ctx *ctx)
 {
     if (ctx->orb_ready) return SVO_OK;
+    if (ctx->cfg.max_keypoints > 65536) {          // the matcher packs (distance, train index) into 32 bits
+        ctx->err = "ORB mode: max_keypoints must be <= 65536";
+        return SVO_ERR_ARG;
+    }
     OrbGeom &g = ctx->orb_geom;
     int rc = orb_make_geom(ctx->cfg, &g);
     if (rc) { ctx->err = "ORB geometry: unsupported image size / level count"; return rc; }
@@ -1062,7 +1109,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
 
 void orb_launch_match_fixed(svo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, hipStream_t st)
 {
-    hipLaunchKernelGGL(orb_match_kernel, dim3((nq + 3) / 4, 1), dim3(256), 0, st, q, (const int *)nullptr, nq, (int64_t)0, t,
+    hipLaunchKernelGGL(orb_match_kernel, dim3((nq + 4 * kMatchQ - 1) / (4 * kMatchQ), 1), dim3(256), 0, st, q, (const int *)nullptr, nq, (int64_t)0, t,
                        (const int *)nullptr, nt, (int64_t)0, ctx->orb_midx[0], ctx->orb_mdist[0], (int64_t)ctx->orb_kp_cap);
 }
 
@@ -1076,10 +1123,10 @@ int orb_match_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipS
     const svo_keypoint *K = (const svo_keypoint *)ctx->orb_kps;
     const int64_t fs = (int64_t)fstep * 2;                         // image slots per pair step
     // match1: last.left -> last.right ; match2: last.left -> cur.left  (src/tracking.cpp:543-544)
-    hipLaunchKernelGGL(orb_match_kernel, dim3((cap + 3) / 4, n_pairs), dim3(256), 0, st, D + (size_t)(2 * fp0) * cap * 32,
+    hipLaunchKernelGGL(orb_match_kernel, dim3((cap + 4 * kMatchQ - 1) / (4 * kMatchQ), n_pairs), dim3(256), 0, st, D + (size_t)(2 * fp0) * cap * 32,
                        N + 2 * fp0, 0, fs * cap * 32, D + (size_t)(2 * fp0 + 1) * cap * 32, N + 2 * fp0 + 1, 0, fs * cap * 32,
                        ctx->orb_midx[0], ctx->orb_mdist[0], (int64_t)cap);
-    hipLaunchKernelGGL(orb_match_kernel, dim3((cap + 3) / 4, n_pairs), dim3(256), 0, st, D + (size_t)(2 * fp0) * cap * 32,
+    hipLaunchKernelGGL(orb_match_kernel, dim3((cap + 4 * kMatchQ - 1) / (4 * kMatchQ), n_pairs), dim3(256), 0, st, D + (size_t)(2 * fp0) * cap * 32,
                        N + 2 * fp0, 0, fs * cap * 32, D + (size_t)(2 * fc0) * cap * 32, N + 2 * fc0, 0, fs * cap * 32,
                        ctx->orb_midx[1], ctx->orb_mdist[1], (int64_t)cap);
     OrbFilterArgs f{};
