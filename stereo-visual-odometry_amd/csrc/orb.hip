@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
     __shared__ uint8_t V[kCellMax * kCellMax];
     __shared__ uint8_t keep[kCellMax * kCellMax];
     __shared__ uint16_t list[kCellMax * kCellMax];
-    __shared__ int s_any, s_found, s_nlist;
+    __shared__ int s_any, s_found, s_nlist, s_ncand;
     const int b = blockIdx.z, cell = blockIdx.x;
     const int W = g.w[l], H = g.h[l], pitch = g.pitch[l];
     const int minBX = 16, minBY = 16, maxBX = W - 16, maxBY = H - 16;
@@ -166,10 +166,11 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
     // i / cw for 0 <= i < 66 * 66 without an integer division (a runtime divisor costs ~25 vector
     // instructions, and every loop below needs one): (i + 0.5) / cw is never within 1e-3 of an
     // integer, far above the float error, so the truncation is exact
+    const int lowTh = min(iniTh, minTh);
     const float inv_cw = 1.0f / (float)cw;
     auto row_of = [&](int i) { return (int)(((float)i + 0.5f) * inv_cw); };
     const uint8_t *img = slots + (int64_t)b * slot_stride + g.origin[l];
-    if (tid == 0) { s_any = 0; s_found = 0; s_nlist = 0; }
+    if (tid == 0) { s_any = 0; s_found = 0; s_nlist = 0; s_ncand = 0; }
     for (int i = tid; i < cw * ch; i += 256) {
         int y = row_of(i), x = i - y * cw;
         raw[y * kCellMax + x] = img[(int64_t)(y0 + y) * pitch + x0 + x];
@@ -184,10 +185,10 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
         if (i < cw * ch) {
             const int y = row_of(i), x = i - y * cw;
             pos = y * kCellMax + x;
-            V[pos] = 0;
+            V[pos] = 0; keep[pos] = 0;
             if (x >= 3 && x < cw - 3 && y >= 3 && y < ch - 3) {
                 const uint8_t *c = &raw[pos];
-                const int v = c[0], t = minTh;
+                const int v = c[0], t = lowTh;
                 const int d0 = v - c[3 * kCellMax], d8 = v - c[-3 * kCellMax], d4 = v - c[3], d12 = v - c[-3];
                 alive = ((d0 > t || d8 > t) && (d4 > t || d12 > t)) || ((d0 < -t || d8 < -t) && (d4 < -t || d12 < -t));
             }
@@ -202,32 +203,49 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
         }
     }
     __syncthreads();
+    // cornerness of the survivors; the positions that reach minTh are compacted again IN PLACE (a
+    // write index never passes the block of 256 entries being read), so the NMS passes below only
+    // visit possible keypoints instead of every pixel of the cell
     int any = 0;
     const int nlist = s_nlist;
-    for (int i = tid; i < nlist; i += 256) {
-        const int pos = list[i];
-        const int v = fast_cornerness(&raw[pos], kCellMax);
-        V[pos] = (uint8_t)v;
-        any |= v >= iniTh;
+    for (int i0 = 0; i0 < nlist; i0 += 256) {
+        const int i = i0 + tid;
+        int pos = 0, v = 0;
+        if (i < nlist) {
+            pos = list[i];
+            v = fast_cornerness(&raw[pos], kCellMax);
+            V[pos] = (uint8_t)v;
+            any |= v >= iniTh;
+        }
+        __syncthreads();
+        const bool cand = v >= lowTh && v > 0;
+        const unsigned long long m = __ballot(cand);
+        if (m) {
+            const int lane = tid & 63;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_ncand, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (cand) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+        }
     }
     if (any) s_any = 1;
     __syncthreads();
+    const int ncand = s_ncand;
     int thr = s_any ? iniTh : minTh;
     for (int pass = 0; pass < 2; pass++) {
         int found = 0;
-        for (int i = tid; i < cw * ch; i += 256) {
-            int y = row_of(i), x = i - y * cw, k = 0;
-            if (x >= 3 && x < cw - 3 && y >= 3 && y < ch - 3) {
-                const uint8_t *p = &V[y * kCellMax + x];
-                const int s = p[0];
-                if (s >= thr) {
+        for (int i = tid; i < ncand; i += 256) {
+            const int pos = list[i];
+            const uint8_t *p = &V[pos];
+            const int s = p[0];
+            int k = 0;
+            if (s >= thr) {
 #define SC(o) (p[o] >= thr ? (int)p[o] : 0)
-                    k = s > SC(-1) && s > SC(1) && s > SC(-kCellMax - 1) && s > SC(-kCellMax) && s > SC(-kCellMax + 1) &&
-                        s > SC(kCellMax - 1) && s > SC(kCellMax) && s > SC(kCellMax + 1);
+                k = s > SC(-1) && s > SC(1) && s > SC(-kCellMax - 1) && s > SC(-kCellMax) && s > SC(-kCellMax + 1) &&
+                    s > SC(kCellMax - 1) && s > SC(kCellMax) && s > SC(kCellMax + 1);
 #undef SC
-                }
             }
-            keep[y * kCellMax + x] = (uint8_t)k;
+            keep[pos] = (uint8_t)k;
             found |= k;
         }
         if (found) s_found = 1;
