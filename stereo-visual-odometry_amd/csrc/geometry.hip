@@ -130,7 +130,7 @@ __device__ inline double lm_eval(const double param[6], const float *X3, const f
     return acc[0];
 }
 
-__global__ __launch_bounds__(64) void pnp_ransac_kernel(PnpArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void pnp_ransac_kernel(PnpArgs a)
 {
     __shared__ double big[144 * 64];          // lane-interleaved 12x12 work matrices (73,728 B)
     __shared__ double bestRt[12];

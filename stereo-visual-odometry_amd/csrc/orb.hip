@@ -144,10 +144,13 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
                                                            int iniTh, int minTh, float4 *cell_cand, int *cell_cnt,
                                                            int64_t cand_img_stride, int64_t cnt_img_stride)
 {
-    __shared__ uint8_t raw[kCellMax * kCellMax];
-    __shared__ uint8_t V[kCellMax * kCellMax];
-    __shared__ uint8_t keep[kCellMax * kCellMax];
-    __shared__ uint16_t list[kCellMax * kCellMax];
+    // dynamic LDS: three byte planes + the position list, kCellMax columns x (hCell + 6) rows of THIS
+    // level (a static 66 x 66 worst case would cost 21.8 KB and starve the kernel of workgroups
+    // while the previous batch's pose solver holds 74 KB per CU)
+    extern __shared__ __attribute__((aligned(16))) uint8_t cf_smem[];
+    const int plane = (kCellMax * (g.hCell[l] + 6) + 15) & ~15;
+    uint8_t *raw = cf_smem, *V = cf_smem + plane, *keep = cf_smem + 2 * plane;
+    uint16_t *list = (uint16_t *)(cf_smem + 3 * plane);
     __shared__ int s_any, s_found, s_nlist, s_ncand;
     const int b = blockIdx.z, cell = blockIdx.x;
     const int W = g.w[l], H = g.h[l], pitch = g.pitch[l];
@@ -1092,11 +1095,19 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
                                (const int2 *)ctx->orb_xtab, (const int4 *)ctx->orb_ytab);
         hipLaunchKernelGGL(orb_border_kernel, dim3(2 * kPad + (g.h[l] + 3) / 4, n_img), blk, 0, st, g, slots, g.slot_bytes, l);
     }
+    // the blurred levels only depend on the pyramid: computed here, before the LDS-hungry kernels,
+    // so that in overlap mode the previous batch's pose solver (74 KB of LDS per workgroup) runs
+    // beside kernels that need no LDS
+    uint8_t *blur = ctx->orb_blur + (size_t)slot0 * g.blur_total;
+    for (int l = 0; l < L; l++)
+        hipLaunchKernelGGL(orb_blur_kernel, dim3((g.w[l] + 255) / 256, (g.h[l] + 4 * kBlurRows - 1) / (4 * kBlurRows), n_img),
+                           dim3(64, 4), 0, st, g, slots, g.slot_bytes, l, blur, g.blur_total);
     float4 *cell_cand = ctx->orb_cell_cand + (size_t)slot0 * g.cells_total * kCellCap;
     int *cell_cnt = ctx->orb_cell_cnt + (size_t)slot0 * g.cells_total;
     for (int l = 0; l < L; l++)
         if (g.ncell[l] > 0)
-            hipLaunchKernelGGL(orb_cellfast_kernel, dim3(g.ncell[l], 1, n_img), blk, 0, st, g, slots, g.slot_bytes, l,
+            hipLaunchKernelGGL(orb_cellfast_kernel, dim3(g.ncell[l], 1, n_img), blk,
+                               (size_t)5 * ((kCellMax * (g.hCell[l] + 6) + 15) & ~15), st, g, slots, g.slot_bytes, l,
                                ctx->cfg.orb_ini_th, ctx->cfg.orb_min_th, cell_cand, cell_cnt,
                                (int64_t)g.cells_total * kCellCap, (int64_t)g.cells_total);
     float4 *lvl_cand = ctx->orb_lvl_cand + (size_t)slot0 * L * kCandCap;
@@ -1109,10 +1120,6 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     d.sel = ctx->orb_sel + (size_t)slot0 * L * kSelCap; d.sel_cnt = ctx->orb_sel_cnt + (size_t)slot0 * L; d.sel_cap = kSelCap;
     d.overflow = ctx->orb_overflow;
     hipLaunchKernelGGL(orb_distribute_kernel, dim3(L, n_img), dim3(64), 0, st, d);
-    uint8_t *blur = ctx->orb_blur + (size_t)slot0 * g.blur_total;
-    for (int l = 0; l < L; l++)
-        hipLaunchKernelGGL(orb_blur_kernel, dim3((g.w[l] + 255) / 256, (g.h[l] + 4 * kBlurRows - 1) / (4 * kBlurRows), n_img),
-                           dim3(64, 4), 0, st, g, slots, g.slot_bytes, l, blur, g.blur_total);
     OrbDescArgs e{};
     e.g = g; e.slots = slots; e.slot_stride = g.slot_bytes; e.blur = blur; e.blur_img_stride = g.blur_total;
     e.lvl_cand = lvl_cand; e.cand_cap = kCandCap; e.sel = d.sel; e.sel_cnt = d.sel_cnt; e.sel_cap = kSelCap;
