@@ -789,11 +789,12 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
 constexpr int kMatchQ = 4;                    // queries per wave
 __global__ __launch_bounds__(256) void orb_match_kernel(const uint8_t *q, const int *nq_p, int nq_fixed, int64_t q_stride,
                                                         const uint8_t *t, const int *nt_p, int nt_fixed, int64_t t_stride,
-                                                        int *idx, float *dist, int64_t out_stride)
+                                                        int n_stride, int *idx, float *dist, int64_t out_stride)
 {
     __shared__ uint32_t tile[8][256];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nq = nq_p ? nq_p[b] : nq_fixed, nt = nt_p ? nt_p[b] : nt_fixed;
+    // per-item row counts sit n_stride ints apart (image slots: left / right of consecutive frames)
+    const int nq = nq_p ? nq_p[(int64_t)b * n_stride] : nq_fixed, nt = nt_p ? nt_p[(int64_t)b * n_stride] : nt_fixed;
     const int i0 = blockIdx.x * (4 * kMatchQ);
     if (i0 >= nq) return;                                            // uniform over the workgroup
     const int iq = i0 + wave * kMatchQ;
@@ -1135,7 +1136,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
 void orb_launch_match_fixed(svo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, hipStream_t st)
 {
     hipLaunchKernelGGL(orb_match_kernel, dim3((nq + 4 * kMatchQ - 1) / (4 * kMatchQ), 1), dim3(256), 0, st, q, (const int *)nullptr, nq, (int64_t)0, t,
-                       (const int *)nullptr, nt, (int64_t)0, ctx->orb_midx[0], ctx->orb_mdist[0], (int64_t)ctx->orb_kp_cap);
+                       (const int *)nullptr, nt, (int64_t)0, 0, ctx->orb_midx[0], ctx->orb_mdist[0], (int64_t)ctx->orb_kp_cap);
 }
 
 // match + filter for n_pairs pairs: pair p = (frame fp0 + p*fstep, frame fc0 + p*fstep); writes
@@ -1150,10 +1151,10 @@ int orb_match_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipS
     // match1: last.left -> last.right ; match2: last.left -> cur.left  (src/tracking.cpp:543-544)
     hipLaunchKernelGGL(orb_match_kernel, dim3((cap + 4 * kMatchQ - 1) / (4 * kMatchQ), n_pairs), dim3(256), 0, st, D + (size_t)(2 * fp0) * cap * 32,
                        N + 2 * fp0, 0, fs * cap * 32, D + (size_t)(2 * fp0 + 1) * cap * 32, N + 2 * fp0 + 1, 0, fs * cap * 32,
-                       ctx->orb_midx[0], ctx->orb_mdist[0], (int64_t)cap);
+                       (int)fs, ctx->orb_midx[0], ctx->orb_mdist[0], (int64_t)cap);
     hipLaunchKernelGGL(orb_match_kernel, dim3((cap + 4 * kMatchQ - 1) / (4 * kMatchQ), n_pairs), dim3(256), 0, st, D + (size_t)(2 * fp0) * cap * 32,
                        N + 2 * fp0, 0, fs * cap * 32, D + (size_t)(2 * fc0) * cap * 32, N + 2 * fc0, 0, fs * cap * 32,
-                       ctx->orb_midx[1], ctx->orb_mdist[1], (int64_t)cap);
+                       (int)fs, ctx->orb_midx[1], ctx->orb_mdist[1], (int64_t)cap);
     OrbFilterArgs f{};
     f.lastL = K + (size_t)(2 * fp0) * cap; f.lastR = K + (size_t)(2 * fp0 + 1) * cap; f.curL = K + (size_t)(2 * fc0) * cap;
     f.kp_stride_prev = fs * cap; f.kp_stride_cur = fs * cap;

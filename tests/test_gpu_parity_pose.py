@@ -353,3 +353,41 @@ def test_capacity_overflow_fails_the_pair_loudly(pkg, tc, small_seq):
     assert rc == 6 and int(r["ok"]) == 0 and int(r["fail_stage"]) == 6 and int(r["n_prev_kps"]) > 64
     assert np.array_equal(c.get_pose(), np.eye(4))
     c.close()
+
+
+@pytest.mark.parametrize("mode", ["lk", "orb"])
+def test_ragged_batch_equals_online_sequence(pkg, tc, small_seq, mode):
+    """A batch with a featureless frame and a repeated frame in the middle (0 keypoints, zero motion,
+    very different keypoint counts per pair) gives record-for-record what the online path gives
+    frame by frame (itself checked against the oracle above), in both track modes; failed pairs are
+    skipped by the pose chain."""
+    seq, frames = small_seq
+    h, w = frames[0][0].shape
+    P1, P2 = seq.proj()
+    flat = np.full((h, w), 90, np.uint8)
+    fs = [frames[0], frames[1], (flat, flat), frames[2], frames[2], frames[3]]
+    kw = dict(P1=P1, P2=P2)
+    if mode == "orb":
+        kw.update(track_mode=pkg.MODE_ORB, orb_nlevels=4, orb_nfeatures=600, min_move2=0.05 ** 2, max_move2=10.0 ** 2)
+    c = pkg.Context(w, h, device=0, max_batch=8, **kw)
+    online = []
+    for l, r in fs:
+        rc, rec = c.add_frame(l, r)
+        online.append((rc, rec, c.get_pose().copy()))
+    c.reset()
+    L = tc.from_numpy(np.stack([f[0] for f in fs])).cuda()
+    R = tc.from_numpy(np.stack([f[1] for f in fs])).cuda()
+    got = c.track_batch(L, R)
+    assert len(got) == len(fs) - 1
+    stages = []
+    for i, g in enumerate(got):
+        rc, rec, pose = online[i + 1]
+        for k in ("ok", "fail_stage", "n_prev_kps", "n_cur_kps", "n_tracked", "n_inliers"):
+            assert int(g[k]) == int(rec[k]), (i, k)
+        assert np.abs(g["pose"].reshape(4, 4) - pose).max() < 1e-9
+        assert rc == (0 if int(rec["ok"]) else int(rec["fail_stage"]))
+        stages.append(int(g["fail_stage"]))
+    assert stages[1] != 0 and stages[2] != 0            # into and out of the featureless frame
+    assert int(got[0]["ok"]) == 1 and int(got[4]["ok"]) == 1
+    assert np.array_equal(got[2]["pose"], got[0]["pose"])         # the chain skipped the two failures
+    c.close()
