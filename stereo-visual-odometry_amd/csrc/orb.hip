@@ -316,17 +316,39 @@ __global__ __launch_bounds__(256) void orb_gather_kernel(OrbGeom g, const float4
 // per lane.  A key is two words: x | y << 16 (cell-space pixel coordinates) and
 // candidate index | response << 24 (FAST cornerness <= 255); the partition is stable, so a node's
 // keys stay in candidate order and "first maximum" == smallest index among the maxima.
-constexpr int kNodeCap = 640;     // live nodes: <= quota + 3 leaves, + 4 children in flight
 constexpr int kLdsKeys = 4096;    // candidates partitioned in LDS; larger inputs use global scratch
 
 struct QBox { short ulx, uly, brx, bry; };
+// dynamic LDS of one instance, carved for `node_cap` live nodes (<= quota + 3 leaves, + 4 children in
+// flight; the host sizes it from the largest per-level quota of the configuration)
 struct QLds {
-    uint2 keys[kLdsKeys];
-    QBox box[kNodeCap];
-    int begin[kNodeCap], count[kNodeCap], seq[kNodeCap];
-    short prev[kNodeCap], next[kNodeCap], free_list[kNodeCap];
-    unsigned long long ea[kNodeCap], eb[kNodeCap];   // (count << 40 | seq << 12 | id) of nodes still to expand
+    uint2 *keys;
+    unsigned long long *ea, *eb;          // (count << 40 | seq << 12 | id) of nodes still to expand
+    QBox *box;
+    int *begin, *count, *seq;
+    short *prev, *next, *free_list;
+    int node_cap;
 };
+__host__ __device__ inline size_t qlds_bytes(int node_cap)
+{
+    return (size_t)kLdsKeys * 8 + (size_t)node_cap * (8 + 8 + 8 + 4 * 3 + 2 * 3) + 16;
+}
+__device__ inline QLds qlds_carve(uint8_t *smem, int node_cap)
+{
+    QLds L;
+    L.node_cap = node_cap;
+    L.keys = (uint2 *)smem; smem += (size_t)kLdsKeys * 8;
+    L.ea = (unsigned long long *)smem; smem += (size_t)node_cap * 8;
+    L.eb = (unsigned long long *)smem; smem += (size_t)node_cap * 8;
+    L.box = (QBox *)smem; smem += (size_t)node_cap * 8;
+    L.begin = (int *)smem; smem += (size_t)node_cap * 4;
+    L.count = (int *)smem; smem += (size_t)node_cap * 4;
+    L.seq = (int *)smem; smem += (size_t)node_cap * 4;
+    L.prev = (short *)smem; smem += (size_t)node_cap * 2;
+    L.next = (short *)smem; smem += (size_t)node_cap * 2;
+    L.free_list = (short *)smem;
+    return L;
+}
 struct QState { int n_free, n_alloc, head, tail, size, seq; bool overflow; };
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -335,8 +357,8 @@ __device__ inline int qt_new(QLds &L, QState &t, int lane)
 {
     int id;
     if (t.n_free > 0) id = rfl(L.free_list[--t.n_free]);
-    else if (t.n_alloc < kNodeCap) id = t.n_alloc++;
-    else { t.overflow = true; id = kNodeCap - 1; }
+    else if (t.n_alloc < L.node_cap) id = t.n_alloc++;
+    else { t.overflow = true; id = L.node_cap - 1; }
     if (lane == 0) L.seq[id] = t.seq;
     t.seq++;
     return id;
@@ -474,11 +496,13 @@ struct OrbDistArgs {
     uint2 *gkeys, *gtmp;                  // per-instance scratch, cand_cap entries each
     int *sel; int *sel_cnt; int sel_cap;  // outputs: selected candidate indices in list order
     int *overflow;
+    int node_cap;
 };
 
 __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
 {
-    __shared__ QLds L;
+    extern __shared__ __attribute__((aligned(16))) uint8_t qt_smem[];
+    QLds L = qlds_carve(qt_smem, a.node_cap);
     const int lane = threadIdx.x;
     const int l = blockIdx.x, b = blockIdx.y, inst = b * a.g.nlevels + l;
     const int nkeys = a.lvl_cnt[inst];
@@ -499,7 +523,7 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
 
     // root nodes: stable binning of the candidates by column strip
     int filled = 0;
-    for (int i = 0; i < nIni && i < 64; i++) {
+    for (int i = 0; i < nIni && i < 64 && i < L.node_cap; i++) {
         const int start = filled;
         for (int base = 0; base < nkeys; base += 256) {
             float4 c4[4];                                     // four loads in flight
@@ -545,7 +569,7 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
                     qt_push_front(L, t, ch[q], lane);
                     if (cn[q] > 1) {
                         nToExpand++;
-                        if (n_exp < kNodeCap) { if (lane == 0) L.ea[n_exp] = exp_key(cn[q], cs[q], ch[q]); n_exp++; }
+                        if (n_exp < L.node_cap) { if (lane == 0) L.ea[n_exp] = exp_key(cn[q], cs[q], ch[q]); n_exp++; }
                     }
                 }
             const int nx = rfl(L.next[lit]);
@@ -568,7 +592,7 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
                     for (int q = 0; q < 4; q++)
                         if (ch[q] >= 0) {
                             qt_push_front(L, t, ch[q], lane);
-                            if (cn[q] > 1 && n_exp < kNodeCap) { if (lane == 0) L.ea[n_exp] = exp_key(cn[q], cs[q], ch[q]); n_exp++; }
+                            if (cn[q] > 1 && n_exp < L.node_cap) { if (lane == 0) L.ea[n_exp] = exp_key(cn[q], cs[q], ch[q]); n_exp++; }
                         }
                     qt_erase(L, t, nid, lane);
                     if (t.size >= N || t.overflow) break;
@@ -1012,7 +1036,6 @@ void orb_make_tables(const OrbGeom &g, std::vector<int2> &xt, std::vector<int4> 
     }
 }
 
-static const int kSelCap = 1024;      // quadtree leaves per (image, level)
 
 int orb_alloc(svo_ctx *ctx)
 {
@@ -1026,6 +1049,18 @@ int orb_alloc(svo_ctx *ctx)
     if (rc) { ctx->err = "ORB geometry: unsupported image size / level count"; return rc; }
     const int n_img = 2 * ctx->n_img;                  // left + right of every frame slot
     const int L = g.nlevels;
+    {
+        // quadtree LDS: room for the largest per-level quota; opt in to more than the default dynamic limit
+        int qmax = 0;
+        for (int l = 0; l < g.nlevels; l++) qmax = qmax > g.quota[l] ? qmax : g.quota[l];
+        ctx->orb_node_cap = (qmax + 16 + 63) / 64 * 64;
+        const size_t bytes = qlds_bytes(ctx->orb_node_cap);
+        if (bytes > 150 * 1024 || ctx->orb_node_cap > 4096) {
+            ctx->err = "ORB: nFeatures per level too large for the quadtree's LDS";
+            return SVO_ERR_ARG;
+        }
+        SVO_HIP(hipFuncSetAttribute((const void *)orb_distribute_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    }
     ctx->orb_cand_cap = 4 * ctx->cfg.max_keypoints;      // FAST candidates kept per (image, level)
     const int kCandCap = ctx->orb_cand_cap;
     SVO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), svo_bit_pattern_31, 1024));
@@ -1045,7 +1080,7 @@ int orb_alloc(svo_ctx *ctx)
     SVO_HIP(hipMalloc(&ctx->orb_lvl_cnt, sizeof(int) * (size_t)L * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_qkeys, sizeof(uint2) * (size_t)kCandCap * L * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_qtmp, sizeof(uint2) * (size_t)kCandCap * L * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_sel, sizeof(int) * (size_t)kSelCap * L * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_sel, sizeof(int) * (size_t)ctx->orb_node_cap * L * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_sel_cnt, sizeof(int) * (size_t)L * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_overflow, sizeof(int)));
     SVO_HIP(hipMemset(ctx->orb_overflow, 0, sizeof(int)));
@@ -1118,12 +1153,13 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     OrbDistArgs d{};
     d.g = g; d.lvl_cand = lvl_cand; d.lvl_cnt = lvl_cnt; d.cand_cap = kCandCap;
     d.gkeys = (uint2 *)ctx->orb_qkeys + (size_t)slot0 * L * kCandCap; d.gtmp = (uint2 *)ctx->orb_qtmp + (size_t)slot0 * L * kCandCap;
-    d.sel = ctx->orb_sel + (size_t)slot0 * L * kSelCap; d.sel_cnt = ctx->orb_sel_cnt + (size_t)slot0 * L; d.sel_cap = kSelCap;
+    d.sel = ctx->orb_sel + (size_t)slot0 * L * ctx->orb_node_cap; d.sel_cnt = ctx->orb_sel_cnt + (size_t)slot0 * L; d.sel_cap = ctx->orb_node_cap;
     d.overflow = ctx->orb_overflow;
-    hipLaunchKernelGGL(orb_distribute_kernel, dim3(L, n_img), dim3(64), 0, st, d);
+    d.node_cap = ctx->orb_node_cap;
+    hipLaunchKernelGGL(orb_distribute_kernel, dim3(L, n_img), dim3(64), qlds_bytes(ctx->orb_node_cap), st, d);
     OrbDescArgs e{};
     e.g = g; e.slots = slots; e.slot_stride = g.slot_bytes; e.blur = blur; e.blur_img_stride = g.blur_total;
-    e.lvl_cand = lvl_cand; e.cand_cap = kCandCap; e.sel = d.sel; e.sel_cnt = d.sel_cnt; e.sel_cap = kSelCap;
+    e.lvl_cand = lvl_cand; e.cand_cap = kCandCap; e.sel = d.sel; e.sel_cnt = d.sel_cnt; e.sel_cap = ctx->orb_node_cap;
     e.kps = (svo_keypoint *)ctx->orb_kps + (size_t)slot0 * ctx->orb_kp_cap; e.desc = ctx->orb_desc + (size_t)slot0 * ctx->orb_kp_cap * 32;
     e.n_out = ctx->orb_n + slot0; e.out_cap = ctx->orb_kp_cap;
     int max_kp = 0;

@@ -50,6 +50,7 @@ struct svo_ctx {
     void *orb_xtab = nullptr, *orb_ytab = nullptr;       // cv::resize coordinate / weight tables
     float4 *orb_cell_cand = nullptr; int *orb_cell_cnt = nullptr;
     float4 *orb_lvl_cand = nullptr; int *orb_lvl_cnt = nullptr;
+    int orb_node_cap = 0;                                // quadtree node capacity (largest level quota + slack)
     void *orb_qkeys = nullptr, *orb_qtmp = nullptr;      // quadtree key scratch (inputs larger than its LDS)
     int *orb_sel = nullptr, *orb_sel_cnt = nullptr, *orb_overflow = nullptr;
     void *orb_kps = nullptr; uint8_t *orb_desc = nullptr; int *orb_n = nullptr; int orb_kp_cap = 0, orb_cand_cap = 0;

@@ -168,3 +168,40 @@ def test_orb_mode_failure_stages(pkg, oracle, tc, synth):
     _check_orb_step(g, ref[0][0])
     assert np.array_equal(c.get_pose(), np.eye(4))
     c.close()
+
+
+@pytest.mark.parametrize("cfg", [dict(nlevels=1, scale_factor=1.2, nfeatures=800, ini_th=20, min_th=7),
+                                 dict(nlevels=5, scale_factor=1.5, nfeatures=1200, ini_th=30, min_th=10),
+                                 dict(nlevels=8, scale_factor=1.1, nfeatures=300, ini_th=12, min_th=12)])
+def test_orb_extract_other_configurations(pkg, oracle, tc, synth, cfg):
+    """ORBextractor with non-default YAML values (nLevels, fScaleFactor, nFeatures, FAST thresholds):
+    resize tables, quotas, cell grid and quadtree all follow the configuration; bit-exact."""
+    seq = synth.StereoSequence(width=500, height=300, n_frames=1, seed=11, supersample=1)
+    img = seq.render(0)[0].numpy()
+    ctx = pkg.Context(500, 300, device=0, track_mode=pkg.MODE_ORB, orb_nlevels=cfg["nlevels"],
+                      orb_scale_factor=cfg["scale_factor"], orb_nfeatures=cfg["nfeatures"],
+                      orb_ini_th=cfg["ini_th"], orb_min_th=cfg["min_th"])
+    kps, desc, per = ctx.orb_extract(img)
+    rk, rd, rper = oracle.orb_extract(img, **cfg)
+    for l in range(cfg["nlevels"]):
+        assert np.array_equal(ctx.orb_read_level(l), oracle.orb_pyramid_level(img, l, scale_factor=cfg["scale_factor"],
+                                                                              nlevels=cfg["nlevels"])), f"level {l}"
+    assert per.tolist()[:cfg["nlevels"]] == rper.tolist()[:cfg["nlevels"]]
+    assert len(rk) > 50 and kps.tobytes() == rk.tobytes() and desc.tobytes() == rd.tobytes()
+    ctx.close()
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (15, 257), (16, 256), (17, 255), (700, 64), (33, 1000)])
+def test_match_hamming_shapes_and_ties(pkg, oracle, tc, nq, nt):
+    """Row counts around the matcher's tile sizes (16 queries per workgroup, 256 train rows per
+    tile) and heavy ties (few distinct rows): the first minimum must win everywhere."""
+    rng = np.random.default_rng(nq * 1000 + nt)
+    base = rng.integers(0, 256, (5, 32), dtype=np.uint8)
+    t = base[rng.integers(0, 5, nt)]
+    q = base[rng.integers(0, 5, nq)].copy()
+    q[:, 7] ^= rng.integers(0, 2, nq).astype(np.uint8)
+    ctx = pkg.Context(416, 128, device=0, track_mode=pkg.MODE_ORB)
+    ridx, rdist = oracle.match_hamming(q, t)
+    idx, dist = ctx.match_hamming(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    ctx.close()
