@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void orb_gather_kernel(OrbGeom g, const float4
 // per lane.  A key is two words: x | y << 16 (cell-space pixel coordinates) and
 // candidate index | response << 24 (FAST cornerness <= 255); the partition is stable, so a node's
 // keys stay in candidate order and "first maximum" == smallest index among the maxima.
-constexpr int kLdsKeys = 4096;    // candidates partitioned in LDS; larger inputs use global scratch
+constexpr int kLdsKeys = 3840;    // candidates partitioned in LDS (three instances per CU at the default quota); larger inputs use global scratch
 
 struct QBox { short ulx, uly, brx, bry; };
 // dynamic LDS of one instance, carved for `node_cap` live nodes (<= quota + 3 leaves, + 4 children in
