@@ -313,37 +313,45 @@ __global__ __launch_bounds__(256) void orb_gather_kernel(OrbGeom g, const float4
 // serial by definition), while everything that touches keys is done by the 64 lanes together:
 // DivideNode is a stable in-place 4-way partition of the node's key range (ballot ranks), the
 // "sort by size" of the last phase is a rank sort, and the final best-response pick runs one leaf
-// per lane.  A key is two words: x | y << 16 (cell-space pixel coordinates) and
-// candidate index | response << 24 (FAST cornerness <= 255); the partition is stable, so a node's
-// keys stay in candidate order and "first maximum" == smallest index among the maxima.
-constexpr int kLdsKeys = 3840;    // candidates partitioned in LDS (three instances per CU at the default quota); larger inputs use global scratch
+// per lane.  A key is x | y << 16 (cell-space pixel coordinates) plus a 16-bit candidate index (two
+// planes, 6 bytes per key; responses are read from the candidate list at the end); the partition is
+// stable, so a node's keys stay in candidate order and "first maximum" == the first key with the
+// largest response.
+constexpr int kLdsKeys = 3456;    // candidates partitioned in LDS (39 KB per instance at the default quota: four per CU, one per SIMD); larger inputs use global scratch
 
 struct QBox { short ulx, uly, brx, bry; };
 // dynamic LDS of one instance, carved for `node_cap` live nodes (<= quota + 3 leaves, + 4 children in
 // flight; the host sizes it from the largest per-level quota of the configuration)
+// A key is (x | y << 16 in cell-space pixels, candidate index): two planes, 6 bytes per key.
+struct KeyArr {
+    uint32_t *xy; uint16_t *id;
+    __device__ __forceinline__ uint2 get(int i) const { return make_uint2(xy[i], id[i]); }
+    __device__ __forceinline__ void set(int i, uint2 v) const { xy[i] = v.x; id[i] = (uint16_t)v.y; }
+};
 struct QLds {
-    uint2 *keys;
+    KeyArr keys;
     unsigned long long *ea, *eb;          // (count << 40 | seq << 12 | id) of nodes still to expand
     QBox *box;
-    int *begin, *count, *seq;
+    unsigned short *begin, *count, *seq;
     short *prev, *next, *free_list;
     int node_cap;
 };
 __host__ __device__ inline size_t qlds_bytes(int node_cap)
 {
-    return (size_t)kLdsKeys * 8 + (size_t)node_cap * (8 + 8 + 8 + 4 * 3 + 2 * 3) + 16;
+    return (size_t)kLdsKeys * 6 + (size_t)node_cap * (8 + 8 + 8 + 2 * 3 + 2 * 3) + 16;
 }
 __device__ inline QLds qlds_carve(uint8_t *smem, int node_cap)
 {
     QLds L;
     L.node_cap = node_cap;
-    L.keys = (uint2 *)smem; smem += (size_t)kLdsKeys * 8;
+    L.keys.xy = (uint32_t *)smem; smem += (size_t)kLdsKeys * 4;
+    L.keys.id = (uint16_t *)smem; smem += (size_t)kLdsKeys * 2;
     L.ea = (unsigned long long *)smem; smem += (size_t)node_cap * 8;
     L.eb = (unsigned long long *)smem; smem += (size_t)node_cap * 8;
     L.box = (QBox *)smem; smem += (size_t)node_cap * 8;
-    L.begin = (int *)smem; smem += (size_t)node_cap * 4;
-    L.count = (int *)smem; smem += (size_t)node_cap * 4;
-    L.seq = (int *)smem; smem += (size_t)node_cap * 4;
+    L.begin = (unsigned short *)smem; smem += (size_t)node_cap * 2;
+    L.count = (unsigned short *)smem; smem += (size_t)node_cap * 2;
+    L.seq = (unsigned short *)smem; smem += (size_t)node_cap * 2;
     L.prev = (short *)smem; smem += (size_t)node_cap * 2;
     L.next = (short *)smem; smem += (size_t)node_cap * 2;
     L.free_list = (short *)smem;
@@ -359,7 +367,7 @@ __device__ inline int qt_new(QLds &L, QState &t, int lane)
     if (t.n_free > 0) id = rfl(L.free_list[--t.n_free]);
     else if (t.n_alloc < L.node_cap) id = t.n_alloc++;
     else { t.overflow = true; id = L.node_cap - 1; }
-    if (lane == 0) L.seq[id] = t.seq;
+    if (lane == 0) L.seq[id] = (unsigned short)t.seq;
     t.seq++;
     return id;
 }
@@ -408,7 +416,7 @@ __device__ __forceinline__ int chunk_rank(bool valid, int q, int lane, int c[4])
 
 // ExtractorNode::DivideNode (ORBextractor.cpp:430-485): stable 4-way partition of the node's keys,
 // children created for the non-empty quadrants (ch[q] = node id or -1, cnt[q] = its key count)
-__device__ inline void qt_divide(QLds &L, QState &t, uint2 *keys, uint2 *gtmp, bool keys_global, int id, int ch[4],
+__device__ inline void qt_divide(QLds &L, QState &t, const KeyArr keys, const KeyArr gtmp, bool keys_global, int id, int ch[4],
                                  int cnt[4], int cseq[4], int lane)
 {
     const QBox P = L.box[id];
@@ -418,44 +426,44 @@ __device__ inline void qt_divide(QLds &L, QState &t, uint2 *keys, uint2 *gtmp, b
     cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
     if (n <= 64) {
         const bool valid = lane < n;
-        const uint2 k = valid ? keys[beg + lane] : make_uint2(0, 0);
+        const uint2 k = valid ? keys.get(beg + lane) : make_uint2(0, 0);
         const int q = key_quadrant(k, midx, midy);
         const int r = chunk_rank(valid, q, lane, cnt);
         const int off = q == 0 ? 0 : (q == 1 ? cnt[0] : (q == 2 ? cnt[0] + cnt[1] : cnt[0] + cnt[1] + cnt[2]));
-        if (valid) keys[beg + off + r] = k;
+        if (valid) keys.set(beg + off + r, k);
     } else if (n <= 512) {
         uint2 k[8];
         int q[8], r[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const bool valid = lane + 64 * c < n;
-            k[c] = valid ? keys[beg + lane + 64 * c] : make_uint2(0, 0);
+            k[c] = valid ? keys.get(beg + lane + 64 * c) : make_uint2(0, 0);
             q[c] = key_quadrant(k[c], midx, midy);
             r[c] = chunk_rank(valid, q[c], lane, cnt);
         }
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const int off = q[c] == 0 ? 0 : (q[c] == 1 ? cnt[0] : (q[c] == 2 ? cnt[0] + cnt[1] : cnt[0] + cnt[1] + cnt[2]));
-            if (lane + 64 * c < n) keys[beg + off + r[c]] = k[c];
+            if (lane + 64 * c < n) keys.set(beg + off + r[c], k[c]);
         }
     } else {
         for (int base = 0; base < n; base += 64) {
             const bool valid = base + lane < n;
-            const uint2 k = valid ? keys[beg + base + lane] : make_uint2(0, 0);
+            const uint2 k = valid ? keys.get(beg + base + lane) : make_uint2(0, 0);
             chunk_rank(valid, key_quadrant(k, midx, midy), lane, cnt);
         }
         int run[4] = {0, 0, 0, 0};
         const int o1 = cnt[0], o2 = cnt[0] + cnt[1], o3 = cnt[0] + cnt[1] + cnt[2];
         for (int base = 0; base < n; base += 64) {
             const bool valid = base + lane < n;
-            const uint2 k = valid ? keys[beg + base + lane] : make_uint2(0, 0);
+            const uint2 k = valid ? keys.get(beg + base + lane) : make_uint2(0, 0);
             const int q = key_quadrant(k, midx, midy);
             const int r = chunk_rank(valid, q, lane, run);
             const int off = q == 0 ? 0 : (q == 1 ? o1 : (q == 2 ? o2 : o3));
-            if (valid) gtmp[off + r] = k;
+            if (valid) gtmp.set(off + r, k);
         }
         __threadfence();
-        for (int i = lane; i < n; i += 64) keys[beg + i] = gtmp[i];
+        for (int i = lane; i < n; i += 64) keys.set(beg + i, gtmp.get(i));
     }
     if (keys_global) __threadfence();
     const int cbeg[4] = {beg, beg + cnt[0], beg + cnt[0] + cnt[1], beg + cnt[0] + cnt[1] + cnt[2]};
@@ -469,7 +477,7 @@ __device__ inline void qt_divide(QLds &L, QState &t, uint2 *keys, uint2 *gtmp, b
         const int nid = qt_new(L, t, lane);
         if (lane == 0) {
             QBox c; c.ulx = (short)cul[q][0]; c.uly = (short)cul[q][1]; c.brx = (short)cbr[q][0]; c.bry = (short)cbr[q][1];
-            L.box[nid] = c; L.begin[nid] = cbeg[q]; L.count[nid] = cnt[q];
+            L.box[nid] = c; L.begin[nid] = (unsigned short)cbeg[q]; L.count[nid] = (unsigned short)cnt[q];
         }
         ch[q] = nid;
     }
@@ -511,8 +519,11 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
     const int W = a.g.w[l], H = a.g.h[l];
     const int minX = 16, maxX = W - 16, minY = 16, maxY = H - 16, N = a.g.quota[l];
     const bool keys_global = nkeys > kLdsKeys;
-    uint2 *keys = keys_global ? a.gkeys + (int64_t)inst * a.cand_cap : L.keys;
-    uint2 *gtmp = a.gtmp + (int64_t)inst * a.cand_cap;
+    // global scratch of an instance: cand_cap x 8 bytes = one xy plane + one index plane
+    KeyArr gk, gtmp;
+    gk.xy = (uint32_t *)(a.gkeys + (int64_t)inst * a.cand_cap); gk.id = (uint16_t *)(gk.xy + a.cand_cap);
+    gtmp.xy = (uint32_t *)(a.gtmp + (int64_t)inst * a.cand_cap); gtmp.id = (uint16_t *)(gtmp.xy + a.cand_cap);
+    const KeyArr keys = keys_global ? gk : L.keys;
     QState t;
     t.n_free = 0; t.n_alloc = 0; t.head = t.tail = -1; t.size = 0; t.seq = 0; t.overflow = false;
     if (maxX <= minX || maxY <= minY || nkeys == 0) { if (lane == 0) a.sel_cnt[inst] = 0; return; }
@@ -535,8 +546,7 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
                 const float4 c = c4[u];
                 const bool mine = k < nkeys && min((int)(c.x / hX), nIni - 1) == i;
                 const unsigned long long m = __ballot(mine);
-                if (mine) keys[filled + __popcll(m & lt)] = make_uint2((uint32_t)(int)c.x | ((uint32_t)(int)c.y << 16),
-                                                                       (uint32_t)k | ((uint32_t)(int)c.z << 24));
+                if (mine) keys.set(filled + __popcll(m & lt), make_uint2((uint32_t)(int)c.x | ((uint32_t)(int)c.y << 16), (uint32_t)k));
                 filled += __popcll(m);
             }
         }
@@ -544,7 +554,7 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
         if (lane == 0) {
             QBox bx; bx.ulx = (short)(int)(hX * (float)i); bx.uly = 0; bx.brx = (short)(int)(hX * (float)(i + 1));
             bx.bry = (short)(maxY - minY);
-            L.box[id] = bx; L.begin[id] = start; L.count[id] = filled - start;
+            L.box[id] = bx; L.begin[id] = (unsigned short)start; L.count[id] = (unsigned short)(filled - start);
         }
         qt_push_back(L, t, id, lane);
     }
@@ -607,13 +617,15 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
     for (int i = t.head; i >= 0 && m < a.sel_cap; i = rfl(L.next[i])) { if (lane == 0) order[m] = i; m++; }
     for (int j = lane; j < m; j += 64) {
         const int id = order[j], beg = L.begin[id], n = L.count[id];
-        uint32_t best = 0;
-        for (int k = 0; k < n; k++) {
-            const uint32_t y = keys[beg + k].y;
-            const uint32_t sc = (y & 0xFF000000u) | (0xFFFFFFu - (y & 0xFFFFFFu));
-            best = max(best, sc);
+        // keys of a node are in candidate order: the first maximum is the smallest index among the maxima
+        int best = keys.id[beg];
+        float maxR = cand[best].z;
+        for (int k = 1; k < n; k++) {
+            const int c = keys.id[beg + k];
+            const float r = cand[c].z;
+            if (r > maxR) { best = c; maxR = r; }
         }
-        sel[j] = (int)(0xFFFFFFu - (best & 0xFFFFFFu));
+        sel[j] = best;
     }
     if (lane == 0) {
         a.sel_cnt[inst] = m;
@@ -1040,8 +1052,8 @@ void orb_make_tables(const OrbGeom &g, std::vector<int2> &xt, std::vector<int4> 
 int orb_alloc(svo_ctx *ctx)
 {
     if (ctx->orb_ready) return SVO_OK;
-    if (ctx->cfg.max_keypoints > 65536) {          // the matcher packs (distance, train index) into 32 bits
-        ctx->err = "ORB mode: max_keypoints must be <= 65536";
+    if (ctx->cfg.max_keypoints > 16384) {          // 16-bit indices: matcher keys, quadtree candidate indices (4 x max_keypoints)
+        ctx->err = "ORB mode: max_keypoints must be <= 16384";
         return SVO_ERR_ARG;
     }
     OrbGeom &g = ctx->orb_geom;
