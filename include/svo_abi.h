@@ -213,6 +213,21 @@ int svo_wait_upload(svo_ctx *ctx, int buf);
 int svo_track_uploaded(svo_ctx *ctx, int buf, int n_frames, const double *pose0,
                        svo_step_result *results, int results_mem);
 
+/* Read-back of the online state (after svo_add_frame), for callers that keep the reference's
+ * per-frame carriers or draw what Tracking::displayTracking drew (src/tracking.cpp:345-382):
+ *   svo_get_frame_keypoints : the keypoints detected on the frame just added.  LK mode: the
+ *       cv::FAST corners of the LEFT image, in cv::FAST order, as the cv::KeyPoint records
+ *       Detect_OpenCVFASTFeatures pushes into Frame::features_left_ (src/tracking.cpp:94-113);
+ *       side must be 0.  ORB mode: side 0 / 1 = left / right ORB keypoints and, if `descriptors`
+ *       is not NULL, their n x 32 descriptor bytes (Frame::left_/right_Descriptors_, :511-526).
+ *   svo_get_last_tracks : the matched tracks that fed the pose solver for the pair just tracked
+ *       (t1_left, t1_right, t2_right -- zeros in ORB mode --, t2_left) and the RANSAC inlier flags;
+ *       n = 0 when the step stopped before matching.  Any output pointer may be NULL.
+ * Host pointers; capacities in elements; SVO_ERR_ARG when a capacity is too small. */
+int svo_get_frame_keypoints(svo_ctx *ctx, int side, svo_keypoint *kps, uint8_t *descriptors, int cap, int *n_out);
+int svo_get_last_tracks(svo_ctx *ctx, svo_pt2f *t1_left, svo_pt2f *t1_right, svo_pt2f *t2_right,
+                        svo_pt2f *t2_left, uint8_t *inlier, int cap, int *n_out);
+
 /* Serial prefix product of n inverse relative motions (svo_step_result.T_rel_inv, row-major 4x4),
  * skipping pairs with ok == 0:  poses_out[p] = pose0 * prod_{q <= p, ok[q]} T[q]  -- the
  * `frame_pose_ = frame_pose_ * T.inv()` recurrence of reference src/tracking.cpp:318 for frame

@@ -87,6 +87,8 @@ def load_library():
     lib.svo_default_config.restype = None
     lib.svo_track_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_int]
+    lib.svo_get_frame_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    lib.svo_get_last_tracks.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int, C.POINTER(C.c_int)]
     lib.svo_chain_relative.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     lib.svo_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
     lib.svo_host_free.argtypes = [C.c_void_p, C.c_void_p]
@@ -427,3 +429,21 @@ class Context:
             tp, op_, up, mem = C.c_void_p(T.data_ptr()), C.c_void_p(okc.data_ptr()), C.c_void_p(out.data_ptr()), MEM_DEVICE
         self._check(self.lib.svo_chain_relative(self.h, tp, op_, int(T.shape[0]), p0, up, mem))
         return out
+
+    def frame_keypoints(self, side=0, with_descriptors=False, cap=65536):
+        """Keypoints detected on the frame last given to add_frame (svo_get_frame_keypoints)."""
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8) if with_descriptors else None
+        n = C.c_int(0)
+        self._check(self.lib.svo_get_frame_keypoints(self.h, int(side), C.c_void_p(kps.ctypes.data),
+                                                     C.c_void_p(desc.ctypes.data) if with_descriptors else None, cap, C.byref(n)))
+        return (kps[:n.value].copy(), desc[:n.value].copy()) if with_descriptors else kps[:n.value].copy()
+
+    def last_tracks(self, cap=65536):
+        """(t1_left, t1_right, t2_right, t2_left, inlier) of the pair last tracked by add_frame."""
+        pts = [np.zeros((cap, 2), np.float32) for _ in range(4)]
+        inl = np.zeros(cap, np.uint8)
+        n = C.c_int(0)
+        self._check(self.lib.svo_get_last_tracks(self.h, *[C.c_void_p(p.ctypes.data) for p in pts], C.c_void_p(inl.ctypes.data),
+                                                 cap, C.byref(n)))
+        return [p[:n.value].copy() for p in pts] + [inl[:n.value].copy()]

@@ -459,6 +459,9 @@ static size_t ws_off_pose0(const svo_config &cfg, int n_items)
     return (ws_off_mask(n_items) + (size_t)n_items * cfg.max_keypoints + 255) / 256 * 256;
 }
 
+// RANSAC inlier flags of batch item 0 (the online pair): max_keypoints bytes
+const uint8_t *pnp_inlier_mask(const svo_ctx *ctx) { return (const uint8_t *)ctx->pnp_ws + ws_off_mask(ctx->cfg.max_batch); }
+
 int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
 {
     *bytes = ws_off_pose0(cfg, n_items) + 256;

@@ -244,7 +244,7 @@ int pipeline_add_frame(svo_ctx *ctx, const uint8_t *left, const uint8_t *right, 
         res->ok = 1; res->n_cur_kps = *h_n;
         for (int i = 0; i < 9; i++) res->R[i] = (i % 4 == 0) ? 1.0 : 0.0;
         for (int i = 0; i < 16; i++) { res->T_rel_inv[i] = (i % 5 == 0) ? 1.0 : 0.0; res->pose[i] = ctx->pose[i]; }
-        ctx->online_frames = 1; ctx->online_cur = cur;
+        ctx->online_frames = 1; ctx->online_cur = cur; ctx->online_tracked = 0;
         return SVO_OK;
     }
     rc = run_pairs(ctx, 1, prev, cur, 0, ctx->pose, nullptr);
@@ -254,6 +254,7 @@ int pipeline_add_frame(svo_ctx *ctx, const uint8_t *left, const uint8_t *right, 
     SVO_HIP(hipMemcpyAsync(h, ctx->d_results, sizeof(svo_step_result), hipMemcpyDeviceToHost, ctx->stream));
     SVO_HIP(hipStreamSynchronize(ctx->stream));
     *res = *h;
+    ctx->online_tracked = res->n_tracked;
     memcpy(ctx->pose, res->pose, sizeof(ctx->pose));
     ctx->online_frames++; ctx->online_cur = cur;       // last_frame_ = current_frame_ on both outcomes (:59-68)
     return res->ok ? SVO_OK : res->fail_stage;

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 #include "svo_ctx.h"
 
 using namespace svo;
@@ -721,4 +722,78 @@ extern "C" int svo_chain_relative(svo_ctx *ctx, const double *T_rel_inv, const i
     if (!ctx) return SVO_ERR_ARG;
     SVO_HIP(hipSetDevice(ctx->device));
     return stage_chain_relative(ctx, T_rel_inv, ok, n, pose0, poses_out, mem);
+}
+
+// ---- read-back of the online state: what the reference keeps in Frame::features_* / shows in
+// displayTracking ------------------------------------------------------------------------------
+extern "C" int svo_get_frame_keypoints(svo_ctx *ctx, int side, svo_keypoint *kps, uint8_t *descriptors, int cap, int *n_out)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(n_out && cap >= 0 && (kps || cap == 0), "null output");
+    SVO_ARG(side == 0 || side == 1, "side must be 0 (left) or 1 (right)");
+    SVO_ARG(ctx->online_frames > 0, "no frame has been added");
+    SVO_HIP(hipSetDevice(ctx->device));
+    if (svo_wait_results(ctx) != SVO_OK) return SVO_ERR_HIP;
+    const int cur = ctx->online_cur;
+    *n_out = 0;
+    if (ctx->cfg.track_mode == SVO_MODE_ORB) {
+        const int slot = 2 * cur + side, kcap = ctx->orb_kp_cap;
+        int n = 0;
+        SVO_HIP(hipMemcpyAsync(&n, ctx->orb_n + slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SVO_HIP(hipStreamSynchronize(ctx->stream));
+        n = n < kcap ? n : kcap;
+        SVO_ARG(n <= cap, "keypoint capacity too small");
+        if (n > 0) {
+            SVO_HIP(hipMemcpyAsync(kps, (const svo_keypoint *)ctx->orb_kps + (size_t)slot * kcap, sizeof(svo_keypoint) * n,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+            if (descriptors)
+                SVO_HIP(hipMemcpyAsync(descriptors, ctx->orb_desc + (size_t)slot * kcap * 32, (size_t)32 * n, hipMemcpyDeviceToHost,
+                                       ctx->stream));
+            SVO_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        *n_out = n;
+        return SVO_OK;
+    }
+    SVO_ARG(side == 0, "LK mode detects on the left image only (src/tracking.cpp:94-113)");
+    const int kcap = ctx->cfg.max_keypoints;
+    int n = 0;
+    SVO_HIP(hipMemcpyAsync(&n, ctx->kp_n + cur, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    n = n < kcap ? n : kcap;
+    SVO_ARG(n <= cap, "keypoint capacity too small");
+    if (n > 0) {
+        std::vector<float2> xy((size_t)n);
+        std::vector<float> resp((size_t)n);
+        SVO_HIP(hipMemcpyAsync(xy.data(), ctx->kp_xy + (size_t)cur * kcap, sizeof(float2) * n, hipMemcpyDeviceToHost, ctx->stream));
+        SVO_HIP(hipMemcpyAsync(resp.data(), ctx->kp_resp + (size_t)cur * kcap, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+        SVO_HIP(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < n; i++) {                   // the cv::KeyPoint cv::FAST produces
+            kps[i].x = xy[i].x; kps[i].y = xy[i].y; kps[i].size = 7.f; kps[i].angle = -1.f;
+            kps[i].response = resp[i]; kps[i].octave = 0; kps[i].class_id = -1;
+        }
+    }
+    *n_out = n;
+    return SVO_OK;
+}
+
+extern "C" int svo_get_last_tracks(svo_ctx *ctx, svo_pt2f *t1_left, svo_pt2f *t1_right, svo_pt2f *t2_right,
+                                   svo_pt2f *t2_left, uint8_t *inlier, int cap, int *n_out)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(n_out && cap >= 0, "null output");
+    SVO_HIP(hipSetDevice(ctx->device));
+    if (svo_wait_results(ctx) != SVO_OK) return SVO_ERR_HIP;
+    const int n = ctx->online_frames >= 2 ? ctx->online_tracked : 0;
+    SVO_ARG(n <= cap, "track capacity too small");
+    *n_out = n;
+    if (n == 0) return SVO_OK;
+    svo_pt2f *dst[4] = {t1_left, t1_right, t2_right, t2_left};
+    for (int k = 0; k < 4; k++) {
+        if (!dst[k]) continue;
+        if (k == 2 && ctx->cfg.track_mode == SVO_MODE_ORB) { memset(dst[k], 0, sizeof(svo_pt2f) * (size_t)n); continue; }
+        SVO_HIP(hipMemcpyAsync(dst[k], ctx->cmp[k], sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (inlier) SVO_HIP(hipMemcpyAsync(inlier, pnp_inlier_mask(ctx), (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    return SVO_OK;
 }

@@ -42,6 +42,7 @@ struct svo_ctx {
     // ---- online state (svo_add_frame)
     int online_frames = 0;            // frames fed since reset
     int online_cur = 0;               // which half of the 2-frame ring holds the latest frame
+    int online_tracked = 0;           // tracks of the last svo_add_frame pair (0 when it stopped before matching)
     double pose[16];
     // ---- ORB path (allocated on first use: orb_alloc)
     bool orb_ready = false;
@@ -104,6 +105,7 @@ void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n
 // orb.hip
 int orb_alloc(svo_ctx *ctx);
 void orb_free(svo_ctx *ctx);
+const uint8_t *pnp_inlier_mask(const svo_ctx *ctx);
 int stage_chain_relative(svo_ctx *ctx, const double *T, const int32_t *ok, int n, const double *pose0_host, double *out, int mem);
 int stage_host_image(svo_ctx *ctx, const uint8_t *img, int pitch, int stage_idx, const uint8_t **dptr, int *dpitch);
 int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int pitch, int64_t img_stride, int slot0,

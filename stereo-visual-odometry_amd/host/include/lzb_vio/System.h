@@ -27,6 +27,8 @@ public:
 
     // additive: write one KITTI-format pose row (12 numbers of [R|t]) per frame
     bool SetPoseFile(const std::string &path);
+    // additive: per-frame track dump (text), the headless replacement of displayTracking
+    bool SetTracksFile(const std::string &path);
     Tracking::Ptr GetTracking() { return tracking_; }
     int FramesProcessed() const { return current_image_index_; }
 
@@ -37,6 +39,7 @@ private:
     void Reset();
     void WritePose();
     void WritePoseRow(const double *pose16);
+    void WriteTracks();
     bool ReadStereo(int index, cv::Mat &left, cv::Mat &right);
 
     std::string config_file_path_;
@@ -46,7 +49,7 @@ private:
     int current_image_index_ = 0;
     bool inited_ = false;
     std::string dataset_path_;
-    FILE *pose_file_ = nullptr;
+    FILE *pose_file_ = nullptr, *tracks_file_ = nullptr;
 };
 
 // 8-bit grayscale image readers used by NextFrame_kitti: binary PGM (P5) and PNG (8-bit gray or

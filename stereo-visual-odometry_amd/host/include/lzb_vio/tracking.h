@@ -30,7 +30,10 @@ public:
     // additive (the reference has no getter for frame_pose_)
     Pose4x4 GetPose() const { return frame_pose_; }
     const svo_step_result &LastResult() const { return last_; }
-    void SetFillFeatures(bool on) { fill_features_ = on; }   // populate Frame::features_left_ (costs a D2H)
+    void SetFillFeatures(bool on) { fill_features_ = on; }   // populate Frame::features_* / *_Descriptors_ (costs a D2H)
+    // the matched tracks of the pair just tracked + RANSAC inlier flags (what displayTracking drew)
+    bool GetLastTracks(std::vector<cv::Point2f> &t1_left, std::vector<cv::Point2f> &t1_right,
+                       std::vector<cv::Point2f> &t2_left, std::vector<unsigned char> &inlier);
 
     // additive: batched tracking of host-resident frames.  The context is
     // (re)created for `max_batch` frame pairs per launch; frames travel with svo_upload_frames and
@@ -46,6 +49,7 @@ private:
     bool LK_StereoF2F_PnP_Track();
     bool ORB_StereoF2F_PnP_Track();
     bool TrackOnGpu();
+    void FillFeatures();
     void Readparameter();
     bool EnsureContext(int width, int height, int max_batch = 1);
 

@@ -122,11 +122,37 @@ System::System(std::string &config_path) : config_file_path_(config_path)
     tracking_ = Tracking::Ptr(new Tracking(this, init_parameter_, sensors_));
     dataset_path_ = init_parameter_->dataset_path_;
     if (Config::Has("pose_file")) SetPoseFile(Config::Get<std::string>("pose_file"));   // additive key
+    // additive keys: the headless stand-in for Tracking::displayTracking (src/tracking.cpp:345-382) and
+    // the reference's per-frame Feature carriers
+    if (Config::Has("tracks_file")) SetTracksFile(Config::Get<std::string>("tracks_file"));
+    if (Config::Has("fill_features") && Config::Get<int>("fill_features") != 0) tracking_->SetFillFeatures(true);
 }
 
 System::~System()
 {
     if (pose_file_) fclose(pose_file_);
+    if (tracks_file_) fclose(tracks_file_);
+}
+
+bool System::SetTracksFile(const std::string &path)
+{
+    if (tracks_file_) fclose(tracks_file_);
+    tracks_file_ = fopen(path.c_str(), "w");
+    if (tracks_file_) fprintf(tracks_file_, "# F frame ok fail_stage n_cur_kps n_tracked n_inliers / T x1l y1l x1r y1r x2l y2l inlier\n");
+    return tracks_file_ != nullptr;
+}
+
+// one record per frame + one row per matched track: the data displayTracking draws as lines/circles
+void System::WriteTracks()
+{
+    if (!tracks_file_) return;
+    const svo_step_result &r = tracking_->LastResult();
+    fprintf(tracks_file_, "F %d %d %d %d %d %d\n", current_image_index_ - 1, r.ok, r.fail_stage, r.n_cur_kps, r.n_tracked, r.n_inliers);
+    std::vector<cv::Point2f> a, b, c;
+    std::vector<unsigned char> in;
+    if (!tracking_->GetLastTracks(a, b, c, in)) return;
+    for (size_t i = 0; i < a.size(); i++)
+        fprintf(tracks_file_, "T %.4f %.4f %.4f %.4f %.4f %.4f %d\n", a[i].x, a[i].y, b[i].x, b[i].y, c[i].x, c[i].y, (int)in[i]);
 }
 
 bool System::SetPoseFile(const std::string &path)
@@ -172,6 +198,7 @@ bool System::Step()
     double dt = std::chrono::duration_cast<std::chrono::duration<double>>(t2 - t1).count();
     if (getenv("LZB_VIO_VERBOSE")) LZB_LOG("INFO", "VO cost time: %f seconds (%s)", dt, success ? "ok" : "skipped");
     WritePose();
+    WriteTracks();
     return true;                                           // the reference ignores AddFrame's result here (:53,58)
 }
 
@@ -180,6 +207,7 @@ bool System::Step_ros(Frame::Ptr new_frame)
     if (new_frame == nullptr) return false;
     bool success = tracking_->AddFrame(new_frame);
     WritePose();
+    WriteTracks();
     return success;
 }
 

@@ -116,12 +116,68 @@ static bool feed(svo_ctx *ctx, Frame::Ptr f, svo_step_result *res, int *rc_out)
     return *rc_out == SVO_OK;
 }
 
+// Frame::features_left_ / features_right_ / *_Descriptors_ as the reference's detectors leave them
+// (Detect_OpenCVFASTFeatures src/tracking.cpp:94-113, Detect_MyORBFeatures :502-532); optional
+// because it costs a device-to-host copy and N heap allocations per frame.
+void Tracking::FillFeatures()
+{
+    if (!fill_features_ || !ctx_ || !current_frame_) return;
+    const bool orb = track_mode_ == "ORB_stereof2f_pnp";
+    std::vector<svo_keypoint> kps(65536);
+    std::vector<uint8_t> desc;
+    if (orb) desc.resize(kps.size() * 32);
+    for (int side = 0; side < (orb ? 2 : 1); side++) {
+        int n = 0;
+        if (svo_get_frame_keypoints(ctx_, side, kps.data(), orb ? desc.data() : nullptr, (int)kps.size(), &n) != SVO_OK) {
+            LZB_LOG("ERROR", "svo_get_frame_keypoints: %s", svo_last_error(ctx_));
+            return;
+        }
+        auto &dst = side == 0 ? current_frame_->features_left_ : current_frame_->features_right_;
+        dst.clear();
+        dst.reserve((size_t)n);
+        for (int i = 0; i < n; i++) {
+            cv::KeyPoint kp;
+            kp.pt.x = kps[i].x; kp.pt.y = kps[i].y; kp.size = kps[i].size; kp.angle = kps[i].angle;
+            kp.response = kps[i].response; kp.octave = kps[i].octave; kp.class_id = kps[i].class_id;
+            Feature::Ptr f(new Feature(current_frame_, kp));
+            f->is_on_left_image_ = side == 0;
+            dst.push_back(f);
+        }
+        if (orb) {
+            cv::Mat &D = side == 0 ? current_frame_->left_Descriptors_ : current_frame_->right_Descriptors_;
+            D.create(n > 0 ? n : 1, 32);
+            D.rows = n;
+            for (int i = 0; i < n; i++) memcpy(D.ptr(i), desc.data() + (size_t)i * 32, 32);
+        }
+    }
+}
+
+bool Tracking::GetLastTracks(std::vector<cv::Point2f> &t1_left, std::vector<cv::Point2f> &t1_right,
+                             std::vector<cv::Point2f> &t2_left, std::vector<unsigned char> &inlier)
+{
+    t1_left.clear(); t1_right.clear(); t2_left.clear(); inlier.clear();
+    if (!ctx_) return false;
+    const int cap = last_.n_tracked > 0 ? last_.n_tracked : 0;
+    std::vector<svo_pt2f> a((size_t)cap + 1), b((size_t)cap + 1), c((size_t)cap + 1);
+    inlier.resize((size_t)cap + 1);
+    int n = 0;
+    if (svo_get_last_tracks(ctx_, a.data(), b.data(), nullptr, c.data(), inlier.data(), cap, &n) != SVO_OK) return false;
+    inlier.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+        t1_left.push_back(cv::Point2f{a[i].x, a[i].y});
+        t1_right.push_back(cv::Point2f{b[i].x, b[i].y});
+        t2_left.push_back(cv::Point2f{c[i].x, c[i].y});
+    }
+    return true;
+}
+
 bool Tracking::StereoInit_f2f()
 {
     if (!EnsureContext(current_frame_->left_img_.cols, current_frame_->left_img_.rows)) return false;
     svo_reset(ctx_);
     int rc;
     feed(ctx_, current_frame_, &last_, &rc);
+    FillFeatures();
     last_frame_ = current_frame_;
     status_ = TrackingStatus::TRACKING_GOOD;
     return rc >= 0;
@@ -144,6 +200,7 @@ bool Tracking::TrackOnGpu()
     int rc;
     bool ok = feed(ctx_, current_frame_, &last_, &rc);
     if (rc < 0) return false;
+    FillFeatures();
     if (ok) {
         memcpy(frame_pose_.m, last_.pose, sizeof(frame_pose_.m));
         Px_ = frame_pose_.m[3]; Py_ = frame_pose_.m[7]; Pz_ = frame_pose_.m[11];

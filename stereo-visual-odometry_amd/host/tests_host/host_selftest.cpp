@@ -1,10 +1,50 @@
-// host_selftest -- CPU-only checks of the host mirror: YAML surface and image readers.
-// usage: host_selftest config.yaml image1 [image2 ...]; prints key=value lines for pytest.
+// host_selftest -- checks of the host mirror for pytest.
+//   host_selftest config.yaml image1 [image2 ...]      CPU only: YAML surface and image readers
+//   host_selftest --track config.yaml n_frames         GPU: Step_ros over <dataset_path>/image_{0,1}/%06d.{png,pgm}
+//                                                       with the per-frame carriers filled (fill_features)
 #include "lzb_vio/System.h"
+
+static int track_mode(int argc, char **argv)
+{
+    if (argc < 4) return 2;
+    std::string cfg = argv[2];
+    lzb_vio::System vo(cfg);
+    vo.GetTracking()->SetFillFeatures(true);
+    lzb_vio::Parameter p;
+    const int n = atoi(argv[3]);
+    for (int i = 0; i < n; i++) {
+        auto f = lzb_vio::Frame::CreateFrame();
+        char name[64];
+        bool ok = true;
+        for (int cam = 0; cam < 2 && ok; cam++) {
+            snprintf(name, sizeof(name), "/image_%d/%06d.png", cam, i);
+            ok = lzb_vio::ReadImageGray(p.dataset_path_ + name, cam == 0 ? f->left_img_ : f->right_img_);
+            if (!ok) {
+                snprintf(name, sizeof(name), "/image_%d/%06d.pgm", cam, i);
+                ok = lzb_vio::ReadImageGray(p.dataset_path_ + name, cam == 0 ? f->left_img_ : f->right_img_);
+            }
+        }
+        if (!ok) return 4;
+        bool good = vo.Step_ros(f);
+        std::vector<cv::Point2f> a, b, c;
+        std::vector<unsigned char> in;
+        vo.GetTracking()->GetLastTracks(a, b, c, in);
+        int n_in = 0;
+        for (unsigned char v : in) n_in += v != 0;
+        double sx = 0;
+        for (auto &ft : f->features_left_) sx += ft->position_.pt.x + 2.0 * ft->position_.pt.y + ft->position_.response;
+        printf("frame=%d good=%d featuresL=%zu featuresR=%zu descL=%d descR=%d tracks=%zu inliers=%d n_tracked=%d n_inliers=%d sumL=%.3f\n",
+               i, good ? 1 : 0, f->features_left_.size(), f->features_right_.size(), f->left_Descriptors_.rows,
+               f->right_Descriptors_.rows, a.size(), n_in, vo.GetTracking()->LastResult().n_tracked,
+               vo.GetTracking()->LastResult().n_inliers, sx);
+    }
+    return 0;
+}
 
 int main(int argc, char **argv)
 {
     if (argc < 2) return 2;
+    if (std::string(argv[1]) == "--track") return track_mode(argc, argv);
     if (!lzb_vio::Config::SetParameterFile(argv[1])) return 3;
     lzb_vio::Parameter p;
     printf("track_mode=%s\n", p.track_mode_.c_str());

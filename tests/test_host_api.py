@@ -179,3 +179,64 @@ def test_run_kitti_stereo_drop_in(host_built, pkg, small_seq, tmp_path):
         ref.append(c.get_pose()[:3])
     c.close()
     assert np.abs(poses_orb - np.array(ref)).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_frame_carriers_and_track_dump(host_built, pkg, oracle, small_seq, tmp_path):
+    """The reference's per-frame carriers (Frame::features_left_/right_, *_Descriptors_) filled from
+    the GPU state, and the headless displayTracking replacement (tracks_file), in both modes."""
+    seq, frames = small_seq
+    h, w = frames[0][0].shape
+    for cam in (0, 1):
+        os.makedirs(tmp_path / f"image_{cam}")
+    for t, (L, R) in enumerate(frames):
+        _write_pgm(tmp_path / "image_0" / f"{t:06d}.pgm", L)
+        _write_pgm(tmp_path / "image_1" / f"{t:06d}.pgm", R)
+    P1, P2 = seq.proj()
+    for mode in ("LK_stereof2f_pnp", "ORB_stereof2f_pnp"):
+        _write_yaml(tmp_path / "c.yaml", str(tmp_path), fx=seq.fx, fy=seq.fy, cx=seq.cx, cy=seq.cy, mode=mode)
+        with open(tmp_path / "c.yaml", "a", encoding="utf-8") as f:
+            f.write(f"tracks_file: {tmp_path}/tracks_{mode}.txt\n")
+        out = subprocess.run([os.path.join(host_built, "host_selftest"), "--track", str(tmp_path / "c.yaml"), str(len(frames))],
+                             capture_output=True)
+        assert out.returncode == 0, out.stderr.decode()
+        rows = [dict(kv.split("=") for kv in line.split()) for line in out.stdout.decode().splitlines() if line.startswith("frame=")]
+        assert len(rows) == len(frames)
+        # the C-ABI read-back through the Python binding on the same frames
+        kw = dict(P1=P1, P2=P2)
+        if mode.startswith("ORB"):
+            kw.update(track_mode=pkg.MODE_ORB, min_move2=0.05 ** 2, max_move2=10.0 ** 2)
+        c = pkg.Context(w, h, device=0, **kw)
+        for t, (L, R) in enumerate(frames):
+            rc, rec = c.add_frame(L, R)
+            r = rows[t]
+            if mode.startswith("ORB"):
+                kl, dl = c.frame_keypoints(0, with_descriptors=True)
+                kr, dr = c.frame_keypoints(1, with_descriptors=True)
+                okl, odl, _ = oracle.orb_extract(L)
+                okr, odr, _ = oracle.orb_extract(R)
+                assert kl.tobytes() == okl.tobytes() and dl.tobytes() == odl.tobytes()
+                assert kr.tobytes() == okr.tobytes() and dr.tobytes() == odr.tobytes()
+                assert int(r["featuresL"]) == len(kl) == int(r["descL"]) and int(r["featuresR"]) == len(kr) == int(r["descR"])
+            else:
+                kl = c.frame_keypoints(0)
+                assert kl.tobytes() == oracle.fast(L).tobytes()
+                assert int(r["featuresL"]) == len(kl) and int(r["featuresR"]) == 0
+            s = float((kl["x"].astype(np.float64) + 2.0 * kl["y"] + kl["response"]).sum())
+            assert abs(float(r["sumL"]) - s) < 1e-2
+            tr = c.last_tracks()
+            if t == 0:
+                assert len(tr[0]) == 0 and int(r["tracks"]) == 0
+            else:
+                assert len(tr[0]) == int(rec["n_tracked"]) == int(r["tracks"]) == int(r["n_tracked"])
+                assert int(tr[4].sum()) == int(rec["n_inliers"]) == int(r["inliers"]) == int(r["n_inliers"])
+                if not mode.startswith("ORB"):
+                    ref = c.circular_match  # the same tracks as the stage API on the ring slots is covered elsewhere
+                    assert np.all(tr[0][:, 0] >= 0) and tr[1].shape == tr[0].shape == tr[3].shape
+        c.close()
+        # the track dump written by System::Step_ros
+        lines = open(tmp_path / f"tracks_{mode}.txt").read().splitlines()
+        F = [ln.split() for ln in lines if ln.startswith("F ")]
+        T = [ln for ln in lines if ln.startswith("T ")]
+        assert len(F) == len(frames) and sum(int(f[5]) for f in F[1:]) == len(T)
+        assert sum(int(ln.split()[-1]) for ln in T) == sum(int(f[6]) for f in F[1:])
