@@ -106,23 +106,41 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)            # launches, events and the RCCL gather share one stream
     ctx.set_overlap(not args.no_overlap)          # pose stage of step k runs beside the front end of step k+1
-    results = torch.zeros((B, pkg.STEP_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    # two result buffers: step k's pose stage (side stream) fills one while the records of step k-1
+    # are gathered from the other -- the gather never waits for the pose stage it overlaps
+    res_buf = [torch.zeros((B, pkg.STEP_DTYPE.itemsize), dtype=torch.uint8, device=dev) for _ in range(2)]
     pose_off = pkg.STEP_DTYPE.fields["pose"][1]
     trel_off, ok_off = pkg.STEP_DTYPE.fields["T_rel_inv"][1], pkg.STEP_DTYPE.fields["ok"][1]
+    state = {"k": 0}
 
-    def step():
-        ctx.track_batch(Lv, Rv, results=results)
-        if by_pairs:       # chunks of ONE sequence: gather 17 doubles per pair, chain on rank 0
-            ctx.wait_results()
-            g = mg.gather_relative(mg.field_view(results, trel_off, B, 16), mg.int_field(results, ok_off, B), rank, world, dst=0)
+    def collect(res):
+        """The only inter-GPU traffic: per pair 16 doubles (poses) or 17 (relative motion + ok) to rank 0."""
+        if by_pairs:       # chunks of ONE sequence: gather, then chain on rank 0
+            g = mg.gather_relative(mg.field_view(res, trel_off, B, 16), mg.int_field(res, ok_off, B), rank, world, dst=0)
             if rank == 0:
                 ctx.chain_relative(g[0], g[1])
-        elif world > 1:    # the only inter-GPU traffic: 16 doubles per pair to rank 0 (RCCL gather)
+        elif world > 1:
+            mg.gather_poses(mg.poses_view(res, pose_off, B), rank, world, dst=0)
+
+    def step():
+        k = state["k"]
+        ctx.track_batch(Lv, Rv, results=res_buf[k & 1])
+        # svo_track_batch(k) has already ordered the context's stream after the pose stage of batch
+        # k-1 (it reuses that stage's buffers), so batch k-1's records are complete here
+        if k > 0 and (world > 1 or by_pairs):
+            collect(res_buf[(k - 1) & 1])
+        state["k"] = k + 1
+
+    def drain():
+        """Records of the last step: wait for its pose stage, then collect them."""
+        if state["k"] > 0 and (world > 1 or by_pairs):
             ctx.wait_results()
-            mg.gather_poses(mg.poses_view(results, pose_off, B), rank, world, dst=0)
+            collect(res_buf[(state["k"] - 1) & 1])
+        state["k"] = 0
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if not args.no_timing_marks:
         ctx.enable_timing(True)
@@ -133,6 +151,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()                                       # every step's records are collected inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -143,6 +162,7 @@ def main():
     ctx.sync()
     stage_ms = dict(ctx.get_timing()) if not args.no_timing_marks else {}
     ctx.enable_timing(False)
+    results = res_buf[(args.steps - 1) & 1]
     res = np.frombuffer(results.cpu().numpy().tobytes(), dtype=pkg.STEP_DTYPE)
     n_ok = int(res["ok"].sum())
     pts_total = int(res["n_prev_kps"].sum())

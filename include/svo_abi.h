@@ -233,7 +233,8 @@ int svo_get_last_tracks(svo_ctx *ctx, svo_pt2f *t1_left, svo_pt2f *t1_right, svo
  * `frame_pose_ = frame_pose_ * T.inv()` recurrence of reference src/tracking.cpp:318 for frame
  * pairs that were tracked as independent chunks (other launches, contexts or GPUs: SURVEY.md 8e
  * granularity 2).  pose0 is a HOST pointer (NULL = identity); T_rel_inv, ok and poses_out live where
- * `mem` says.  The call returns when poses_out is complete. */
+ * `mem` says.  SVO_MEM_HOST: the call returns when poses_out is complete; SVO_MEM_DEVICE: one
+ * launch in stream order on the context's stream, no host synchronisation. */
 int svo_chain_relative(svo_ctx *ctx, const double *T_rel_inv, const int32_t *ok, int n,
                        const double *pose0, double *poses_out, int mem);
 

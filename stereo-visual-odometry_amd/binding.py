@@ -428,7 +428,7 @@ class Context:
             out = torch.zeros_like(T)
             tp, op_, up, mem = C.c_void_p(T.data_ptr()), C.c_void_p(okc.data_ptr()), C.c_void_p(out.data_ptr()), MEM_DEVICE
         self._check(self.lib.svo_chain_relative(self.h, tp, op_, int(T.shape[0]), p0, up, mem))
-        return out
+        return out                      # device tensors: complete in stream order on the context's stream
 
     def frame_keypoints(self, side=0, with_descriptors=False, cap=65536):
         """Keypoints detected on the frame last given to add_frame (svo_get_frame_keypoints)."""

@@ -396,13 +396,14 @@ __device__ __forceinline__ double quad_bcast_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(64) void chain_relative_kernel(const double *T, const int *ok, int n, const double *pose0,
+struct Pose16 { double m[16]; };
+__global__ __launch_bounds__(64) void chain_relative_kernel(const double *T, const int *ok, int n, Pose16 pose0,
                                                             double *out)
 {
     __shared__ double sT[64 * 16];
     __shared__ int sOk[64];
     const int lane = threadIdx.x, i = (lane >> 2) & 3, j = lane & 3;
-    double P = pose0[i * 4 + j];
+    double P = pose0.m[i * 4 + j];
     for (int base = 0; base < n; base += 64) {
         const int cnt = min(64, n - base);
         __syncthreads();
@@ -428,26 +429,25 @@ int stage_chain_relative(svo_ctx *ctx, const double *T, const int32_t *ok, int n
     SVO_ARG(T && ok && out && n >= 0, "null pointer / negative count");
     SVO_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE, "bad mem");
     if (n == 0) return SVO_OK;
-    double p0[16];
-    for (int q = 0; q < 16; q++) p0[q] = pose0_host ? pose0_host[q] : (q % 5 == 0 ? 1.0 : 0.0);
-    double *d_p0 = nullptr, *dT = nullptr, *dOut = nullptr;
-    int *dOk = nullptr;
-    SVO_HIP(hipMalloc(&d_p0, sizeof(p0)));
-    SVO_HIP(hipMemcpyAsync(d_p0, p0, sizeof(p0), hipMemcpyHostToDevice, ctx->stream));
-    if (mem == SVO_MEM_HOST) {
-        SVO_HIP(hipMalloc(&dT, sizeof(double) * 16 * (size_t)n));
-        SVO_HIP(hipMalloc(&dOut, sizeof(double) * 16 * (size_t)n));
-        SVO_HIP(hipMalloc(&dOk, sizeof(int) * (size_t)n));
-        SVO_HIP(hipMemcpyAsync(dT, T, sizeof(double) * 16 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-        SVO_HIP(hipMemcpyAsync(dOk, ok, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    Pose16 p0;                                     // travels as a kernel argument: no copy, no allocation
+    for (int q = 0; q < 16; q++) p0.m[q] = pose0_host ? pose0_host[q] : (q % 5 == 0 ? 1.0 : 0.0);
+    if (mem == SVO_MEM_DEVICE) {                   // stream-ordered, nothing else to do
+        hipLaunchKernelGGL(chain_relative_kernel, dim3(1), dim3(64), 0, ctx->stream, T, (const int *)ok, n, p0, out);
+        SVO_HIP(hipGetLastError());
+        return SVO_OK;
     }
-    hipLaunchKernelGGL(chain_relative_kernel, dim3(1), dim3(64), 0, ctx->stream, mem == SVO_MEM_HOST ? dT : T,
-                       mem == SVO_MEM_HOST ? dOk : (const int *)ok, n, d_p0, mem == SVO_MEM_HOST ? dOut : out);
+    double *dT = nullptr, *dOut = nullptr;
+    int *dOk = nullptr;
+    SVO_HIP(hipMalloc(&dT, sizeof(double) * 16 * (size_t)n));
+    SVO_HIP(hipMalloc(&dOut, sizeof(double) * 16 * (size_t)n));
+    SVO_HIP(hipMalloc(&dOk, sizeof(int) * (size_t)n));
+    SVO_HIP(hipMemcpyAsync(dT, T, sizeof(double) * 16 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    SVO_HIP(hipMemcpyAsync(dOk, ok, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(chain_relative_kernel, dim3(1), dim3(64), 0, ctx->stream, dT, dOk, n, p0, dOut);
     SVO_HIP(hipGetLastError());
-    if (mem == SVO_MEM_HOST)
-        SVO_HIP(hipMemcpyAsync(out, dOut, sizeof(double) * 16 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    SVO_HIP(hipStreamSynchronize(ctx->stream));       // p0 (stack) and the temporaries are released below
-    (void)hipFree(d_p0); (void)hipFree(dT); (void)hipFree(dOut); (void)hipFree(dOk);
+    SVO_HIP(hipMemcpyAsync(out, dOut, sizeof(double) * 16 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(dT); (void)hipFree(dOut); (void)hipFree(dOk);
     return SVO_OK;
 }
 

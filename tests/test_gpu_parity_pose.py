@@ -328,6 +328,7 @@ def test_pair_sharding_chains_to_the_whole_sequence(pkg, tc, small_seq):
         got = c.chain_relative(T, ok)
         assert got.tobytes() == whole["pose"].reshape(-1, 16).tobytes()          # same association order
         got_d = c.chain_relative(tc.from_numpy(T).cuda(), tc.from_numpy(ok).cuda())
+        c.sync()                                             # device operands: stream-ordered, not host-synchronous
         assert got_d.cpu().numpy().tobytes() == got.tobytes()
         ref = mg.chain_relative(tc.from_numpy(T), tc.from_numpy(ok)).numpy().reshape(-1, 16)
         assert np.abs(ref - got).max() < 1e-12
