@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(OrbGeom g, uint8_t *slo
 
 // ---- per-cell FAST ---------------------------------------------------------------------------
 constexpr int kCellMax = 66;                 // wCell = ceil(width / floor(width / 30)) < 60, +6 overlap
+constexpr int kCellPitch = 72;               // LDS row pitch of a cell: kCellPitch + 3 bytes of dword-alignment slack, multiple of 4
 constexpr int kCellCap = 256;                // candidates kept per cell
 
 // FAST cornerness V = largest t for which the pixel is a FAST-9/16 corner (0 when < 1):
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
     // level (a static 66 x 66 worst case would cost 21.8 KB and starve the kernel of workgroups
     // while the previous batch's pose solver holds 74 KB per CU)
     extern __shared__ __attribute__((aligned(16))) uint8_t cf_smem[];
-    const int plane = (kCellMax * (g.hCell[l] + 6) + 15) & ~15;
+    const int plane = (kCellPitch * (g.hCell[l] + 6) + 15) & ~15;
     uint8_t *raw = cf_smem, *V = cf_smem + plane, *keep = cf_smem + 2 * plane;
     uint16_t *list = (uint16_t *)(cf_smem + 3 * plane);
     __shared__ int s_any, s_found, s_nlist, s_ncand;
@@ -174,10 +175,18 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
     auto row_of = [&](int i) { return (int)(((float)i + 0.5f) * inv_cw); };
     const uint8_t *img = slots + (int64_t)b * slot_stride + g.origin[l];
     if (tid == 0) { s_any = 0; s_found = 0; s_nlist = 0; s_ncand = 0; }
-    for (int i = tid; i < cw * ch; i += 256) {
-        int y = row_of(i), x = i - y * cw;
-        raw[y * kCellMax + x] = img[(int64_t)(y0 + y) * pitch + x0 + x];
+    // the cell as aligned dwords (rows of the level are 4-byte aligned; the cell's first column
+    // sits `ox` bytes into its first dword, so every LDS row is shifted by ox: rawc = raw + ox)
+    const int ox = x0 & 3, nd = (ox + cw + 3) >> 2;
+    {
+        const float inv_nd = 1.0f / (float)nd;
+        const uint8_t *src = img + (int64_t)y0 * pitch + (x0 - ox);
+        for (int i = tid; i < nd * ch; i += 256) {
+            const int y = (int)(((float)i + 0.5f) * inv_nd), c = i - y * nd;
+            ((uint32_t *)(raw + y * kCellPitch))[c] = *(const uint32_t *)(src + (int64_t)y * pitch + 4 * c);
+        }
     }
+    raw += ox;
     __syncthreads();
     // Cornerness only matters where it can reach minTh: a corner at threshold t needs one pixel
     // of each opposite pair (0,8), (4,12) beyond t, so positions failing that 4-pixel test at minTh
@@ -187,12 +196,12 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
         int pos = 0;
         if (i < cw * ch) {
             const int y = row_of(i), x = i - y * cw;
-            pos = y * kCellMax + x;
+            pos = y * kCellPitch + x;
             V[pos] = 0; keep[pos] = 0;
             if (x >= 3 && x < cw - 3 && y >= 3 && y < ch - 3) {
                 const uint8_t *c = &raw[pos];
                 const int v = c[0], t = lowTh;
-                const int d0 = v - c[3 * kCellMax], d8 = v - c[-3 * kCellMax], d4 = v - c[3], d12 = v - c[-3];
+                const int d0 = v - c[3 * kCellPitch], d8 = v - c[-3 * kCellPitch], d4 = v - c[3], d12 = v - c[-3];
                 alive = ((d0 > t || d8 > t) && (d4 > t || d12 > t)) || ((d0 < -t || d8 < -t) && (d4 < -t || d12 < -t));
             }
         }
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
         int pos = 0, v = 0;
         if (i < nlist) {
             pos = list[i];
-            v = fast_cornerness(&raw[pos], kCellMax);
+            v = fast_cornerness(&raw[pos], kCellPitch);
             V[pos] = (uint8_t)v;
             any |= v >= iniTh;
         }
@@ -244,8 +253,8 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
             int k = 0;
             if (s >= thr) {
 #define SC(o) (p[o] >= thr ? (int)p[o] : 0)
-                k = s > SC(-1) && s > SC(1) && s > SC(-kCellMax - 1) && s > SC(-kCellMax) && s > SC(-kCellMax + 1) &&
-                    s > SC(kCellMax - 1) && s > SC(kCellMax) && s > SC(kCellMax + 1);
+                k = s > SC(-1) && s > SC(1) && s > SC(-kCellPitch - 1) && s > SC(-kCellPitch) && s > SC(-kCellPitch + 1) &&
+                    s > SC(kCellPitch - 1) && s > SC(kCellPitch) && s > SC(kCellPitch + 1);
 #undef SC
             }
             keep[pos] = (uint8_t)k;
@@ -265,13 +274,13 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
         for (int i0 = 0; i0 < cw * ch; i0 += 64) {
             const int i = i0 + tid;
             int y = 0, x = 0, k = 0;
-            if (i < cw * ch) { y = row_of(i); x = i - y * cw; k = keep[y * kCellMax + x]; }
+            if (i < cw * ch) { y = row_of(i); x = i - y * cw; k = keep[y * kCellPitch + x]; }
             const unsigned long long m = __ballot(k != 0);
             if (k) {
                 const int idx = n + __popcll(m & ((1ull << tid) - 1ull));
                 if (idx < kCellCap)
                     out[idx] = make_float4((float)x + (float)(cj * wCell), (float)y + (float)(ci * hCell),
-                                           (float)V[y * kCellMax + x], 0.f);
+                                           (float)V[y * kCellPitch + x], 0.f);
             }
             n += __popcll(m);
         }
@@ -1155,7 +1164,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     for (int l = 0; l < L; l++)
         if (g.ncell[l] > 0)
             hipLaunchKernelGGL(orb_cellfast_kernel, dim3(g.ncell[l], 1, n_img), blk,
-                               (size_t)5 * ((kCellMax * (g.hCell[l] + 6) + 15) & ~15), st, g, slots, g.slot_bytes, l,
+                               (size_t)5 * ((kCellPitch * (g.hCell[l] + 6) + 15) & ~15), st, g, slots, g.slot_bytes, l,
                                ctx->cfg.orb_ini_th, ctx->cfg.orb_min_th, cell_cand, cell_cnt,
                                (int64_t)g.cells_total * kCellCap, (int64_t)g.cells_total);
     float4 *lvl_cand = ctx->orb_lvl_cand + (size_t)slot0 * L * kCandCap;
