@@ -94,54 +94,6 @@ __device__ inline int allsum_mod4(int v)
     return (int)(b[0] + b[1]);
 }
 
-// four wave-wide int32 sums (each must fit in int32); results are wave-uniform
-__device__ inline void wave_sum4_i32(int lane, int v0, int v1, int v2, int v3, int &s0, int &s1, int &s2, int &s3)
-{
-    const bool odd = lane & 1, b1 = lane & 2;
-    int k0 = odd ? v2 : v0, g0 = odd ? v0 : v2;
-    int k1 = odd ? v3 : v1, g1 = odd ? v1 : v3;
-    k0 += dpp_xor1(g0);
-    k1 += dpp_xor1(g1);
-    int k = b1 ? k1 : k0, g = b1 ? k0 : k1;
-    k += dpp_xor2(g);
-    k = allsum_mod4(k);                     // lane % 4: 0 -> v0, 1 -> v2, 2 -> v1, 3 -> v3
-    s0 = __builtin_amdgcn_readlane(k, 0);
-    s2 = __builtin_amdgcn_readlane(k, 1);
-    s1 = __builtin_amdgcn_readlane(k, 2);
-    s3 = __builtin_amdgcn_readlane(k, 3);
-}
-
-// Reduce-scatter of 16 per-lane values: lane l returns the 64-lane total of value index (l & 15).
-// Steps: quad xor-1 and xor-2 exchanges, row_ror:4 / row_ror:8 exchanges (every lane keeps the
-// half of its values whose index bit matches its lane bit and hands the other half over), then an
-// all-reduce across the four rows.  51 cross-lane/select instructions for 16 sums.
-__device__ inline int reduce_scatter16_i32(const int (&v)[16], int lane)
-{
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-    int a[8], b[4], c[2];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        int keep = b0 ? v[2 * i + 1] : v[2 * i], give = b0 ? v[2 * i] : v[2 * i + 1];
-        a[i] = keep + dpp_xor1(give);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int keep = b1 ? a[2 * i + 1] : a[2 * i], give = b1 ? a[2 * i] : a[2 * i + 1];
-        b[i] = keep + dpp_xor2(give);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        int keep = b2 ? b[2 * i + 1] : b[2 * i], give = b2 ? b[2 * i] : b[2 * i + 1];
-        c[i] = keep + dpp_ror4(give);
-    }
-    int keep = b3 ? c[1] : c[0], give = b3 ? c[0] : c[1];
-    int d = keep + dpp_ror8(give);
-    auto x = __builtin_amdgcn_permlane16_swap((unsigned)d, (unsigned)d, false, false);
-    d = (int)(x[0] + x[1]);
-    auto y = __builtin_amdgcn_permlane32_swap((unsigned)d, (unsigned)d, false, false);
-    return (int)(y[0] + y[1]);
-}
-
 // Reduce-scatter of 8 per-lane values v[2*slot + t] (slot 0..3, t 0..1) whose 64-lane totals may
 // exceed 32 bits (each |v| < 2^29).  Two exchange steps first add groups of four lanes in full
 // 32-bit precision; the 4-lane sums are then split into 16-bit halves, which are reduced
@@ -182,18 +134,6 @@ template <int Q>
 __device__ inline int quad_bcast(int v)
 {
     return __builtin_amdgcn_update_dpp(0, v, Q * 0x55, 0xF, 0xF, true);
-}
-
-// two wave-wide int32 sums
-__device__ inline void wave_sum2_i32(int lane, int v0, int v1, int &s0, int &s1)
-{
-    const bool odd = lane & 1;
-    int k = odd ? v1 : v0, g = odd ? v0 : v1;
-    k += dpp_xor1(g);
-    k += dpp_xor2(k);                       // parity-preserving
-    k = allsum_mod4(k);
-    s0 = __builtin_amdgcn_readlane(k, 0);
-    s1 = __builtin_amdgcn_readlane(k, 1);
 }
 
 // LDS traffic of ONE wave is ordered by the hardware queue; this only stops the compiler from
