@@ -12,5 +12,5 @@ for PMC in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_
   i=$((i+1))
   rocprofv3 --pmc $PMC --kernel-include-regex "svo::orb" --output-format csv -d /tmp/pmc_orb$i -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-pairs 0 --mode orb --batch 256 --no-timing-marks --no-overlap --frames-cache $CACHE > $R/gpurun_out/pmc_orb$i.log 2>&1; echo "pmc$i exit=$?"
   f=$(find /tmp/pmc_orb$i -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python3 $R/scripts_pmc_summary.py "$f" > $R/gpurun_out/pmc_orb$i.txt
+  [ -n "$f" ] && python3 $R/tools/gpu/pmc_summary.py "$f" > $R/gpurun_out/pmc_orb$i.txt
 done

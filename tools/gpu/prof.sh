@@ -16,6 +16,6 @@ for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   i=$((i+1))
   rocprofv3 --pmc $PMC --kernel-include-regex "svo::" --output-format csv -d /tmp/prof_pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --no-timing-marks --no-overlap --frames-cache $CACHE > $R/gpurun_out/prof_pmc$i.log 2>&1; echo "pmc$i exit=$?"
   f=$(find /tmp/prof_pmc$i -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python3 $R/scripts_pmc_summary.py "$f" > $R/gpurun_out/prof_pmc$i.txt
+  [ -n "$f" ] && python3 $R/tools/gpu/pmc_summary.py "$f" > $R/gpurun_out/prof_pmc$i.txt
 done
 cat $R/gpurun_out/prof_pmc*.txt | grep lk_kernel
