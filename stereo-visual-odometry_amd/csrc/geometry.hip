@@ -436,18 +436,21 @@ int stage_chain_relative(svo_ctx *ctx, const double *T, const int32_t *ok, int n
         SVO_HIP(hipGetLastError());
         return SVO_OK;
     }
-    double *dT = nullptr, *dOut = nullptr;
-    int *dOk = nullptr;
-    SVO_HIP(hipMalloc(&dT, sizeof(double) * 16 * (size_t)n));
-    SVO_HIP(hipMalloc(&dOut, sizeof(double) * 16 * (size_t)n));
-    SVO_HIP(hipMalloc(&dOk, sizeof(int) * (size_t)n));
-    SVO_HIP(hipMemcpyAsync(dT, T, sizeof(double) * 16 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    SVO_HIP(hipMemcpyAsync(dOk, ok, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(chain_relative_kernel, dim3(1), dim3(64), 0, ctx->stream, dT, dOk, n, p0, dOut);
+    // host operands: temporaries released on every exit path
+    struct DevBuf {
+        void *p = nullptr;
+        ~DevBuf() { if (p) (void)hipFree(p); }
+    } bT, bOut, bOk;
+    SVO_HIP(hipMalloc(&bT.p, sizeof(double) * 16 * (size_t)n));
+    SVO_HIP(hipMalloc(&bOut.p, sizeof(double) * 16 * (size_t)n));
+    SVO_HIP(hipMalloc(&bOk.p, sizeof(int) * (size_t)n));
+    SVO_HIP(hipMemcpyAsync(bT.p, T, sizeof(double) * 16 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    SVO_HIP(hipMemcpyAsync(bOk.p, ok, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(chain_relative_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)bT.p, (const int *)bOk.p, n, p0,
+                       (double *)bOut.p);
     SVO_HIP(hipGetLastError());
-    SVO_HIP(hipMemcpyAsync(out, dOut, sizeof(double) * 16 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipMemcpyAsync(out, bOut.p, sizeof(double) * 16 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     SVO_HIP(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(dT); (void)hipFree(dOut); (void)hipFree(dOk);
     return SVO_OK;
 }
 
