@@ -392,3 +392,38 @@ def test_ragged_batch_equals_online_sequence(pkg, tc, small_seq, mode):
     assert int(got[0]["ok"]) == 1 and int(got[4]["ok"]) == 1
     assert np.array_equal(got[2]["pose"], got[0]["pose"])         # the chain skipped the two failures
     c.close()
+
+
+def test_new_entry_points_reject_bad_arguments(pkg, tc, small_seq):
+    """Hard errors (SVO_ERR_ARG) instead of silent truncation or undefined behaviour."""
+    import ctypes as C
+    seq, frames = small_seq
+    h, w = frames[0][0].shape
+    P1, P2 = seq.proj()
+    c = pkg.Context(w, h, device=0, max_batch=2, P1=P1, P2=P2)
+    with pytest.raises(pkg.SvoError):
+        c.frame_keypoints(0)                                   # no frame added yet
+    c.add_frame(*frames[0])
+    with pytest.raises(pkg.SvoError):
+        c.frame_keypoints(1)                                   # LK mode detects on the left image only
+    with pytest.raises(pkg.SvoError):
+        c.frame_keypoints(0, cap=8)                            # capacity too small: error, not truncation
+    assert len(c.last_tracks()[0]) == 0
+    c.add_frame(*frames[1])
+    with pytest.raises(pkg.SvoError):
+        c.last_tracks(cap=4)
+    hl = c.host_frames(4)
+    with pytest.raises(pkg.SvoError):
+        c.upload_frames(0, hl, hl)                             # 4 frames > max_batch + 1
+    with pytest.raises(pkg.SvoError):
+        c.upload_frames(2, hl[:2], hl[:2])                     # buffer index
+    with pytest.raises(pkg.SvoError):
+        c.track_uploaded(1, 2)                                 # nothing uploaded into buffer 1
+    c.host_free(hl)
+    assert c.lib.svo_chain_relative(c.h, None, None, 3, None, None, pkg.MEM_HOST) < 0
+    assert c.chain_relative(np.zeros((0, 16)), np.zeros(0, np.int32)).shape == (0, 16)
+    c.close()
+    with pytest.raises(pkg.SvoError):
+        pkg.Context(w, h, device=0, track_mode=pkg.MODE_ORB, max_keypoints=1 << 15).orb_extract(frames[0][0])
+    with pytest.raises(pkg.SvoError):
+        pkg.Context(w, h, device=0, track_mode=pkg.MODE_ORB, orb_nfeatures=40000, orb_nlevels=1).orb_extract(frames[0][0])
