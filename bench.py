@@ -200,6 +200,16 @@ def main():
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "launch_ms": round(lk_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
+        elif stage_ms.get("orb_cellfast"):
+            # ORB mode: the largest kernel group is the per-cell FAST over the 8-level pyramid
+            # (3.09 W H bytes read per image; the candidate records are negligible)
+            cf_ms = stage_ms["orb_cellfast"]
+            alg_bytes = int(3.09 * W * H * 2 * (B + 1))
+            achieved = alg_bytes / (cf_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "orb_cellfast_kernel (8 launches per step, one per pyramid level)",
+                               "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                               "launch_ms": round(cf_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
         else:
             out["roofline"] = None
         # ---- cpu_baseline: the oracle (CPU restatement of the reference path) on a bounded sample

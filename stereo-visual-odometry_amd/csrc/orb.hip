@@ -1159,6 +1159,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     for (int l = 0; l < L; l++)
         hipLaunchKernelGGL(orb_blur_kernel, dim3((g.w[l] + 255) / 256, (g.h[l] + 4 * kBlurRows - 1) / (4 * kBlurRows), n_img),
                            dim3(64, 4), 0, st, g, slots, g.slot_bytes, l, blur, g.blur_total);
+    timing_mark(ctx, "orb_pyramid");
     float4 *cell_cand = ctx->orb_cell_cand + (size_t)slot0 * g.cells_total * kCellCap;
     int *cell_cnt = ctx->orb_cell_cnt + (size_t)slot0 * g.cells_total;
     for (int l = 0; l < L; l++)
@@ -1171,6 +1172,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     int *lvl_cnt = ctx->orb_lvl_cnt + (size_t)slot0 * L;
     hipLaunchKernelGGL(orb_gather_kernel, dim3(L, n_img), blk, 0, st, g, cell_cand, cell_cnt, (int64_t)g.cells_total * kCellCap,
                        (int64_t)g.cells_total, lvl_cand, lvl_cnt, kCandCap, ctx->orb_overflow);
+    timing_mark(ctx, "orb_cellfast");
     OrbDistArgs d{};
     d.g = g; d.lvl_cand = lvl_cand; d.lvl_cnt = lvl_cnt; d.cand_cap = kCandCap;
     d.gkeys = (uint2 *)ctx->orb_qkeys + (size_t)slot0 * L * kCandCap; d.gtmp = (uint2 *)ctx->orb_qtmp + (size_t)slot0 * L * kCandCap;
@@ -1178,6 +1180,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     d.overflow = ctx->orb_overflow;
     d.node_cap = ctx->orb_node_cap;
     hipLaunchKernelGGL(orb_distribute_kernel, dim3(L, n_img), dim3(64), qlds_bytes(ctx->orb_node_cap), st, d);
+    timing_mark(ctx, "orb_quadtree");
     OrbDescArgs e{};
     e.g = g; e.slots = slots; e.slot_stride = g.slot_bytes; e.blur = blur; e.blur_img_stride = g.blur_total;
     e.lvl_cand = lvl_cand; e.cand_cap = kCandCap; e.sel = d.sel; e.sel_cnt = d.sel_cnt; e.sel_cap = ctx->orb_node_cap;
@@ -1187,6 +1190,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     for (int l = 0; l < L; l++) max_kp += g.quota[l] + 8;
     if (max_kp > ctx->orb_kp_cap) max_kp = ctx->orb_kp_cap;
     hipLaunchKernelGGL(orb_describe_kernel, dim3((max_kp + 3) / 4, n_img), blk, 0, st, e);
+    timing_mark(ctx, "orb_describe");
     return SVO_OK;
 }
 

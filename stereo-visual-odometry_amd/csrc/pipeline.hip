@@ -14,7 +14,7 @@
 
 namespace svo {
 
-static void mark(svo_ctx *ctx, const char *name)
+void timing_mark(svo_ctx *ctx, const char *name)
 {
     if (!ctx->timing) return;
     if (ctx->ev_used >= 16384) return;                 // bounded log
@@ -27,8 +27,9 @@ static void mark(svo_ctx *ctx, const char *name)
     (void)hipEventRecord(ev, ctx->stream);
     ctx->marks.emplace_back(name, ev);
 }
+static inline void mark(svo_ctx *ctx, const char *name) { timing_mark(ctx, name); }
 
-static const char *kTOrb = "orb_extract", *kTMatch = "orb_match";
+static const char *kTMatch = "orb_match";
 static const char *kT0 = "start", *kTPyr = "pyramid", *kTFast = "fast", *kTLk = "lk", *kTCompact = "compact",
                   *kTTri = "triangulate", *kTPnp = "pnp", *kTFin = "finalize";
 
@@ -40,9 +41,8 @@ static int ingest_frames(svo_ctx *ctx, const uint8_t *L, const uint8_t *R, int p
     if (ctx->cfg.track_mode == SVO_MODE_ORB) {
         // Detect_MyORBFeatures (src/tracking.cpp:502-532): ORBextractor on the left AND right image;
         // frame f -> feature slots 2f (left), 2f+1 (right)
-        int rc = orb_extract_batch(ctx, L, R, pitch, frame_stride, 2 * f0, 2 * n_new, ctx->stream);
-        mark(ctx, kTOrb);
-        return rc;
+        // (orb_extract_batch records its own stage marks: orb_pyramid, orb_cellfast, orb_quadtree, orb_describe)
+        return orb_extract_batch(ctx, L, R, pitch, frame_stride, 2 * f0, 2 * n_new, ctx->stream);
     }
     const PyrGeom &g = ctx->geom;
     PyrArgs p{};

@@ -105,6 +105,7 @@ void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n
 // orb.hip
 int orb_alloc(svo_ctx *ctx);
 void orb_free(svo_ctx *ctx);
+void timing_mark(svo_ctx *ctx, const char *name);     // HIP event on the context's stream when timing is enabled
 const uint8_t *pnp_inlier_mask(const svo_ctx *ctx);
 int stage_chain_relative(svo_ctx *ctx, const double *T, const int32_t *ok, int n, const double *pose0_host, double *out, int mem);
 int stage_host_image(svo_ctx *ctx, const uint8_t *img, int pitch, int stage_idx, const uint8_t **dptr, int *dpitch);
