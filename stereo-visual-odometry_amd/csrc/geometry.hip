@@ -130,10 +130,16 @@ __device__ inline double lm_eval(const double param[6], const float *X3, const f
     return acc[0];
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void pnp_ransac_kernel(PnpArgs a)
+constexpr size_t kPnpLdsBytes = (size_t)(144 * 64 + 16) * sizeof(double);
+// The LDS image is declared dynamic so that the compiler does not know it limits the kernel to two
+// workgroups per CU: it would otherwise hand the single wave all 512 registers of its SIMD, which
+// starves every kernel that overlaps the pose stage.  With two waves per EU
+// as the target it gets 256 (architectural + accumulation; spills go to the latter, not to memory).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void pnp_ransac_kernel(PnpArgs a)
 {
-    __shared__ double big[144 * 64];          // lane-interleaved 12x12 work matrices (73,728 B)
-    __shared__ double bestRt[12];
+    extern __shared__ __attribute__((aligned(16))) double pnp_smem[];
+    double *big = pnp_smem;                   // lane-interleaved 12x12 work matrices (73,728 B)
+    double *bestRt = pnp_smem + 144 * 64;
     const int lane = threadIdx.x, b = blockIdx.x;
     const int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
     const float *X3 = a.X3 + (int64_t)b * a.stride * 3;
@@ -467,6 +473,10 @@ const uint8_t *pnp_inlier_mask(const svo_ctx *ctx) { return (const uint8_t *)ctx
 
 int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
 {
+    // called once per context at creation: the pose solver needs more dynamic LDS than the default limit
+    if (hipFuncSetAttribute((const void *)pnp_ransac_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kPnpLdsBytes) != hipSuccess)
+        return SVO_ERR_HIP;
     *bytes = ws_off_pose0(cfg, n_items) + 256;
     return SVO_OK;
 }
@@ -494,7 +504,7 @@ void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n
     a.confidence = (double)ctx->cfg.confidence;
     a.mask = (uint8_t *)ctx->pnp_ws + ws_off_mask(ctx->cfg.max_batch);
     a.out = (PnpRecord *)ctx->pnp_ws;
-    hipLaunchKernelGGL(pnp_ransac_kernel, dim3(n_items), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(pnp_ransac_kernel, dim3(n_items), dim3(64), kPnpLdsBytes, st, a);
 }
 
 void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur, const double *pose0_host,
@@ -572,7 +582,7 @@ int stage_pnp_ransac(svo_ctx *ctx, const svo_pt3f *obj, const svo_pt2f *img, int
     } else {
         a.X3 = (const float *)obj; a.img = (const float2 *)img; a.mask = inlier_mask ? inlier_mask : ws_mask;
     }
-    hipLaunchKernelGGL(pnp_ransac_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(pnp_ransac_kernel, dim3(1), dim3(64), kPnpLdsBytes, ctx->stream, a);
     SVO_HIP(hipGetLastError());
     PnpRecord *h = (PnpRecord *)((char *)ctx->h_pinned + 256);
     SVO_HIP(hipMemcpyAsync(h, ctx->pnp_ws, sizeof(PnpRecord), hipMemcpyDeviceToHost, ctx->stream));
