@@ -405,6 +405,31 @@ __device__ inline void qt_erase(QLds &L, QState &t, int id, int lane)
     t.size--; t.n_free++;
 }
 
+// All scalar fields of a node in one batch of LDS reads (one round trip instead of one per field:
+// the tree walk is a chain of dependent LDS accesses, and its latency is what the kernel costs)
+struct NodeView { int ulx, uly, brx, bry, beg, cnt, prev, next; };
+__device__ __forceinline__ NodeView qt_view(const QLds &L, int id)
+{
+    const QBox P = L.box[id];
+    const int b = L.begin[id], c = L.count[id], p = L.prev[id], n = L.next[id];
+    NodeView v;
+    v.ulx = rfl(P.ulx); v.uly = rfl(P.uly); v.brx = rfl(P.brx); v.bry = rfl(P.bry);
+    v.beg = rfl(b); v.cnt = rfl(c); v.prev = rfl(p); v.next = rfl(n);
+    return v;
+}
+// erase with the neighbours already known (no reads)
+__device__ inline void qt_erase_known(QLds &L, QState &t, int id, int p, int n, int lane)
+{
+    if (lane == 0) {
+        if (p >= 0) L.next[p] = (short)n;
+        if (n >= 0) L.prev[n] = (short)p;
+        L.free_list[t.n_free] = (short)id;
+    }
+    if (p < 0) t.head = n;
+    if (n < 0) t.tail = p;
+    t.size--; t.n_free++;
+}
+
 __device__ __forceinline__ int key_quadrant(uint2 k, int midx, int midy)
 {
     return ((int)(k.x & 0xFFFFu) < midx ? 0 : 1) + ((int)(k.x >> 16) < midy ? 0 : 2);
@@ -425,12 +450,15 @@ __device__ __forceinline__ int chunk_rank(bool valid, int q, int lane, int c[4])
 
 // ExtractorNode::DivideNode (ORBextractor.cpp:430-485): stable 4-way partition of the node's keys,
 // children created for the non-empty quadrants (ch[q] = node id or -1, cnt[q] = its key count)
-__device__ inline void qt_divide(QLds &L, QState &t, const KeyArr keys, const KeyArr gtmp, bool keys_global, int id, int ch[4],
-                                 int cnt[4], int cseq[4], int lane)
+__device__ inline void qt_divide(QLds &L, QState &t, const KeyArr keys, const KeyArr gtmp, bool keys_global, const NodeView &nv,
+                                 int ch[4], int cnt[4], int cseq[4], int lane)
 {
-    const QBox P = L.box[id];
-    const int ulx = rfl(P.ulx), uly = rfl(P.uly), brx = rfl(P.brx), bry = rfl(P.bry);
-    const int beg = rfl(L.begin[id]), n = rfl(L.count[id]);
+    const int ulx = nv.ulx, uly = nv.uly, brx = nv.brx, bry = nv.bry, beg = nv.beg, n = nv.cnt;
+    // the (up to four) ids the children may take from the free list, fetched together up front;
+    // nothing is pushed onto the list before the parent is erased, after the children exist
+    const int nf0 = t.n_free;
+    const int f0 = L.free_list[max(nf0 - 1, 0)], f1 = L.free_list[max(nf0 - 2, 0)], f2 = L.free_list[max(nf0 - 3, 0)],
+              f3 = L.free_list[max(nf0 - 4, 0)];
     const int midx = ulx + ((brx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);   // ceil(d / 2)
     cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
     if (n <= 64) {
@@ -475,6 +503,7 @@ __device__ inline void qt_divide(QLds &L, QState &t, const KeyArr keys, const Ke
         for (int i = lane; i < n; i += 64) keys.set(beg + i, gtmp.get(i));
     }
     if (keys_global) __threadfence();
+    const int pre[4] = {rfl(f0), rfl(f1), rfl(f2), rfl(f3)};
     const int cbeg[4] = {beg, beg + cnt[0], beg + cnt[0] + cnt[1], beg + cnt[0] + cnt[1] + cnt[2]};
     const int cul[4][2] = {{ulx, uly}, {midx, uly}, {ulx, midy}, {midx, midy}};
     const int cbr[4][2] = {{midx, midy}, {brx, midy}, {midx, bry}, {brx, bry}};
@@ -483,7 +512,12 @@ __device__ inline void qt_divide(QLds &L, QState &t, const KeyArr keys, const Ke
         ch[q] = -1; cseq[q] = 0;
         if (cnt[q] == 0) continue;
         cseq[q] = t.seq;
-        const int nid = qt_new(L, t, lane);
+        int nid;
+        if (t.n_free > 0) { nid = pre[nf0 - t.n_free]; t.n_free--; }
+        else if (t.n_alloc < L.node_cap) nid = t.n_alloc++;
+        else { t.overflow = true; nid = L.node_cap - 1; }
+        if (lane == 0) L.seq[nid] = (unsigned short)t.seq;
+        t.seq++;
         if (lane == 0) {
             QBox c; c.ulx = (short)cul[q][0]; c.uly = (short)cul[q][1]; c.brx = (short)cbr[q][0]; c.bry = (short)cbr[q][1];
             L.box[nid] = c; L.begin[nid] = (unsigned short)cbeg[q]; L.count[nid] = (unsigned short)cnt[q];
@@ -580,20 +614,22 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
         int prevSize = t.size, nToExpand = 0, lit = t.head, ch[4], cn[4], cs[4];
         n_exp = 0;
         while (lit >= 0) {
-            if (rfl(L.count[lit]) == 1) { lit = rfl(L.next[lit]); continue; }
-            qt_divide(L, t, keys, gtmp, keys_global, lit, ch, cn, cs, lane);
+            const NodeView nv = qt_view(L, lit);
+            if (nv.cnt == 1) { lit = nv.next; continue; }
+            qt_divide(L, t, keys, gtmp, keys_global, nv, ch, cn, cs, lane);
+            int lit_prev = nv.prev;                        // pushing in front of the head changes the head's prev
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (ch[q] >= 0) {
+                    if (t.head == lit) lit_prev = ch[q];
                     qt_push_front(L, t, ch[q], lane);
                     if (cn[q] > 1) {
                         nToExpand++;
                         if (n_exp < L.node_cap) { if (lane == 0) L.ea[n_exp] = exp_key(cn[q], cs[q], ch[q]); n_exp++; }
                     }
                 }
-            const int nx = rfl(L.next[lit]);
-            qt_erase(L, t, lit, lane);
-            lit = nx;
+            qt_erase_known(L, t, lit, lit_prev, nv.next, lane);
+            lit = nv.next;
             if (t.overflow) break;
         }
         if (t.overflow) break;
@@ -606,14 +642,17 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
                 exp_sort(L.ea, L.eb, n_prev, lane);
                 for (int j = n_prev - 1; j >= 0; j--) {
                     const int nid = rfl((int)((uint32_t)L.eb[j] & 0xFFFu));
-                    qt_divide(L, t, keys, gtmp, keys_global, nid, ch, cn, cs, lane);
+                    const NodeView nv = qt_view(L, nid);
+                    qt_divide(L, t, keys, gtmp, keys_global, nv, ch, cn, cs, lane);
+                    int nid_prev = nv.prev;
 #pragma unroll
                     for (int q = 0; q < 4; q++)
                         if (ch[q] >= 0) {
+                            if (t.head == nid) nid_prev = ch[q];
                             qt_push_front(L, t, ch[q], lane);
                             if (cn[q] > 1 && n_exp < L.node_cap) { if (lane == 0) L.ea[n_exp] = exp_key(cn[q], cs[q], ch[q]); n_exp++; }
                         }
-                    qt_erase(L, t, nid, lane);
+                    qt_erase_known(L, t, nid, nid_prev, nv.next, lane);
                     if (t.size >= N || t.overflow) break;
                 }
                 if (t.size >= N || t.size == prevSize || t.overflow) finish = true;
