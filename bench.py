@@ -49,6 +49,9 @@ def parse():
                     help="N > 1: one independent sequence per GPU (default, BASELINE config #5), or ONE sequence cut "
                          "into contiguous chunks of frame pairs with a one-frame halo, relative motions gathered "
                          "and chained on rank 0 (SURVEY.md 8e granularity 2)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N > 1: nccl (= RCCL, the real path) or gloo (rehearsal of the "
+                         "multi-rank control flow with several ranks sharing one GPU: collectives on CPU copies)")
     ap.add_argument("--frames-cache", default="", help="torch file to load/save the rendered S0 frames "
                     "(keeps profiler traces free of the renderer's torch kernels)")
     return ap.parse_args()
@@ -64,11 +67,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    gloo = args.dist_backend == "gloo"
+    if gloo:                                       # rehearsal: every rank on the same card
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     pkg = entry.load_package()
     import importlib
@@ -115,12 +124,13 @@ def main():
 
     def collect(res):
         """The only inter-GPU traffic: per pair 16 doubles (poses) or 17 (relative motion + ok) to rank 0."""
+        host = (lambda t: t.cpu()) if gloo else (lambda t: t)
         if by_pairs:       # chunks of ONE sequence: gather, then chain on rank 0
-            g = mg.gather_relative(mg.field_view(res, trel_off, B, 16), mg.int_field(res, ok_off, B), rank, world, dst=0)
+            g = mg.gather_relative(host(mg.field_view(res, trel_off, B, 16)), host(mg.int_field(res, ok_off, B)), rank, world, dst=0)
             if rank == 0:
-                ctx.chain_relative(g[0], g[1])
+                ctx.chain_relative(g[0].to(dev), g[1].to(dev))
         elif world > 1:
-            mg.gather_poses(mg.poses_view(res, pose_off, B), rank, world, dst=0)
+            mg.gather_poses(host(mg.poses_view(res, pose_off, B)), rank, world, dst=0)
 
     def step():
         k = state["k"]
@@ -157,7 +167,7 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    elapsed = mg.max_over_ranks(elapsed, dev, world)
+    elapsed = mg.max_over_ranks(elapsed, torch.device("cpu") if gloo else dev, world)
 
     ctx.sync()
     stage_ms = dict(ctx.get_timing()) if not args.no_timing_marks else {}

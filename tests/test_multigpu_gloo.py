@@ -99,3 +99,31 @@ def test_single_rank_is_identity(pkg):
     assert mg.max_over_ranks(2.5, torch.device("cpu"), 1) == 2.5
     assert mg.sequence_seed(0, 1) == 20200710
     assert mg.shard_sequences(8, 1, 0) == list(range(8))
+
+
+import json
+import subprocess
+import sys
+
+import pytest
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shard", ["sequences", "pairs"])
+def test_bench_two_ranks_rehearsal_on_one_gpu(shard):
+    """bench.py's N > 1 control flow (double-buffered collection of the previous step's records,
+    final drain, barrier, max over ranks, one JSON line from rank 0) with two ranks sharing the one
+    GPU of the test box; the collectives run over gloo instead of RCCL (--dist-backend gloo)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(conftest.ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--batch", "6", "--cpu-pairs", "0", "--dist-backend", "gloo", "--shard", shard]
+    r = subprocess.run(cmd, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["pairs_ok_last_step"] == 6 and out["roofline"]["frac"] > 0
