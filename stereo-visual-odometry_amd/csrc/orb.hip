@@ -298,14 +298,43 @@ __global__ __launch_bounds__(256) void orb_gather_kernel(OrbGeom g, const float4
     const int l = blockIdx.x, b = blockIdx.y;
     const int ncell = g.ncell[l];
     const int *cnt = cell_cnt + (int64_t)b * cnt_img_stride + g.cell_off[l];
-    if (threadIdx.x == 0) {
-        int s = 0;
+    // exclusive prefix of the per-cell counts: four cells per thread, wave scan, scan of the four wave totals
+    {
+        __shared__ int wave_sum[4];
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        int v[4], mine = 0;
         bool ovf = false;
-        for (int c = 0; c < ncell; c++) { offs[c] = s; s += min(cnt[c], kCellCap); ovf = ovf || cnt[c] > kCellCap; }
-        total = s;
-        if (ovf || s > cand_cap) atomicOr(overflow, 2);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = tid * 4 + q;
+            const int n = c < ncell ? cnt[c] : 0;
+            ovf = ovf || n > kCellCap;
+            v[q] = min(n, kCellCap);
+            mine += v[q];
+        }
+        int incl = mine;                                   // inclusive scan across the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_sum[wv] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wv; w++) base += wave_sum[w];
+        int run = base + incl - mine;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = tid * 4 + q;
+            if (c < ncell) offs[c] = run;
+            run += v[q];
+        }
+        if (tid == 255) total = run;                       // ncell <= 1024 == 4 * 256: the last thread ends the scan
+        const unsigned long long any_ovf = __ballot(ovf);
+        if (lane == 0 && any_ovf) atomicOr(overflow, 2);
     }
     __syncthreads();
+    if (threadIdx.x == 0 && total > cand_cap) atomicOr(overflow, 2);
     const float4 *src = cell_cand + (int64_t)b * cand_img_stride + (int64_t)g.cell_off[l] * kCellCap;
     float4 *dst = lvl_cand + ((int64_t)b * g.nlevels + l) * cand_cap;
     for (int c = threadIdx.x >> 6; c < ncell; c += 4) {
