@@ -864,7 +864,9 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     // computeOrbDescriptor on the blurred level
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ang = angle * factorPI;
-    const float ca = (float)cos((double)ang), sb = (float)sin((double)ang);
+    double sd, cd;                                 // one shared argument reduction for both
+    sincos((double)ang, &sd, &cd);
+    const float ca = (float)cd, sb = (float)sd;
     if (lane < 32) {
         const signed char *pat = c_pattern + lane * 32;
         const int balign = (int)((uintptr_t)bimg & 3);
