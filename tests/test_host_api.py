@@ -240,3 +240,48 @@ def test_frame_carriers_and_track_dump(host_built, pkg, oracle, small_seq, tmp_p
         T = [ln for ln in lines if ln.startswith("T ")]
         assert len(F) == len(frames) and sum(int(f[5]) for f in F[1:]) == len(T)
         assert sum(int(ln.split()[-1]) for ln in T) == sum(int(f[6]) for f in F[1:])
+
+
+def test_image_readers_survive_corrupted_files(host_built, tmp_path):
+    """PNG / PGM readers (System::NextFrame_kitti replaces cv::imread with them) on truncated,
+    bit-flipped and length-corrupted files, built with AddressSanitizer + UBSan: they may refuse a
+    file, they must not crash, read out of bounds or overflow."""
+    import random
+    import struct
+    from PIL import Image
+    exe = str(tmp_path / "host_selftest_asan")
+    srcs = [os.path.join(HOST, "tests_host", "host_selftest.cpp")] + \
+           [os.path.join(HOST, "src", f) for f in sorted(os.listdir(os.path.join(HOST, "src"))) if f.endswith(".cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++14", "-pthread", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-I" + os.path.join(HOST, "include"), "-I" + os.path.join(conftest.ROOT, "include"), "-o", exe] + srcs +
+                          ["-L" + os.path.dirname(HOST), "-lsvo_hip", "-lz", "-Wl,-rpath," + os.path.dirname(HOST)])
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (40, 57), dtype=np.uint8)
+    Image.fromarray(img).save(tmp_path / "ok.png")
+    Image.fromarray(np.stack([img] * 3, 2)).save(tmp_path / "rgb.png")
+    _write_pgm(tmp_path / "ok.pgm", img)
+    random.seed(3)
+    files = []
+    for name in ("ok.png", "rgb.png", "ok.pgm"):
+        data = open(tmp_path / name, "rb").read()
+        for i in range(40):
+            b = bytearray(data)
+            if i % 4 == 0:
+                b = b[:random.randrange(1, len(b))]
+            elif i % 4 == 1:
+                for _ in range(random.randrange(1, 6)):
+                    b[random.randrange(len(b))] = random.randrange(256)
+            elif i % 4 == 2:
+                b = b + bytes(random.randrange(256) for _ in range(50))
+            else:
+                p = random.randrange(len(b))
+                b[p:p + 4] = struct.pack(">I", random.choice([0, 0xFFFFFFFF, 0x7FFFFFFF, 65536]))
+            fn = str(tmp_path / f"{name}.{i}.bin")
+            open(fn, "wb").write(bytes(b))
+            files.append(fn)
+    _write_yaml(tmp_path / "c.yaml", str(tmp_path))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([exe, str(tmp_path / "c.yaml"), str(tmp_path / "ok.png")] + files, capture_output=True, env=env, timeout=300)
+    err = r.stderr.decode()
+    assert r.returncode == 0 and "AddressSanitizer" not in err and "runtime error" not in err, err[-3000:]
+    assert f"image1 ok=1 rows=40 cols=57 hash={_hash(img)}" in r.stdout.decode()
