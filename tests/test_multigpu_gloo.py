@@ -127,3 +127,38 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(shard):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["pairs_ok_last_step"] == 6 and out["roofline"]["frac"] > 0
+
+
+def test_shard_pairs_partitions_every_pair_exactly_once():
+    """Property (hypothesis): for any sequence length and rank count the chunks tile the frame pairs
+    in order, neighbouring chunks share exactly one (halo) frame, and sizes differ by at most one."""
+    import importlib
+    from hypothesis import given, settings, strategies as st
+    mg = importlib.import_module(conftest.entry.PKG_NAME + ".multigpu")
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(min_value=2, max_value=5000), st.integers(min_value=1, max_value=16))
+    def check(n_frames, world):
+        nxt, sizes = 0, []
+        for rank in range(world):
+            first, nf = mg.shard_pairs(n_frames, world, rank)
+            if nf == 0:
+                continue
+            assert first == nxt and nf >= 2            # starts on the previous chunk's last frame
+            nxt = first + nf - 1
+            sizes.append(nf - 1)
+        assert nxt == n_frames - 1 and sum(sizes) == n_frames - 1
+        assert max(sizes) - min(sizes) <= 1 or len(sizes) < world
+    check()
+
+    @settings(max_examples=100, deadline=None)
+    @given(st.integers(min_value=1, max_value=40), st.integers(min_value=0, max_value=2 ** 31 - 1))
+    def chain(n, seed):
+        rng = np.random.default_rng(seed)
+        T = np.tile(np.eye(4), (n, 1, 1))
+        T[:, :3, 3] = rng.normal(size=(n, 3))
+        ok = rng.integers(0, 2, n).astype(np.int32)
+        got = mg.chain_relative(torch.from_numpy(T.reshape(n, 16).copy()), torch.from_numpy(ok)).numpy()
+        acc = np.cumsum(T[:, :3, 3] * ok[:, None], 0)          # pure translations: the product is a running sum
+        assert np.allclose(got[:, :3, 3], acc, atol=1e-12) and np.allclose(got[:, :3, :3], np.eye(3))
+    chain()
