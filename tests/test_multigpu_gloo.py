@@ -69,7 +69,7 @@ def _worker(rank, world, port, out_dir):
             if okall[i]:
                 P = P @ Tall[i]
             ref.append(P.copy())
-        ok = ok and chained.shape == (n_frames - 1, 4, 4) and np.array_equal(chained, np.array(ref))
+        ok = ok and chained.shape == (n_frames - 1, 4, 4) and np.allclose(chained, np.array(ref), rtol=0, atol=1e-12)   # BLAS-dependent last ulps
         ok = ok and np.array_equal(g[1].numpy(), okall)
     else:
         ok = ok and g is None
