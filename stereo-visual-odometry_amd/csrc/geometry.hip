@@ -302,6 +302,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // ------------------------------------------------------------------------------------------
 struct FinalizeArgs {
     const PnpRecord *pnp; const int *n_prev, *n_cur, *n_tracked;   // per pair
+    const int *ovf;                // per pair (ORB mode): an image of the pair overflowed a capacity; may be null
     int n_pairs;
     int mode;                      // SVO_MODE_LK checks "< 30 FAST corners" first (src/tracking.cpp:261)
     int cap;                       // max_keypoints: a frame with more corners was truncated -> SVO_FAIL_CAPACITY
@@ -321,7 +322,7 @@ __global__ void finalize_kernel(FinalizeArgs a)
     for (int i = 0; i < 9; i++) r.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
     for (int i = 0; i < 16; i++) { r.T_rel_inv[i] = (i % 5 == 0) ? 1.0 : 0.0; r.pose[i] = 0; }
     int fail = 0;
-    if (r.n_prev_kps > a.cap || r.n_cur_kps > a.cap) fail = SVO_FAIL_CAPACITY;         // never silently track a truncated set
+    if (r.n_prev_kps > a.cap || r.n_cur_kps > a.cap || (a.ovf && a.ovf[p])) fail = SVO_FAIL_CAPACITY;   // never silently track a truncated set
     else if (a.mode == SVO_MODE_LK && r.n_cur_kps < 30) fail = SVO_FAIL_FEW_KEYPOINTS;     // src/tracking.cpp:261
     else {
         const int m = a.n_tracked[p];
@@ -368,12 +369,15 @@ __global__ void finalize_kernel(FinalizeArgs a)
     a.res[p] = r;
 }
 
-// frame_pose_ = frame_pose_ * T^-1 over consecutive pairs; failed steps are skipped (:59-68)
-__global__ void chain_kernel(svo_step_result *res, int n_pairs, const double *pose0)
+// frame_pose_ = frame_pose_ * T^-1 over consecutive pairs; failed steps are skipped (:59-68).
+// The seed pose travels BY VALUE in the kernel argument block: a launch queued behind many others
+// (callers of svo_track_batch with device results never synchronise) keeps the seed it was given.
+struct Pose16 { double m[16]; };
+__global__ void chain_kernel(svo_step_result *res, int n_pairs, Pose16 pose0)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double P[16];
-    for (int i = 0; i < 16; i++) P[i] = pose0[i];
+    for (int i = 0; i < 16; i++) P[i] = pose0.m[i];
     for (int p = 0; p < n_pairs; p++) {
         if (res[p].ok) {
             double Q[16];
@@ -402,7 +406,6 @@ __device__ __forceinline__ double quad_bcast_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
-struct Pose16 { double m[16]; };
 __global__ __launch_bounds__(64) void chain_relative_kernel(const double *T, const int *ok, int n, Pose16 pose0,
                                                             double *out)
 {
@@ -461,9 +464,9 @@ int stage_chain_relative(svo_ctx *ctx, const double *T, const int32_t *ok, int n
 }
 
 // ------------------------------------------------------------------------------------------
-// workspace layout inside ctx->pnp_ws: [PnpRecord x items][mask bytes x items*cap][pose0 16 doubles]
+// workspace layout inside ctx->pnp_ws: [PnpRecord x items][mask bytes x items*cap]
 static size_t ws_off_mask(int n_items) { return ((sizeof(PnpRecord) * (size_t)n_items) + 255) / 256 * 256; }
-static size_t ws_off_pose0(const svo_config &cfg, int n_items)
+static size_t ws_end(const svo_config &cfg, int n_items)
 {
     return (ws_off_mask(n_items) + (size_t)n_items * cfg.max_keypoints + 255) / 256 * 256;
 }
@@ -477,7 +480,7 @@ int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
     if (hipFuncSetAttribute((const void *)pnp_ransac_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPnpLdsBytes) != hipSuccess)
         return SVO_ERR_HIP;
-    *bytes = ws_off_pose0(cfg, n_items) + 256;
+    *bytes = ws_end(cfg, n_items) + 256;
     return SVO_OK;
 }
 
@@ -507,25 +510,19 @@ void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n
     hipLaunchKernelGGL(pnp_ransac_kernel, dim3(n_items), dim3(64), kPnpLdsBytes, st, a);
 }
 
-void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur, const double *pose0_host,
-                           hipStream_t st)
+void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur, const int *ovf,
+                           const double *pose0_host, hipStream_t st)
 {
     FinalizeArgs f{};
-    f.pnp = (const PnpRecord *)ctx->pnp_ws; f.n_prev = n_prev; f.n_cur = n_cur; f.n_tracked = ctx->m_out;
+    f.pnp = (const PnpRecord *)ctx->pnp_ws; f.n_prev = n_prev; f.n_cur = n_cur; f.n_tracked = ctx->m_out; f.ovf = ovf;
     f.cap = ctx->cfg.max_keypoints;
     f.n_pairs = n_pairs; f.mode = ctx->cfg.track_mode; f.num_features_tracking = ctx->cfg.num_features_tracking;
     f.inlier_rate = ctx->cfg.inlier_rate; f.min_move2 = ctx->cfg.min_move2; f.max_move2 = ctx->cfg.max_move2;
     f.res = ctx->d_results;
     hipLaunchKernelGGL(finalize_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, f);
-    // pose0 goes through pinned scratch so the async copy is valid; two alternating copies so a
-    // pose stage still pending on the side stream never sees the next call's seed
-    static_assert(sizeof(double) * 32 <= 256, "pose0 ring");
-    const int ring = (ctx->pose0_ring++) & 1;
-    double *d_pose0 = (double *)((char *)ctx->pnp_ws + ws_off_pose0(ctx->cfg, ctx->cfg.max_batch)) + 16 * ring;
-    double *h = (double *)((char *)ctx->h_pinned + 512) + 16 * ring;
-    for (int i = 0; i < 16; i++) h[i] = pose0_host ? pose0_host[i] : ((i % 5 == 0) ? 1.0 : 0.0);
-    (void)hipMemcpyAsync(d_pose0, h, sizeof(double) * 16, hipMemcpyHostToDevice, st);
-    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, st, ctx->d_results, n_pairs, d_pose0);
+    Pose16 p0;
+    for (int i = 0; i < 16; i++) p0.m[i] = pose0_host ? pose0_host[i] : ((i % 5 == 0) ? 1.0 : 0.0);
+    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, st, ctx->d_results, n_pairs, p0);
 }
 
 // ---- stage API ------------------------------------------------------------------------------

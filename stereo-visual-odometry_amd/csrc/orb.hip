@@ -11,9 +11,14 @@
 //   copy0/border -> [resize(l), border(l)] x7 -> cellfast(l) x8 -> gather -> distribute -> blur rows/cols
 //   -> orient+describe -> assemble.
 // The quadtree (std::list / sort / pointer code in the reference) is restated as an array-based
-// doubly linked list walked by ONE lane per (image, level): it is serial by nature (each split
-// decision depends on the node count so far) and small (<= a few thousand keys, <= ~450 leaves);
-// 16 instances per frame run concurrently on different waves.
+// doubly linked list in LDS walked by ONE WAVE per (image, level): the walk is serial by nature (each
+// split decision depends on the node count so far), so its control flow is wave-uniform, while every
+// operation on keys (DivideNode's 4-way partition, the size sort, the best-response pick) is 64 lanes
+// wide; 16 instances per frame run concurrently, four per CU.
+// Capacity: a cell with more than kCellCap candidates, a level with more than 4 * max_keypoints, a
+// quadtree that outgrows its node pool or an image with more than max_keypoints keypoints raises
+// that IMAGE's bit in orb_overflow[]; the stage call reports it as an error, the fused paths fail
+// the pairs that use the image with SVO_FAIL_CAPACITY (never a silently truncated set).
 #include <cstring>
 #include <vector>
 #include "svo_ctx.h"
@@ -331,10 +336,10 @@ __global__ __launch_bounds__(256) void orb_gather_kernel(OrbGeom g, const float4
         }
         if (tid == 255) total = run;                       // ncell <= 1024 == 4 * 256: the last thread ends the scan
         const unsigned long long any_ovf = __ballot(ovf);
-        if (lane == 0 && any_ovf) atomicOr(overflow, 2);
+        if (lane == 0 && any_ovf) atomicOr(overflow + b, 2);
     }
     __syncthreads();
-    if (threadIdx.x == 0 && total > cand_cap) atomicOr(overflow, 2);
+    if (threadIdx.x == 0 && total > cand_cap) atomicOr(overflow + b, 2);
     const float4 *src = cell_cand + (int64_t)b * cand_img_stride + (int64_t)g.cell_off[l] * kCellCap;
     float4 *dst = lvl_cand + ((int64_t)b * g.nlevels + l) * cand_cap;
     for (int c = threadIdx.x >> 6; c < ncell; c += 4) {
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
     }
     if (lane == 0) {
         a.sel_cnt[inst] = m;
-        if (t.overflow) atomicOr(a.overflow, 1);
+        if (t.overflow) atomicOr(a.overflow + b, 1);
     }
 }
 
@@ -791,6 +796,7 @@ struct OrbDescArgs {
     const float4 *lvl_cand; int cand_cap;
     const int *sel; const int *sel_cnt; int sel_cap;
     svo_keypoint *kps; uint8_t *desc; int *n_out; int out_cap;       // per image: out_cap keypoints
+    int *overflow;                                                   // per image
 };
 
 // one wave per keypoint: lanes 0..31 compute one descriptor byte each; the angle is computed by
@@ -802,7 +808,10 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     // locate level: prefix over the per-level selected counts
     int l = 0, base = 0, total = 0;
     for (int q = 0; q < a.g.nlevels; q++) total += a.sel_cnt[b * a.g.nlevels + q];
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.n_out[b] = min(total, a.out_cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.n_out[b] = min(total, a.out_cap);
+        if (total > a.out_cap) atomicOr(a.overflow + b, 4);          // more keypoints than max_keypoints
+    }
     if (gidx >= total || gidx >= a.out_cap) return;
     for (l = 0; l < a.g.nlevels; l++) {
         const int c = a.sel_cnt[b * a.g.nlevels + l];
@@ -1173,8 +1182,8 @@ int orb_alloc(svo_ctx *ctx)
     SVO_HIP(hipMalloc(&ctx->orb_qtmp, sizeof(uint2) * (size_t)kCandCap * L * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_sel, sizeof(int) * (size_t)ctx->orb_node_cap * L * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_sel_cnt, sizeof(int) * (size_t)L * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_overflow, sizeof(int)));
-    SVO_HIP(hipMemset(ctx->orb_overflow, 0, sizeof(int)));
+    SVO_HIP(hipMalloc(&ctx->orb_overflow, sizeof(int) * (size_t)n_img));
+    SVO_HIP(hipMemset(ctx->orb_overflow, 0, sizeof(int) * (size_t)n_img));
     ctx->orb_kp_cap = ctx->cfg.max_keypoints;
     SVO_HIP(hipMalloc(&ctx->orb_kps, sizeof(svo_keypoint) * (size_t)ctx->orb_kp_cap * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_desc, (size_t)32 * ctx->orb_kp_cap * n_img));
@@ -1206,6 +1215,8 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     const int L = g.nlevels, kCandCap = ctx->orb_cand_cap;
     uint8_t *slots = ctx->orb_slots + (size_t)slot0 * g.slot_bytes;
     dim3 blk(256);
+    int *ovf = ctx->orb_overflow + slot0;
+    SVO_HIP(hipMemsetAsync(ovf, 0, sizeof(int) * (size_t)n_img, st));
     if (img2) {
         // left images -> even slots, right images -> odd slots
         hipLaunchKernelGGL(orb_copy0_kernel, dim3((g.w[0] + 4095) / 4096, g.h[0], n_img / 2), blk, 0, st, g, img, pitch, img_stride,
@@ -1241,13 +1252,13 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     float4 *lvl_cand = ctx->orb_lvl_cand + (size_t)slot0 * L * kCandCap;
     int *lvl_cnt = ctx->orb_lvl_cnt + (size_t)slot0 * L;
     hipLaunchKernelGGL(orb_gather_kernel, dim3(L, n_img), blk, 0, st, g, cell_cand, cell_cnt, (int64_t)g.cells_total * kCellCap,
-                       (int64_t)g.cells_total, lvl_cand, lvl_cnt, kCandCap, ctx->orb_overflow);
+                       (int64_t)g.cells_total, lvl_cand, lvl_cnt, kCandCap, ovf);
     timing_mark(ctx, "orb_cellfast");
     OrbDistArgs d{};
     d.g = g; d.lvl_cand = lvl_cand; d.lvl_cnt = lvl_cnt; d.cand_cap = kCandCap;
     d.gkeys = (uint2 *)ctx->orb_qkeys + (size_t)slot0 * L * kCandCap; d.gtmp = (uint2 *)ctx->orb_qtmp + (size_t)slot0 * L * kCandCap;
     d.sel = ctx->orb_sel + (size_t)slot0 * L * ctx->orb_node_cap; d.sel_cnt = ctx->orb_sel_cnt + (size_t)slot0 * L; d.sel_cap = ctx->orb_node_cap;
-    d.overflow = ctx->orb_overflow;
+    d.overflow = ovf;
     d.node_cap = ctx->orb_node_cap;
     hipLaunchKernelGGL(orb_distribute_kernel, dim3(L, n_img), dim3(64), qlds_bytes(ctx->orb_node_cap), st, d);
     timing_mark(ctx, "orb_quadtree");
@@ -1255,13 +1266,33 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     e.g = g; e.slots = slots; e.slot_stride = g.slot_bytes; e.blur = blur; e.blur_img_stride = g.blur_total;
     e.lvl_cand = lvl_cand; e.cand_cap = kCandCap; e.sel = d.sel; e.sel_cnt = d.sel_cnt; e.sel_cap = ctx->orb_node_cap;
     e.kps = (svo_keypoint *)ctx->orb_kps + (size_t)slot0 * ctx->orb_kp_cap; e.desc = ctx->orb_desc + (size_t)slot0 * ctx->orb_kp_cap * 32;
-    e.n_out = ctx->orb_n + slot0; e.out_cap = ctx->orb_kp_cap;
+    e.n_out = ctx->orb_n + slot0; e.out_cap = ctx->orb_kp_cap; e.overflow = ovf;
     int max_kp = 0;
     for (int l = 0; l < L; l++) max_kp += g.quota[l] + 8;
     if (max_kp > ctx->orb_kp_cap) max_kp = ctx->orb_kp_cap;
     hipLaunchKernelGGL(orb_describe_kernel, dim3((max_kp + 3) / 4, n_img), blk, 0, st, e);
     timing_mark(ctx, "orb_describe");
     return SVO_OK;
+}
+
+// Keypoint counts and capacity flags of the images a batch of pairs uses, frozen for the pose stage
+// (the next batch's extraction overwrites orb_n / orb_overflow while the side stream still needs them):
+// snap[p] = n(last.left), snap[n_pairs + p] = n(cur.left), snap[2 n_pairs + p] = OR of the flags of
+// last.left, last.right, cur.left, cur.right.
+__global__ void orb_snapshot_kernel(const int *n, const int *ovf, int n_pairs, int fp0, int fc0, int fstep, int *snap)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const int sp = 2 * (fp0 + p * fstep), sc = 2 * (fc0 + p * fstep);
+    snap[p] = n[sp];
+    snap[n_pairs + p] = n[sc];
+    snap[2 * n_pairs + p] = ovf[sp] | ovf[sp + 1] | ovf[sc] | ovf[sc + 1];
+}
+
+void orb_snapshot_counts(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipStream_t st)
+{
+    hipLaunchKernelGGL(orb_snapshot_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, (const int *)ctx->orb_n,
+                       (const int *)ctx->orb_overflow, n_pairs, fp0, fc0, fstep, ctx->kp_n_snap);
 }
 
 void orb_launch_match_fixed(svo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, hipStream_t st)

@@ -85,12 +85,8 @@ static int run_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, con
         orb_match_pairs(ctx, n_pairs, fp0, fc0, fstep, ctx->stream);
         mark(ctx, kTMatch);
         launch_triangulate_batch(ctx, n_pairs, cap, ctx->cmp[0], ctx->cmp[1], ctx->m_out, 0);
-        // n_prev / n_cur = left keypoint counts of the two frames (feature slots 2f)
-        const int np = fstep == 1 ? n_pairs : 1;
-        SVO_HIP(hipMemcpy2DAsync(ctx->kp_n_snap, sizeof(int), ctx->orb_n + 2 * fp0, 2 * sizeof(int), sizeof(int), np,
-                                 hipMemcpyDeviceToDevice, ctx->stream));
-        SVO_HIP(hipMemcpy2DAsync(ctx->kp_n_snap + n_pairs, sizeof(int), ctx->orb_n + 2 * fc0, 2 * sizeof(int), sizeof(int), np,
-                                 hipMemcpyDeviceToDevice, ctx->stream));
+        // n_prev / n_cur = left keypoint counts of the two frames (feature slots 2f) + capacity flags
+        orb_snapshot_counts(ctx, n_pairs, fp0, fc0, fstep, ctx->stream);
         mark(ctx, kTTri);
         return run_back(ctx, n_pairs, pose0_host, results_dev);
     }
@@ -154,7 +150,8 @@ static int run_back(svo_ctx *ctx, int n_pairs, const double *pose0_host, svo_ste
     }
     launch_pnp_batch(ctx, n_pairs, ctx->cmp[3], ctx->m_out, 0, bs);
     if (!side) mark(ctx, kTPnp);
-    launch_finalize_chain(ctx, n_pairs, ctx->kp_n_snap, ctx->kp_n_snap + n_pairs, pose0_host, bs);
+    launch_finalize_chain(ctx, n_pairs, ctx->kp_n_snap, ctx->kp_n_snap + n_pairs,
+                          ctx->cfg.track_mode == SVO_MODE_ORB ? ctx->kp_n_snap + 2 * n_pairs : nullptr, pose0_host, bs);
     if (results_dev)
         SVO_HIP(hipMemcpyAsync(results_dev, ctx->d_results, sizeof(svo_step_result) * (size_t)n_pairs,
                                hipMemcpyDeviceToDevice, bs));

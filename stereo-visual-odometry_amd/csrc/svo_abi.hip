@@ -163,7 +163,7 @@ extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
     CK(hipMalloc(&ctx->pnp_ws, ctx->pnp_ws_bytes));
     CK(hipMalloc(&ctx->d_results, sizeof(svo_step_result) * (size_t)B));
     CK(hipMalloc(&ctx->bslots, (size_t)2 * n_img * ctx->geom.slot_bytes));
-    CK(hipMalloc(&ctx->kp_n_snap, sizeof(int) * (size_t)(2 * n_img)));
+    CK(hipMalloc(&ctx->kp_n_snap, sizeof(int) * (size_t)(3 * n_img)));
     CK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     CK(hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&ctx->ev_back, hipEventDisableTiming));
@@ -500,8 +500,8 @@ extern "C" int svo_orb_extract(svo_ctx *ctx, const uint8_t *img, int pitch, int 
     const int n = h[0];
     *n_out = n;
     if (h[1]) {
-        ctx->err = (h[1] & 2) ? "ORB: FAST candidates exceed the per-level capacity (4 * max_keypoints)" : "ORB quadtree node pool overflow";
-        SVO_HIP(hipMemsetAsync(ctx->orb_overflow, 0, sizeof(int), ctx->stream));
+        ctx->err = (h[1] & 2) ? "ORB: FAST candidates exceed the per-cell (256) or per-level (4 * max_keypoints) capacity"
+                   : (h[1] & 1) ? "ORB quadtree node pool overflow" : "ORB: keypoints exceed max_keypoints";
         return SVO_ERR_ARG;
     }
     if (per_level) for (int l = 0; l < 8; l++) per_level[l] = l < ctx->orb_geom.nlevels ? h[8 + l] : 0;

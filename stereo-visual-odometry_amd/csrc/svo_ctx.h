@@ -70,8 +70,7 @@ struct svo_ctx {
     int fb_frames[2] = {0, 0};
     hipEvent_t ev_front = nullptr, ev_back = nullptr;
     bool back_pending = false;
-    unsigned pose0_ring = 0;
-    int *kp_n_snap = nullptr;         // n_prev / n_cur of the batch the pose stage works on
+    int *kp_n_snap = nullptr;         // n_prev / n_cur (/ ORB capacity flags) of the batch the pose stage works on: 3 x max_batch
     // ---- timing
     // stage marks are HIP events recorded on the context's stream; they are resolved (elapsed
     // times averaged per stage over all steps since the last query) in svo_get_timing
@@ -112,7 +111,8 @@ int stage_host_image(svo_ctx *ctx, const uint8_t *img, int pitch, int stage_idx,
 int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int pitch, int64_t img_stride, int slot0,
                       int n_img, hipStream_t st);
 int orb_match_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipStream_t st);
+void orb_snapshot_counts(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipStream_t st);
 void orb_launch_match_fixed(svo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, hipStream_t st);
-void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur,
+void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur, const int *ovf,
                            const double *pose0_host, hipStream_t st);
 }  // namespace svo

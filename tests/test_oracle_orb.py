@@ -3,6 +3,7 @@ the numbers derived in SURVEY.md section 8 (a9), fixed-point resize / blur again
 formulations, fastAtan2 accuracy, quadtree invariants, rBRIEF rotation behaviour, the Hamming
 matcher and an end-to-end ORB-mode step on rendered stereo with ground truth."""
 import numpy as np
+import pytest
 
 from conftest import rand_image
 
@@ -151,3 +152,33 @@ def test_orb_step_recovers_synthetic_motion(oracle, synth):
     t2l, t1l, t1r = oracle.orb_robust_match(kL, dL, kR, dR, k2, d2)
     assert len(t2l) == res["n_tracked"] and (np.abs(t1l[:, 1] - t1r[:, 1]) < 3).all()
     assert np.median(t1l[:, 0] - t1r[:, 0]) > 5                 # brute-force matches: mostly true stereo pairs
+
+
+def test_brief_pattern_tables_equal_the_reference_table():
+    """The 256 x 4 rBRIEF test locations are constant DATA the descriptor is defined by (reference
+    src/ORBextractor.cpp:99-357).  Both committed tables (oracle/ and csrc/) must hold it value for
+    value; checked against the reference's text whenever /root/reference is readable (it is not on
+    the GPU box), and always against each other and the first / last rows quoted in SURVEY.md."""
+    import os
+    import re
+
+    def table(path):
+        text = open(path).read()
+        body = text[text.index("{") + 1:text.index("};")]
+        return [int(v) for v in re.findall(r"-?\d+", body)]
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = table(os.path.join(root, "oracle", "orb_pattern.h"))
+    b = table(os.path.join(root, "stereo-visual-odometry_amd", "csrc", "orb_pattern.h"))
+    assert len(a) == 1024 and a == b
+    assert a[:8] == [8, -3, 9, 5, 4, 2, 7, -12] and a[-8:] == [7, 0, 12, -2, -1, -6, 0, -11]
+    assert all(-15 <= v <= 15 for v in a)
+    ref_path = "/root/reference/src/ORBextractor.cpp"
+    if not os.path.exists(ref_path):
+        pytest.skip("reference tree not present (GPU box): committed tables checked against each other only")
+    src = open(ref_path).read()
+    body = src[src.index("static int bit_pattern_31_[256 * 4]"):]
+    body = body[body.index("{") + 1:body.index("};")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    ref = [int(v) for v in re.findall(r"-?\d+", body)]
+    assert ref == a
