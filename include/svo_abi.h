@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 3
+#define SVO_ABI_VERSION 4
 
 /* status codes */
 #define SVO_OK                 0
@@ -175,6 +175,8 @@ int svo_add_frame(svo_ctx *ctx, const uint8_t *left, const uint8_t *right, int p
                   svo_step_result *res);
 int svo_reset(svo_ctx *ctx);                         /* back to INITING, pose = identity */
 int svo_get_pose(svo_ctx *ctx, double pose[16]);     /* frame_pose_ (src/tracking.h:117)  */
+int svo_set_pose(svo_ctx *ctx, const double pose[16]);   /* seeds frame_pose_ of the online path (e.g. a context
+                                                            rebuilt for another frame size continues the chain) */
 
 /* Batched step: n_frames consecutive stereo frames resident in HBM (frame f at base +
  * f*frame_stride), n_frames - 1 <= max_batch pairs processed as one set of launches
@@ -212,6 +214,13 @@ int svo_upload_frames(svo_ctx *ctx, int buf, const uint8_t *left_frames, const u
 int svo_wait_upload(svo_ctx *ctx, int buf);
 int svo_track_uploaded(svo_ctx *ctx, int buf, int n_frames, const double *pose0,
                        svo_step_result *results, int results_mem);
+/* The same without waiting for the GPU (ABI v4): the n_frames - 1 step records stay in the context
+ * until svo_collect_results copies them to a HOST array (it waits for the batch).  Between the two
+ * calls the caller is free to decode and svo_upload_frames the NEXT chunk into the other buffer, so
+ * that its host-to-device copy runs beside this batch's kernels.  One batch may be outstanding:
+ * collect before the next svo_track_* call on the context. */
+int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, const double *pose0);
+int svo_collect_results(svo_ctx *ctx, svo_step_result *results, int n_pairs);
 
 /* Read-back of the online state (after svo_add_frame), for callers that keep the reference's
  * per-frame carriers or draw what Tracking::displayTracking drew (src/tracking.cpp:345-382):

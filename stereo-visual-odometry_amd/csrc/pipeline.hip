@@ -168,7 +168,8 @@ int pipeline_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t
                          int64_t frame_stride, int n_frames, const double *pose0,
                          svo_step_result *results, int results_mem)
 {
-    SVO_ARG(left_frames && right_frames && results, "null pointer");
+    // results == NULL with SVO_MEM_DEVICE: the records stay in the context (svo_collect_results)
+    SVO_ARG(left_frames && right_frames && (results || results_mem == SVO_MEM_DEVICE), "null pointer");
     SVO_ARG(n_frames >= 2 && n_frames - 1 <= ctx->cfg.max_batch, "n_frames - 1 must be in [1, max_batch]");
     SVO_ARG(pitch >= ctx->cfg.width && frame_stride >= (int64_t)pitch * ctx->cfg.height, "bad pitch / frame_stride");
     SVO_ARG(results_mem == SVO_MEM_HOST || results_mem == SVO_MEM_DEVICE, "bad results_mem");

@@ -620,6 +620,13 @@ extern "C" int svo_get_pose(svo_ctx *ctx, double pose[16])
     return SVO_OK;
 }
 
+extern "C" int svo_set_pose(svo_ctx *ctx, const double pose[16])
+{
+    if (!ctx || !pose) return SVO_ERR_ARG;
+    memcpy(ctx->pose, pose, sizeof(double) * 16);
+    return SVO_OK;
+}
+
 extern "C" int svo_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t *right_frames,
                                int pitch, int64_t frame_stride, int n_frames, const double *pose0,
                                svo_step_result *results, int results_mem)
@@ -714,6 +721,36 @@ extern "C" int svo_track_uploaded(svo_ctx *ctx, int buf, int n_frames, const dou
     SVO_HIP(hipEventRecord(ctx->ev_fb_free[buf], ctx->stream));
     ctx->fb_used[buf] = true;
     return rc;
+}
+
+extern "C" int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, const double *pose0)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(buf == 0 || buf == 1, "buf must be 0 or 1");
+    SVO_ARG(n_frames >= 2 && n_frames <= ctx->fb_frames[buf], "n_frames exceeds what was uploaded");
+    SVO_HIP(hipSetDevice(ctx->device));
+    const size_t fbytes = (size_t)ctx->stage_pitch * ctx->cfg.height, per_cam = fbytes * (size_t)(ctx->cfg.max_batch + 1);
+    SVO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_up[buf], 0));
+    int rc = pipeline_track_batch(ctx, ctx->fb[buf], ctx->fb[buf] + per_cam, ctx->stage_pitch, (int64_t)fbytes, n_frames,
+                                  pose0, nullptr, SVO_MEM_DEVICE);
+    if (rc < 0) return rc;
+    SVO_HIP(hipEventRecord(ctx->ev_fb_free[buf], ctx->stream));
+    ctx->fb_used[buf] = true;
+    ctx->async_pairs = n_frames - 1;
+    return rc;
+}
+
+extern "C" int svo_collect_results(svo_ctx *ctx, svo_step_result *results, int n_pairs)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(results && n_pairs >= 1 && n_pairs <= ctx->async_pairs, "no outstanding batch with that many pairs");
+    SVO_HIP(hipSetDevice(ctx->device));
+    svo_step_result *h = (svo_step_result *)((char *)ctx->h_pinned + 4096);
+    SVO_HIP(hipMemcpyAsync(h, ctx->d_results, sizeof(svo_step_result) * (size_t)n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(results, h, sizeof(svo_step_result) * (size_t)n_pairs);
+    ctx->async_pairs = 0;
+    return SVO_OK;
 }
 
 extern "C" int svo_chain_relative(svo_ctx *ctx, const double *T_rel_inv, const int32_t *ok, int n, const double *pose0,

@@ -68,6 +68,7 @@ struct svo_ctx {
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_fb_free[2] = {nullptr, nullptr};
     bool fb_used[2] = {false, false};
     int fb_frames[2] = {0, 0};
+    int async_pairs = 0;              // pairs of the batch launched by svo_track_uploaded_async, not yet collected
     hipEvent_t ev_front = nullptr, ev_back = nullptr;
     bool back_pending = false;
     int *kp_n_snap = nullptr;         // n_prev / n_cur (/ ORB capacity flags) of the batch the pose stage works on: 3 x max_batch

@@ -51,6 +51,11 @@ private:
     std::shared_ptr<uint8_t> buf_;
 };
 
+// the reference's ORBextractor::operator() is declared with cv::InputArray / cv::OutputArray
+// (include/lzb_vio/ORBextractor.h:40-42); with the Mat stand-in they are plain references
+typedef const Mat &InputArray;
+typedef Mat &OutputArray;
+
 }  // namespace cv
 
 namespace lzb_vio {

@@ -18,6 +18,9 @@ struct Feature {
     typedef std::shared_ptr<Feature> Ptr;
 
     cv::KeyPoint position_;                 // pixel position, size, angle, response, octave
+    cv::Mat Descriptor_;                    // reference feature.h:24; never written by the reference's Tracking
+                                            // (descriptors live in Frame::*_Descriptors_): ORB mode fills it with the
+                                            // keypoint's 1 x 32 descriptor row when the carriers are requested
     std::weak_ptr<Frame> frame_;            // owner (weak: a frame owns its features, not vice versa)
     bool is_on_left_image_ = true;          // false for ORB keypoints of the right image
     bool is_outlier_ = false;

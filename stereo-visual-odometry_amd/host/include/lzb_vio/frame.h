@@ -32,6 +32,8 @@ struct Frame {
     std::vector<unsigned char> status_;
 
     Frame() = default;
+    // reference include/lzb_vio/frame.h:42-43 / src/frame.cpp:25-26 (pose: 16 doubles instead of Sophus::SE3d)
+    Frame(long id, double time_stamp, const Pose4x4 &pose, const cv::Mat &left, const cv::Mat &right);
     static std::shared_ptr<Frame> CreateFrame();
     void SetKeyFrame();
 

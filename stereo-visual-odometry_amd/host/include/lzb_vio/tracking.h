@@ -27,6 +27,10 @@ public:
     bool AddFrame(Frame::Ptr frame);
     TrackingStatus GetStatus() const { return status_; }
 
+    // private no-op in the reference (include/lzb_vio/tracking.h:46, src/tracking.cpp:662-665; its call
+    // sites are commented out); public here and it does what the name says: back to INITING, identity pose
+    bool Reset();
+
     // additive (the reference has no getter for frame_pose_)
     Pose4x4 GetPose() const { return frame_pose_; }
     const svo_step_result &LastResult() const { return last_; }
@@ -42,6 +46,10 @@ public:
     bool EnsureBatchContext(int width, int height, int max_batch) { return EnsureContext(width, height, max_batch); }
     svo_ctx *Context() { return ctx_; }
     bool TrackUploaded(int buf, int n_frames, std::vector<svo_step_result> &out);
+    // the same in two halves: launch without waiting for the GPU, then (after the caller has decoded and
+    // uploaded the next chunk, whose copy then overlaps this batch's kernels) collect the records
+    bool TrackUploadedAsync(int buf, int n_frames);
+    bool CollectUploaded(std::vector<svo_step_result> &out);
 
 private:
     bool StereoInit_f2f();
@@ -62,7 +70,7 @@ private:
     double Px_ = 0, Py_ = 0, Pz_ = 0;
 
     svo_ctx *ctx_ = nullptr;
-    int ctx_w_ = 0, ctx_h_ = 0, ctx_batch_ = 0;
+    int ctx_w_ = 0, ctx_h_ = 0, ctx_batch_ = 0, async_pairs_ = 0;
     svo_step_result last_;
     bool fill_features_ = false;
 

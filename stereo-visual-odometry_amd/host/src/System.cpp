@@ -23,6 +23,10 @@ static bool read_file(const std::string &path, std::vector<uint8_t> &buf)
     return ok;
 }
 
+// largest width / height accepted from a file header (svo_create's own limit): a corrupted or
+// hostile header must be refused before anything is allocated from it
+static const int kMaxImageDim = 16384;
+
 static bool read_pgm(const std::vector<uint8_t> &b, cv::Mat &out)
 {
     size_t p = 2;
@@ -31,12 +35,15 @@ static bool read_pgm(const std::vector<uint8_t> &b, cv::Mat &out)
         while (p < b.size() && (b[p] == ' ' || b[p] == '\n' || b[p] == '\r' || b[p] == '\t')) p++;
         if (p < b.size() && b[p] == '#') { while (p < b.size() && b[p] != '\n') p++; continue; }
         int v = 0; bool any = false;
-        while (p < b.size() && b[p] >= '0' && b[p] <= '9') { v = v * 10 + (b[p] - '0'); p++; any = true; }
+        while (p < b.size() && b[p] >= '0' && b[p] <= '9') {
+            v = v * 10 + (b[p] - '0'); p++; any = true;
+            if (v > kMaxImageDim) return false;             // also keeps the accumulator far from overflow
+        }
         if (!any) return false;
         vals[nv++] = v;
     }
     p++;                                                    // single whitespace after maxval
-    if (nv != 3 || vals[2] != 255 || b.size() < p + (size_t)vals[0] * vals[1]) return false;
+    if (nv != 3 || vals[0] < 1 || vals[1] < 1 || vals[2] != 255 || b.size() < p + (size_t)vals[0] * vals[1]) return false;
     out.create(vals[1], vals[0]);
     for (int y = 0; y < vals[1]; y++) memcpy(out.ptr(y), &b[p + (size_t)y * vals[0]], vals[0]);
     return true;
@@ -64,10 +71,12 @@ static bool read_png(const std::vector<uint8_t> &b, cv::Mat &out)
         } else if (!memcmp(type, "IEND", 4)) break;
         p += 12 + len;
     }
-    if (w <= 0 || h <= 0 || depth != 8 || interlace != 0) return false;
+    if (w <= 0 || h <= 0 || w > kMaxImageDim || h > kMaxImageDim || depth != 8 || interlace != 0) return false;
     int ch = ctype == 0 ? 1 : ctype == 4 ? 2 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
     if (!ch) return false;
     const size_t stride = (size_t)w * ch;
+    // deflate expands by at most ~1032x: a header promising more pixels than the IDAT bytes can hold is corrupt
+    if ((stride + 1) * (size_t)h > idat.size() * 1032 + 64) return false;
     std::vector<uint8_t> raw((stride + 1) * (size_t)h);
     uLongf rawlen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return false;
@@ -309,16 +318,18 @@ void System::RunBatched(int B, int decode_threads)
             });
         recs.clear();
         auto t1 = std::chrono::steady_clock::now();
-        ok = tracking_->TrackUploaded(k, cur_n, recs);
-        auto t2 = std::chrono::steady_clock::now();
+        ok = tracking_->TrackUploadedAsync(k, cur_n);       // returns at once: the GPU works on chunk c ...
         if (bg.joinable()) bg.join();
+        // ... while chunk c+1, decoded meanwhile, already crosses PCIe on the copy stream
+        const bool more = ok && nn >= 2 && upload(k ^ 1, nn);
+        ok = ok && tracking_->CollectUploaded(recs);
+        auto t2 = std::chrono::steady_clock::now();
         if (!ok) break;
         if (getenv("LZB_VIO_VERBOSE"))
             LZB_LOG("INFO", "VO cost time: %f seconds for %d pairs", std::chrono::duration<double>(t2 - t1).count(), cur_n - 1);
         for (const auto &r : recs) { WritePoseRow(r.pose); current_image_index_++; }
-        if (nn < 2) break;
+        if (!more) break;
         next += nn - 1;
-        if (!upload(k ^ 1, nn)) break;
         k ^= 1;
         cur_n = nn;
     }

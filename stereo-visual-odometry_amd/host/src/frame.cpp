@@ -3,6 +3,9 @@
 
 namespace lzb_vio {
 
+Frame::Frame(long id, double time_stamp, const Pose4x4 &pose, const cv::Mat &left, const cv::Mat &right)
+    : left_img_(left), right_img_(right), id_((unsigned long)id), time_stamp_(time_stamp), pose_(pose) {}
+
 Frame::Ptr Frame::CreateFrame()
 {
     static long factory_id = 0;

@@ -45,14 +45,43 @@ void Tracking::Readparameter()
 
 void Tracking::Set_vo(System *slam) { system_ = slam; }
 
+bool Tracking::Reset()
+{
+    status_ = TrackingStatus::INITING;
+    current_frame_ = nullptr; last_frame_ = nullptr;
+    frame_pose_ = Pose4x4();
+    Px_ = Py_ = Pz_ = 0;
+    memset(&last_, 0, sizeof(last_));
+    if (ctx_) svo_reset(ctx_);
+    return true;
+}
+
 // The HIP context is sized by the first frame (the reference learns the size from cv::imread too).
 bool Tracking::EnsureContext(int width, int height, int max_batch)
 {
     if (ctx_ && width == ctx_w_ && height == ctx_h_ && max_batch <= ctx_batch_) return true;
+    const bool resized = ctx_ && (width != ctx_w_ || height != ctx_h_);
+    if (resized)
+        LZB_LOG("WARNING", "frame size changed from %dx%d to %dx%d: the HIP context is rebuilt; this frame only "
+                "re-initialises the tracker (no motion is estimated for it), the pose chain continues from frame_pose_",
+                ctx_w_, ctx_h_, width, height);
     if (ctx_) { svo_destroy(ctx_); ctx_ = nullptr; }
     svo_config cfg;
     svo_default_config(&cfg, width, height);
     cfg.max_batch = max_batch;
+    // cv::FAST is uncapped in the reference; the device buffers are not.  Capacity per image: the additive
+    // YAML key max_keypoints, else one keypoint per 24 pixels (NMS keeps at most one corner per 3x3
+    // block; textured KITTI frames hold 2-5 k, i.e. one per ~100-200 pixels), never less than 8192 or
+    // than what the ORB extractor is asked for.  A frame that still exceeds it fails its pairs with
+    // SVO_FAIL_CAPACITY, which is logged as an error below.
+    {
+        long cap = Config::Has("max_keypoints") ? Config::Get<int>("max_keypoints") : (long)width * height / 24;
+        if (cap < 8192) cap = 8192;
+        if (cap < 2L * nFeatures_) cap = 2L * nFeatures_;
+        if (track_mode_ == "ORB_stereof2f_pnp" && cap > 16384) cap = 16384;     // 16-bit indices in the ORB kernels
+        if (cap > (1 << 20)) cap = 1 << 20;
+        cfg.max_keypoints = (int)cap;
+    }
     cfg.fast_threshold = 20;                                     // hard-coded, src/tracking.cpp:99
     cfg.num_features_tracking = num_features_tracking_;
     cfg.iterations = iterationsCount_;
@@ -82,6 +111,7 @@ bool Tracking::EnsureContext(int width, int height, int max_batch)
         return false;
     }
     ctx_w_ = width; ctx_h_ = height; ctx_batch_ = max_batch;
+    if (resized) svo_set_pose(ctx_, frame_pose_.m);          // the new context's first frame only initialises; the chain goes on
     return true;
 }
 
@@ -113,6 +143,9 @@ static bool feed(svo_ctx *ctx, Frame::Ptr f, svo_step_result *res, int *rc_out)
     }
     *rc_out = svo_add_frame(ctx, L.data, R.data, (int)L.step, SVO_MEM_HOST, res);
     if (*rc_out < 0) LZB_LOG("ERROR", "svo_add_frame: %s", svo_last_error(ctx));
+    if (*rc_out == SVO_FAIL_CAPACITY)
+        LZB_LOG("ERROR", "frame %lu: more keypoints than the context's capacity (YAML key max_keypoints); "
+                "the pair was NOT tracked and the pose keeps its previous value", f->id_);
     return *rc_out == SVO_OK;
 }
 
@@ -141,6 +174,7 @@ void Tracking::FillFeatures()
             kp.response = kps[i].response; kp.octave = kps[i].octave; kp.class_id = kps[i].class_id;
             Feature::Ptr f(new Feature(current_frame_, kp));
             f->is_on_left_image_ = side == 0;
+            if (orb) { f->Descriptor_.create(1, 32); memcpy(f->Descriptor_.ptr(0), desc.data() + (size_t)i * 32, 32); }
             dst.push_back(f);
         }
         if (orb) {
@@ -211,15 +245,37 @@ bool Tracking::TrackOnGpu()
 // Batched equivalent of n_frames - 1 AddFrame calls on frames already in device buffer `buf`.
 bool Tracking::TrackUploaded(int buf, int n_frames, std::vector<svo_step_result> &out)
 {
+    return TrackUploadedAsync(buf, n_frames) && CollectUploaded(out);
+}
+
+bool Tracking::TrackUploadedAsync(int buf, int n_frames)
+{
     if (!ctx_ || n_frames < 2) return false;
-    const size_t first = out.size();
-    out.resize(first + (size_t)(n_frames - 1));
-    int rc = svo_track_uploaded(ctx_, buf, n_frames, frame_pose_.m, out.data() + first, SVO_MEM_HOST);
+    int rc = svo_track_uploaded_async(ctx_, buf, n_frames, frame_pose_.m);
     if (rc < 0) {
-        LZB_LOG("ERROR", "svo_track_uploaded: %s", svo_last_error(ctx_));
+        LZB_LOG("ERROR", "svo_track_uploaded_async: %s", svo_last_error(ctx_));
+        return false;
+    }
+    async_pairs_ = n_frames - 1;
+    return true;
+}
+
+bool Tracking::CollectUploaded(std::vector<svo_step_result> &out)
+{
+    if (!ctx_ || async_pairs_ < 1) return false;
+    const size_t first = out.size();
+    out.resize(first + (size_t)async_pairs_);
+    int rc = svo_collect_results(ctx_, out.data() + first, async_pairs_);
+    async_pairs_ = 0;
+    if (rc < 0) {
+        LZB_LOG("ERROR", "svo_collect_results: %s", svo_last_error(ctx_));
         out.resize(first);
         return false;
     }
+    for (size_t i = first; i < out.size(); i++)
+        if (out[i].fail_stage == SVO_FAIL_CAPACITY)
+            LZB_LOG("ERROR", "pair %zu of the batch: a frame has more keypoints than the context's capacity "
+                    "(YAML key max_keypoints); the pair was NOT tracked", i - first);
     last_ = out.back();
     memcpy(frame_pose_.m, last_.pose, sizeof(frame_pose_.m));
     Px_ = frame_pose_.m[3]; Py_ = frame_pose_.m[7]; Pz_ = frame_pose_.m[11];

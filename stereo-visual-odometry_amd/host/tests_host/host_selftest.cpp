@@ -2,7 +2,58 @@
 //   host_selftest config.yaml image1 [image2 ...]      CPU only: YAML surface and image readers
 //   host_selftest --track config.yaml n_frames         GPU: Step_ros over <dataset_path>/image_{0,1}/%06d.{png,pgm}
 //                                                       with the per-frame carriers filled (fill_features)
+//   host_selftest --orb config.yaml left right          GPU: one lzb_vio::ORBextractor called on the left and then the
+//                                                       right image, as Tracking::Detect_MyORBFeatures does
+//                                                       (reference src/tracking.cpp:508-509); prints byte hashes of
+//                                                       the keypoints, descriptors and of mvImagePyramid
+#include "lzb_vio/ORBextractor.h"
 #include "lzb_vio/System.h"
+
+static unsigned long long hash_bytes(const void *p, size_t n, unsigned long long h = 0)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; i++) h = h * 31 + b[i];
+    return h;
+}
+
+static int orb_mode(int argc, char **argv)
+{
+    if (argc < 5) return 2;
+    if (!lzb_vio::Config::SetParameterFile(argv[2])) return 3;
+    lzb_vio::Parameter p;
+    lzb_vio::ORBextractor ex(p.nFeatures_, p.fScaleFactor_, p.nLevels_, p.fIniThFAST_, p.fMinThFAST_);
+    printf("levels=%d scale=%.6f", ex.GetLevels(), ex.GetScaleFactor());
+    for (float v : ex.GetScaleFactors()) printf(" %.9g", v);
+    for (float v : ex.GetInverseScaleSigmaSquares()) printf(" %.9g", v);
+    printf(" quota");
+    for (int q : ex.FeaturesPerLevel()) printf(" %d", q);
+    printf("\n");
+    static_assert(sizeof(cv::KeyPoint) == 28, "cv::KeyPoint stand-in must be the 28-byte record");
+    for (int i = 3; i <= 4; i++) {
+        cv::Mat img;
+        if (!lzb_vio::ReadImageGray(argv[i], img)) return 4;
+        std::vector<cv::KeyPoint> kps;
+        cv::Mat desc;
+        ex(img, cv::Mat(), kps, desc);
+        if (!ex.Ok()) { fprintf(stderr, "ORBextractor: %s\n", ex.LastError().c_str()); return 5; }
+        unsigned long long hd = 0;
+        for (int r = 0; r < desc.rows; r++) hd = hash_bytes(desc.ptr(r), 32, hd);
+        printf("image%d n=%zu rows=%d cols=%d kp_hash=%llu desc_hash=%llu\n", i - 2, kps.size(), desc.rows, desc.cols,
+               hash_bytes(kps.data(), kps.size() * sizeof(cv::KeyPoint)), hd);
+    }
+    for (size_t l = 0; l < ex.mvImagePyramid.size(); l++) {
+        const cv::Mat &m = ex.mvImagePyramid[l];
+        unsigned long long h = 0;
+        for (int y = 0; y < m.rows; y++) h = hash_bytes(m.ptr(y), (size_t)m.cols, h);
+        printf("pyramid%zu rows=%d cols=%d hash=%llu\n", l, m.rows, m.cols, h);
+    }
+    // an empty image returns an empty set (src/ORBextractor.cpp:994-995)
+    std::vector<cv::KeyPoint> none;
+    cv::Mat nodesc;
+    ex(cv::Mat(), cv::Mat(), none, nodesc);
+    printf("empty n=%zu rows=%d\n", none.size(), nodesc.rows);
+    return 0;
+}
 
 static int track_mode(int argc, char **argv)
 {
@@ -45,6 +96,7 @@ int main(int argc, char **argv)
 {
     if (argc < 2) return 2;
     if (std::string(argv[1]) == "--track") return track_mode(argc, argv);
+    if (std::string(argv[1]) == "--orb") return orb_mode(argc, argv);
     if (!lzb_vio::Config::SetParameterFile(argv[1])) return 3;
     lzb_vio::Parameter p;
     printf("track_mode=%s\n", p.track_mode_.c_str());

@@ -242,6 +242,48 @@ def test_frame_carriers_and_track_dump(host_built, pkg, oracle, small_seq, tmp_p
         assert sum(int(ln.split()[-1]) for ln in T) == sum(int(f[6]) for f in F[1:])
 
 
+@pytest.mark.gpu
+def test_orbextractor_class_matches_oracle(host_built, oracle, small_seq, tmp_path):
+    """lzb_vio::ORBextractor (reference include/lzb_vio/ORBextractor.h:33-75): constructor tables,
+    operator() on the left then the right image (src/tracking.cpp:508-509), getters, and the public
+    mvImagePyramid, which afterwards holds the RIGHT image's pyramid --
+    all compared byte for byte with the oracle through hashes printed by host_selftest --orb."""
+    seq, frames = small_seq
+    L, R = frames[0]
+    h, w = L.shape
+    _write_pgm(tmp_path / "l.pgm", L)
+    _write_pgm(tmp_path / "r.pgm", R)
+    _write_yaml(tmp_path / "c.yaml", str(tmp_path), mode="ORB_stereof2f_pnp")
+    out = subprocess.run([os.path.join(host_built, "host_selftest"), "--orb", str(tmp_path / "c.yaml"), str(tmp_path / "l.pgm"),
+                          str(tmp_path / "r.pgm")], capture_output=True)
+    assert out.returncode == 0, out.stderr.decode()
+    lines = out.stdout.decode().splitlines()
+
+    def bhash(b):
+        hh = 0
+        for v in bytes(b):
+            hh = (hh * 31 + v) & 0xFFFFFFFFFFFFFFFF
+        return hh
+
+    sc, inv, quota, umax = oracle.orb_setup(2000, 1.2, 8)
+    head = lines[0].split()
+    assert head[0] == "levels=8" and head[1] == "scale=1.200000"
+    got_sc = np.array([float(v) for v in head[2:10]], np.float32)
+    got_isig = np.array([float(v) for v in head[10:18]], np.float32)
+    assert np.array_equal(got_sc, sc) and np.array_equal(got_isig, (np.float32(1) / (sc * sc)).astype(np.float32))
+    assert [int(v) for v in head[19:27]] == quota.tolist()
+    for i, img in ((1, L), (2, R)):
+        kp, desc, _ = oracle.orb_extract(img)
+        kv = dict(x.split("=") for x in lines[i].split()[1:])
+        assert int(kv["n"]) == len(kp) == int(kv["rows"]) and int(kv["cols"]) == 32 and len(kp) > 50
+        assert int(kv["kp_hash"]) == bhash(kp.tobytes()) and int(kv["desc_hash"]) == bhash(desc.tobytes())
+    for l in range(8):
+        lvl = oracle.orb_pyramid_level(R, l)                    # the RIGHT image's pyramid
+        kv = dict(x.split("=") for x in lines[3 + l].split()[1:])
+        assert (int(kv["rows"]), int(kv["cols"])) == lvl.shape and int(kv["hash"]) == bhash(lvl.tobytes())
+    assert lines[11] == "empty n=0 rows=0"
+
+
 def test_image_readers_survive_corrupted_files(host_built, tmp_path):
     """PNG / PGM readers (System::NextFrame_kitti replaces cv::imread with them) on truncated,
     bit-flipped and length-corrupted files, built with AddressSanitizer + UBSan: they may refuse a
@@ -279,6 +321,20 @@ def test_image_readers_survive_corrupted_files(host_built, tmp_path):
             fn = str(tmp_path / f"{name}.{i}.bin")
             open(fn, "wb").write(bytes(b))
             files.append(fn)
+        if name.endswith(".png"):
+            # deterministic: IHDR width (bytes 16-19) and height (20-23) overwritten with hostile values --
+            # the reader must refuse them before allocating anything from the header
+            for j, (off, val) in enumerate((o, v) for o in (16, 20) for v in (0x7FFFFFFF, 0xFFFFFFFF, 0x80000000, 65536, 16385, 0)):
+                b = bytearray(data)
+                b[off:off + 4] = struct.pack(">I", val)
+                fn = str(tmp_path / f"{name}.ihdr{j}.bin")
+                open(fn, "wb").write(bytes(b))
+                files.append(fn)
+    # PGM headers with absurd or overflowing dimensions
+    for j, hdr in enumerate((b"P5\n99999999999999999999 4\n255\n", b"P5\n4 2147483647\n255\n", b"P5\n0 0\n255\n", b"P5\n70000 70000\n255\n")):
+        fn = str(tmp_path / f"hdr{j}.pgm.bin")
+        open(fn, "wb").write(hdr + b"\x00" * 64)
+        files.append(fn)
     _write_yaml(tmp_path / "c.yaml", str(tmp_path))
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
     r = subprocess.run([exe, str(tmp_path / "c.yaml"), str(tmp_path / "ok.png")] + files, capture_output=True, env=env, timeout=300)
