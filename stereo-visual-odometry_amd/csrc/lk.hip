@@ -54,8 +54,14 @@ constexpr int W_BITS = 14;
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
-__device__ __forceinline__ int cv_floor(float v) { return __float2int_rd(v); }
+// cvFloor: one instruction (floor + convert; the compiler's __float2int_rd is v_floor_f32 + v_cvt_i32_f32,
+// and on gfx950 conversions issue at half the rate of plain 32-bit adds -- profiles/r02_valu_roof.txt)
+__device__ __forceinline__ int cv_floor(float v)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
 __device__ __forceinline__ uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
 {
@@ -79,17 +85,24 @@ __device__ __forceinline__ float wide_to_f32(int hi, int lo)
 {
     return __builtin_fmaf((float)hi, 65536.f, (float)lo);
 }
-struct Weights { int w00, w01, w10, w11; };
-// iw00 = cvRound((1-a)(1-b) 2^14) ...: the 2^14 scale is folded into the b factors first; scaling
-// by a power of two is exact, so every product rounds exactly as upstream's expression does.
-__device__ __forceinline__ Weights bilinear_weights(float a, float b)
+// The four bilinear weights as the two packed operands of the column-word dot products:
+//   Wa = iw00 | iw10 << 16   (column tap k: window rows A | B),   Wb = iw01 | iw11 << 16   (tap k + 1)
+// iw00 = cvRound((1-a)(1-b) 2^14) ...: the 2^14 scale is folded into the b factors first (scaling by a
+// power of two is exact, so every product rounds exactly as upstream's expression does).  cvRound of
+// 0 <= x <= 2^14 is taken with the 1.5 * 2^23 trick: x + 12582912.f rounds x to the nearest-even
+// integer and leaves it in the low mantissa bits (two full-rate adds instead of v_rndne + v_cvt);
+// the low 16 bits of the sum's bit pattern ARE the weight, so the packing is one v_perm.
+struct PackedWeights { uint32_t Wa, Wb; };
+__device__ __forceinline__ PackedWeights bilinear_weights(float a, float b)
 {
-    Weights w;
+    const float magic = 12582912.f;                            // 0x4B400000
     const float a1 = 1.f - a, b1 = (1.f - b) * (float)(1 << W_BITS), b0 = b * (float)(1 << W_BITS);
-    w.w00 = cv_round(a1 * b1);
-    w.w01 = cv_round(a * b1);
-    w.w10 = cv_round(a1 * b0);
-    w.w11 = (1 << W_BITS) - w.w00 - w.w01 - w.w10;
+    const uint32_t u00 = __float_as_uint(a1 * b1 + magic), u01 = __float_as_uint(a * b1 + magic),
+                   u10 = __float_as_uint(a1 * b0 + magic);     // 0x4B400000 + iw
+    const uint32_t w11 = (uint32_t)(1 << W_BITS) + 3u * 0x4B400000u - u00 - u01 - u10;
+    PackedWeights w;
+    w.Wa = perm_b32(u10, u00, 0x05040100u);
+    w.Wb = perm_b32(w11, u01, 0x05040100u);
     return w;
 }
 
@@ -132,14 +145,18 @@ struct PixLane { int row, seg; bool on; };
 // side in one register per column, which is exactly the operand the bilinear v_dot2 wants:
 //   val_k = dot2(D[k], (w00 | w10 << 16)) + dot2(D[k+1], (w01 | w11 << 16)) + rounding
 // so no lane ever realigns a pixel pair.
-// Outputs: packed patch (Iv, Ix, Iy as 4 pairs each; pair 3 has a zero high half) and the three
-// partial sums of Ix^2, Ix*Iy, Iy^2.
+// Outputs: packed patch derivatives (Ix, Iy as 4 pairs each; pair 3 has a zero high half), the
+// lane's NEGATED constants -sum(I*Ix), -sum(I*Iy) over its 7 pixels, and the three partial sums of
+// Ix^2, Ix*Iy, Iy^2.  The iterations need I only inside sum((J - I) * Ix) = sum(J*Ix) - sum(I*Ix):
+// the second term does not change, so the per-iteration mismatch chain starts from the negated
+// constant instead of subtracting I from every J sample (exact: integers, |partial| < 2^29).
 template <bool EDGE>
 __device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane &pl, int offI, uint32_t Wau,
                                            uint32_t Wbu, int ipx, int ipy, int w, int h,
-                                           uint32_t (&IvP)[4], uint32_t (&IxP)[4], uint32_t (&IyP)[4],
+                                           uint32_t (&IxP)[4], uint32_t (&IyP)[4], int &nIIx, int &nIIy,
                                            int &pA11, int &pA12, int &pA22)
 {
+    uint32_t IvP[4];
     // (lane 63 carries no window pixel: zero weights make its I, Ix, Iy and sums vanish)
     const uint32_t Wa = pl.on ? Wau : 0u, Wb = pl.on ? Wbu : 0u;
     uint32_t R[4][3];
@@ -189,6 +206,7 @@ __device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane 
         iy[k] = dot2(DY[k + 1], Wb, dot2_k(DY[k], Wa, 1 << (W_BITS - 1))) >> W_BITS;
     }
     pA11 = 0; pA12 = 0; pA22 = 0;
+    int sIIx = 0, sIIy = 0;
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         IvP[m] = perm_b32((uint32_t)iv[2 * m + 1], (uint32_t)iv[2 * m], 0x05040100u);
@@ -197,28 +215,38 @@ __device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane 
         pA11 = dot2(IxP[m], IxP[m], pA11);
         pA12 = dot2(IxP[m], IyP[m], pA12);
         pA22 = dot2(IyP[m], IyP[m], pA22);
+        sIIx = dot2(IvP[m], IxP[m], sIIx);
+        sIIy = dot2(IvP[m], IyP[m], sIIy);
     }
+    nIIx = -sIIx; nIIy = -sIIy;
 }
 
 // ---- one iteration's pixel work for one slot --------------------------------------------------
 // Column words C_j = (J[r0][j] | J[r1][j] << 16) pair the two window rows, so a bilinear sample is
 //   val_k = dot2(C_k, (w00 | w10 << 16)) + dot2(C_k+1, (w01 | w11 << 16)) + 2^8
 // (signed 16-bit weights: w11 == -1 needs no special case).
-__device__ __forceinline__ int dot2_z(uint32_t a, uint32_t b)      // a . b + 0, no v_mov of the zero
+__device__ __forceinline__ int dot2_v(uint32_t a, uint32_t b, int c)      // a . b + c, c in a VGPR that stays live
 {
     int r;
-    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ void mismatch_slot(const uint32_t *tileJ, const PixLane &pl, int cx, int cy,
-                                              uint32_t Wa, uint32_t Wb, const uint32_t (&IvP)[4],
-                                              const uint32_t (&IxP)[4], const uint32_t (&IyP)[4], int &pb1, int &pb2)
+// `off` = byte offset of the lane's first J sample inside the slot's tile: (cy + row) * 40 + cx + seg * 7
+// (the slot part is one value broadcast from its control lane, the lane part a constant)
+__device__ __forceinline__ void mismatch_slot(const uint32_t *tileJ, int off, uint32_t Wa, uint32_t Wb,
+                                              const uint32_t (&IxP)[4], const uint32_t (&IyP)[4], int nIIx, int nIIy,
+                                              int &pb1, int &pb2)
 {
     // (ds_read_u8_d16 / _d16_hi straight into register halves would spare the perms, but with
     //  SRAM-ECC on -- gfx950 -- a d16 load zeroes the other half instead of preserving it)
     uint32_t a0, b0, a1, b1;                 // row 0 / row 1: bytes 0-3 (a), 4-7 (b)
-    load8(tileJ + (cy + pl.row) * kTileJDw, cx + pl.seg * 7, a0, b0);
-    load8(tileJ + (cy + pl.row + 1) * kTileJDw, cx + pl.seg * 7, a1, b1);
+    {
+        const uint32_t *p = tileJ + (off >> 2);
+        const int sh = off & 3;              // rows are 40 bytes apart: the same shift for both
+        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], e0 = p[kTileJDw], e1 = p[kTileJDw + 1], e2 = p[kTileJDw + 2];
+        a0 = __builtin_amdgcn_alignbyte(d1, d0, sh); b0 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        a1 = __builtin_amdgcn_alignbyte(e1, e0, sh); b1 = __builtin_amdgcn_alignbyte(e2, e1, sh);
+    }
     uint32_t C[8];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -234,9 +262,10 @@ __device__ __forceinline__ void mismatch_slot(const uint32_t *tileJ, const PixLa
     for (int m = 0; m < 4; m++) {
         const uint32_t vp = m < 3 ? as_u32(as_u16x2(perm_b32((uint32_t)d[2 * m + 1], (uint32_t)d[2 * m], 0x06050201u)) >> one)
                                   : (uint32_t)(d[6] >> (W_BITS - 5));
-        const uint32_t dp = as_u32(as_u16x2(vp) - as_u16x2(IvP[m]));      // packed J - I (13-bit magnitudes)
-        pb1 = m == 0 ? dot2_z(dp, IxP[m]) : dot2(dp, IxP[m], pb1);
-        pb2 = m == 0 ? dot2_z(dp, IyP[m]) : dot2(dp, IyP[m], pb2);
+        // the chains start from - sum(I * Ix), - sum(I * Iy) (see patch_slot); three-operand form for the
+        // first link so that the constant is not copied into the accumulator first
+        pb1 = m == 0 ? dot2_v(vp, IxP[m], nIIx) : dot2(vp, IxP[m], pb1);
+        pb2 = m == 0 ? dot2_v(vp, IyP[m], nIIy) : dot2(vp, IyP[m], pb2);
     }
 }
 
@@ -250,7 +279,9 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
     const float half = 10.f;                     // (winSize - 1) * 0.5
     const float FLT_SCALE = 1.f / (1 << 20);
 
-    uint32_t IvP[kSlots][4], IxP[kSlots][4], IyP[kSlots][4];
+    uint32_t IxP[kSlots][4], IyP[kSlots][4];
+    int nIIx[kSlots], nIIy[kSlots];
+    const int lane_off = pl.row * (kTileJDw * 4) + pl.seg * 7;     // lane part of the J sample offset
     status = 1;
     float nx = 0.f, ny = 0.f;                    // nextPts[i]
     for (int level = g.nlevels - 1; level >= 0; --level) {
@@ -267,9 +298,8 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
         const bool oob = window_oob(ipx, ipy, w, h);
         if (live && oob && level == 0) status = 0;
         bool lvl_on = live && !oob;
-        const Weights wt = bilinear_weights(px - (float)ipx, py - (float)ipy);
-        const uint32_t WIa = ((uint32_t)wt.w00 & 0xFFFFu) | ((uint32_t)wt.w10 << 16);   // column tap k:   rows A | B
-        const uint32_t WIb = ((uint32_t)wt.w01 & 0xFFFFu) | ((uint32_t)wt.w11 << 16);   // column tap k+1
+        const PackedWeights wt = bilinear_weights(px - (float)ipx, py - (float)ipy);
+        const uint32_t WIa = wt.Wa, WIb = wt.Wb;
         const int x0 = (ipx - 1) & ~3;
         const int offI = (ipx - 1) - x0;
 
@@ -301,10 +331,10 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
             const uint32_t W01s = __builtin_amdgcn_readlane(WIa, 4 * s), W23s = __builtin_amdgcn_readlane(WIb, 4 * s);
             const int ipxs = __builtin_amdgcn_readlane(ipx, 4 * s), ipys = __builtin_amdgcn_readlane(ipy, 4 * s);
             if (__builtin_expect(ipxs < 0 || ipxs + kWin >= w || ipys < 0 || ipys + kWin >= h, 0))
-                patch_slot<true>(lds + s * kSlotDw, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IvP[s], IxP[s], IyP[s],
+                patch_slot<true>(lds + s * kSlotDw, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
                                  pA[s][0], pA[s][1], pA[s][2]);
             else
-                patch_slot<false>(lds + s * kSlotDw, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IvP[s], IxP[s], IyP[s],
+                patch_slot<false>(lds + s * kSlotDw, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
                                   pA[s][0], pA[s][1], pA[s][2]);
         }
         wave_lds_fence();                        // the J tiles reuse the I tiles' LDS
@@ -341,12 +371,12 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
                 if (level == 0) status = 0;
                 it_on = false;
             }
-            const Weights wj = bilinear_weights(qx - (float)inx, qy - (float)iny);
-            const uint32_t Wa = ((uint32_t)wj.w00 & 0xFFFFu) | ((uint32_t)wj.w10 << 16);
-            const uint32_t Wb = ((uint32_t)wj.w01 & 0xFFFFu) | ((uint32_t)wj.w11 << 16);
+            const PackedWeights wj = bilinear_weights(qx - (float)inx, qy - (float)iny);
+            const uint32_t Wa = wj.Wa, Wb = wj.Wb;
             int cx = inx - tx0, cy = iny - ty0;
             const bool restage = it_on && ((unsigned)cx > 17u || (unsigned)cy > 10u);
             if (restage) { tx0 = (inx - 8) & ~3; ty0 = iny - 5; cx = inx - tx0; cy = iny - ty0; }
+            const int joff = cy * (kTileJDw * 4) + cx;          // slot part of the J sample offset (bytes)
             const unsigned long long m_it = __ballot(it_on), m_rs = __ballot(restage);
             int pb[kSlots][2];
 #pragma unroll
@@ -364,9 +394,9 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
                     }
                     wave_lds_fence();
                 }
-                const int cxs = __builtin_amdgcn_readlane(cx, 4 * s), cys = __builtin_amdgcn_readlane(cy, 4 * s);
+                const int joffs = __builtin_amdgcn_readlane(joff, 4 * s);
                 const uint32_t Was = __builtin_amdgcn_readlane(Wa, 4 * s), Wbs = __builtin_amdgcn_readlane(Wb, 4 * s);
-                mismatch_slot(tile, pl, cxs, cys, Was, Wbs, IvP[s], IxP[s], IyP[s], pb[s][0], pb[s][1]);
+                mismatch_slot(tile, joffs + lane_off, Was, Wbs, IxP[s], IyP[s], nIIx[s], nIIy[s], pb[s][0], pb[s][1]);
             }
             float b1f, b2f;
             {
@@ -407,6 +437,10 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
     outPt = make_float2(nx, ny);
 }
 
+// Grid: blockIdx.y = batch item; the gridDim.x workgroups of an item walk its points in strides of
+// gridDim.x * 16 (four waves x four slots), so the launch is sized from the batch, not from the
+// keypoint CAPACITY: cv::FAST is uncapped and the capacity is generous, a grid of capacity / 16
+// workgroups per item was mostly empty waves.  No workgroup barrier anywhere: each wave loops on its own.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void lk_kernel(LkArgs a)
 {
     __shared__ uint32_t lds[4 * kLdsDwPerWave];
@@ -415,43 +449,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int slot = (lane >> 2) & 3;
     int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
     n = min(n, a.cap);
-    const int first = (blockIdx.x * 4 + wave) * kSlots;
-    if (first >= n) return;
-    const int idx = first + slot;
-    const bool valid = idx < n;
-    const bool writer = valid && lane == 4 * slot;         // one lane per slot stores results
     uint32_t *my = lds + wave * kLdsDwPerWave;
-    const int64_t po = (int64_t)b * a.pts_stride + (valid ? idx : first);
-    const float2 p0 = a.pts_in[po];
-    float2 cur = p0, nxt;
-    bool outside = p0.x < 0 || p0.y < 0, bad = false, noepi = false;
-    bool live = valid;
-    float prev_y = p0.y;
+    for (int first = (blockIdx.x * 4 + wave) * kSlots; first < n; first += gridDim.x * 4 * kSlots) {
+        const int idx = first + slot;
+        const bool valid = idx < n;
+        const bool writer = valid && lane == 4 * slot;         // one lane per slot stores results
+        const int64_t po = (int64_t)b * a.pts_stride + (valid ? idx : first);
+        const float2 p0 = a.pts_in[po];
+        float2 cur = p0, nxt;
+        bool outside = p0.x < 0 || p0.y < 0, bad = false, noepi = false;
+        bool live = valid;
+        float prev_y = p0.y;
 #pragma nounroll
-    for (int c = 0; c < a.ncalls; c++) {
-        const uint8_t *sI = a.prev[c] + (int64_t)b * a.slot_stride;
-        const uint8_t *sJ = a.next[c] + (int64_t)b * a.slot_stride;
-        int st;
-        lk_call4(a.g, sI, sJ, cur, nxt, st, live, my, lane);
-        if (writer && live) {
-            a.pts_out[c][po] = nxt;
-            a.status[c][po] = (uint8_t)st;
+        for (int c = 0; c < a.ncalls; c++) {
+            const uint8_t *sI = a.prev[c] + (int64_t)b * a.slot_stride;
+            const uint8_t *sJ = a.next[c] + (int64_t)b * a.slot_stride;
+            int st;
+            lk_call4(a.g, sI, sJ, cur, nxt, st, live, my, lane);
+            if (writer && live) {
+                a.pts_out[c][po] = nxt;
+                a.status[c][po] = (uint8_t)st;
+            }
+            // Tracking::deleteBadmatchFeatures terms (p0 = t1_left, p1 = t1_right, p2 = t2_right,
+            // p3 = t2_left, p0_return = LK#4 output; call-site mapping src/tracking.cpp:619-620)
+            if (live) {
+                outside = outside || nxt.x < 0 || nxt.y < 0;
+                bad = bad || st == 0;
+                if (c == 0 || c == 2) noepi = noepi || (double)fabsf(prev_y - nxt.y) > a.match_err;   // |y0-y1|, |y2-y3|
+                prev_y = nxt.y;
+                cur = nxt;
+            }
+            // a rejected point can never be kept: the remaining calls of the circular chain only feed
+            // the keep predicate (their pts_out/status entries are scratch in the fused mode)
+            if (a.ncalls == 4 && (outside || bad || noepi)) live = false;
+            if (!__any(live)) break;
         }
-        // Tracking::deleteBadmatchFeatures terms (p0 = t1_left, p1 = t1_right, p2 = t2_right,
-        // p3 = t2_left, p0_return = LK#4 output; call-site mapping src/tracking.cpp:619-620)
-        if (live) {
-            outside = outside || nxt.x < 0 || nxt.y < 0;
-            bad = bad || st == 0;
-            if (c == 0 || c == 2) noepi = noepi || (double)fabsf(prev_y - nxt.y) > a.match_err;   // |y0-y1|, |y2-y3|
-            prev_y = nxt.y;
-            cur = nxt;
-        }
-        // a rejected point can never be kept: the remaining calls of the circular chain only feed
-        // the keep predicate (their pts_out/status entries are scratch in the fused mode)
-        if (a.ncalls == 4 && (outside || bad || noepi)) live = false;
-        if (!__any(live)) break;
+        if (a.ncalls == 4 && writer) a.keep[po] = !(outside || bad || noepi);
+        wave_lds_fence();                                      // the next chunk restages this wave's tiles
     }
-    if (a.ncalls == 4 && writer) a.keep[po] = !(outside || bad || noepi);
 }
 
 // Stable compaction (deleteBadmatchFeatures erases in place, preserving order): one workgroup of
@@ -491,7 +526,14 @@ __global__ __launch_bounds__(1024) void compact_kernel(CompactArgs a)
 void launch_lk(const LkArgs &a, int batch, int max_pts, hipStream_t st)
 {
     if (max_pts <= 0 || batch <= 0) return;
-    dim3 grid((max_pts + 4 * kSlots - 1) / (4 * kSlots), batch, 1), blk(256, 1, 1);
+    // about 8 k workgroups per launch (8 per CU-slot of the 256 CUs x 4), at least 4 and at most
+    // capacity / 16 per item: a single pair (online) still spreads over the whole chip, a 256-pair
+    // batch launches 32 workgroups per pair that each walk ~5 chunks of 16 points
+    const int chunks = (max_pts + 4 * kSlots - 1) / (4 * kSlots);
+    int gx = (8192 + batch - 1) / batch;
+    gx = gx < 4 ? 4 : gx;
+    gx = gx > chunks ? chunks : gx;
+    dim3 grid(gx, batch, 1), blk(256, 1, 1);
     hipLaunchKernelGGL(lk_kernel, grid, blk, 0, st, a);
 }
 
