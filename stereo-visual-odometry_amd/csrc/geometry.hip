@@ -6,15 +6,13 @@
 //
 // Kernels
 //   triangulate_kernel : one thread per point, 4x4 DLT + one-sided Jacobi SVD in f64.
-//   pnp_ransac_kernel  : one 64-lane workgroup per frame pair.  Hypotheses are evaluated 64 at a
-//       time -- lane h runs the 5-point EPnP of hypothesis base+h (its 12x12 eigenproblem lives in
-//       a lane-interleaved 72 KB LDS image) and scores it against all M points -- then the wave
-//       replays OpenCV's sequential "better model -> shrink niters" rule over the 64 inlier counts,
-//       so the winning hypothesis, the adaptive stop and the inlier mask are exactly those of the
-//       serial algorithm.  The RNG (cv::RNG multiply-with-carry, seed 2^64-1) is stepped by every
-//       lane identically.  The refit on the inliers is LM on 6 parameters with the residual /
-//       J^T J / J^T e reductions done across the wave (butterfly all-reduce, every lane holds
-//       bit-identical sums and takes the same branches).
+//   pnp_begin / pnp_hyp / pnp_score / pnp_select / pnp_refit : solvePnPRansac as a pipeline of
+//       launches -- EPnP hypotheses 64 per workgroup (one per lane, 12x12 eigenproblem in LDS), all
+//       blocks of a phase concurrently; inlier counts over many workgroups; OpenCV's sequential
+//       model-selection rule replayed over the counts in order (exactly the serial algorithm's
+//       winner, adaptive stop and mask; the cv::RNG multiply-with-carry sequence, seed 2^64-1, is
+//       drawn serially); LM refit on the inliers with 256 threads per pair.  Details above
+//       struct PnpRecord.
 //   finalize_kernel    : per pair failure staging, Euler / translation gates, inv([R t;0 1]).
 //   chain_kernel       : frame_pose_ *= T^-1 over the batch, skipping failed steps.
 #include <cstring>
@@ -56,10 +54,41 @@ __global__ __launch_bounds__(64) void triangulate_kernel(TriArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// solvePnPRansac as a short pipeline of launches (all on one stream, no host round trip):
+//
+//   pnp_begin    : per item state (niters, best model, cv::RNG state) + the first 64 point subsets
+//   per PHASE p (phase 0 = hypotheses 0..63, later phases up to 448 hypotheses each):
+//     pnp_hyp    : one 64-lane workgroup per block of 64 hypotheses: lane h runs the 5-point EPnP of
+//                  hypothesis base+h (12x12 eigenproblem in a lane-interleaved 72 KB LDS image) -- the
+//                  blocks of a phase run CONCURRENTLY (the single-wave version ran them one after the
+//                  other: 8 x the EPnP latency at iterationsCount 500 with few inliers);
+//     pnp_score  : inlier counts of every hypothesis of the phase, points spread over many
+//                  workgroups (lane = hypothesis, four waves x grid.z point chunks; integer counts
+//                  added with atomics: order-free, exact);
+//     pnp_select : replays OpenCV's sequential "better model -> shrink niters" rule over the counts
+//                  in hypothesis order, so the winner, the adaptive stop and the iteration count are
+//                  exactly those of the serial algorithm; then draws the next phase's subsets (the
+//                  RNG is inherently serial: one lane) if the rule still wants more hypotheses.
+//                  Hypotheses past the stop were computed speculatively and are ignored; workgroups
+//                  of a phase that is not needed exit on their first instruction.
+//   pnp_refit    : inlier mask of the winner + Levenberg-Marquardt on the inliers with 256 threads
+//                  per item (block-wide reductions in a fixed order; every thread sees identical sums).
+//
+// Exactness: hypotheses, counts, winner, stop and mask are bit-identical to the oracle (same
+// expressions, IEEE f64); only the LM sums are associated differently (observed pose error <= 1e-9).
 struct PnpRecord {                 // device-side record of one solve
     double rvec[3], tvec[3], R[9];
     int n_inliers, ransac_iters, best_iter, lm_iters, ok, n;
 };
+
+constexpr int kHypBlock = 64;                  // hypotheses per EPnP workgroup (one per lane)
+constexpr int kPhaseHyps = 448;                // hypotheses of a phase after the first: 64 + 448 = 512 >= iterationsCount 500
+struct PnpState {                              // per item, lives across the launches of one solve
+    double bestRt[12];
+    uint64_t rng;
+    int n, niters, max_good, best_iter, iters_done, next_base, phase_hyps, _pad;
+};
+struct PnpHyp { double R[9], t[3]; };
 
 struct PnpArgs {
     const float *X3; const float2 *img; int64_t stride;     // points of item b at + b*stride
@@ -68,6 +97,8 @@ struct PnpArgs {
     int iterations; float reproj_err; double confidence;
     uint8_t *mask;                                          // stride bytes per item
     PnpRecord *out;
+    PnpState *state; PnpHyp *hyp; int *counts; int *subsets;   // per item: 1, kPhaseHyps, kPhaseHyps, 2 x 5 * kPhaseHyps
+    int phase_base, phase_cap, phase_index;                 // hypotheses [phase_base, phase_base + phase_cap) in this phase
 };
 
 __device__ inline double wave_allsum_f64(double v)
@@ -77,10 +108,211 @@ __device__ inline double wave_allsum_f64(double v)
     return v;
 }
 
-// One LM evaluation over the masked points: err norm^2, optionally J^T J (upper, 21) and J^T e (6).
+// cv::RNG draws for RANSACPointSetRegistrator::getSubset.  The generator is a serial chain
+// (multiply-with-carry) and the number of draws per subset depends on the data (a duplicate index is
+// redrawn), so subsets are drawn by ONE wave, and everything is kept wave-uniform: the compiler
+// then runs the chain on the scalar unit (s_mul_i32 / s_mul_hi_u32, ~5x shorter latency per step
+// than the vector unit; drawn by a single divergent lane 64 subsets took 41 us).  x % n is one
+// multiply-high by floor(2^32 / n) and at most two corrections instead of a 32-bit division.
+struct FastMod { uint32_t n, m; };
+__device__ inline FastMod fastmod_make(uint32_t n) { FastMod f; f.n = n; f.m = n > 1 ? (uint32_t)(0x100000000ull / n) : 0u; return f; }
+__device__ inline uint32_t fastmod(uint32_t x, FastMod f)
+{
+    uint32_t r = x - __umulhi(x, f.m) * f.n;             // quotient estimate is low by at most 2
+    if (r >= f.n) r -= f.n;
+    if (r >= f.n) r -= f.n;
+    return r;
+}
+__device__ inline uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// `count` consecutive subsets into dst[5 * count]; all lanes of the wave call this with the same
+// arguments, lanes 0..4 store.  Returns the advanced state.
+__device__ inline uint64_t draw_subsets(uint64_t rng_in, int n, int count, int *dst, int lane)
+{
+    uint32_t lo = sgpr((uint32_t)rng_in), hi = sgpr((uint32_t)(rng_in >> 32));
+    const FastMod fm = fastmod_make(sgpr((uint32_t)n));
+    if (fm.n <= 1) return rng_in;
+    for (int h = 0; h < count; h++) {
+        uint32_t idx[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            for (;;) {
+                // state = (uint32)state * 4164903690 + (state >> 32)
+                const uint64_t st = (uint64_t)lo * 4164903690u + hi;
+                lo = sgpr((uint32_t)st); hi = sgpr((uint32_t)(st >> 32));
+                idx[i] = sgpr(fastmod(lo, fm));
+                bool dup = false;
+#pragma unroll
+                for (int j = 0; j < i; j++) dup = dup || idx[j] == idx[i];
+                if (!dup) break;
+            }
+        }
+        const uint32_t mine = lane == 0 ? idx[0] : lane == 1 ? idx[1] : lane == 2 ? idx[2] : lane == 3 ? idx[3] : idx[4];
+        if (lane < 5) dst[h * 5 + lane] = (int)mine;
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Subsets are double-buffered by phase parity: while the EPnP blocks of phase p run, one extra
+// workgroup of the same launch draws the subsets phase p+1 would need (they depend on the RNG state
+// only, not on the selection), so the serial drawing never sits on the critical path.
+__global__ __launch_bounds__(64) void pnp_begin_kernel(PnpArgs a)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
+    PnpState *st = a.state + b;
+    int *counts = a.counts + (int64_t)b * kPhaseHyps;
+    for (int i = lane; i < kPhaseHyps; i += 64) counts[i] = 0;
+    const int niters = a.iterations > 1 ? a.iterations : 1;
+    uint64_t rng = ~0ull;
+    int *sub = a.subsets + (int64_t)b * 2 * kPhaseHyps * 5;         // phase 0 -> buffer 0
+    int hyps = 0;
+    if (n >= 5) {
+        hyps = niters < kHypBlock ? niters : kHypBlock;
+        if (n > 5) rng = draw_subsets(rng, n, hyps, sub, lane);
+        else { hyps = 1; if (lane < 5) sub[lane] = lane; }          // npoints == model_points: one solve, all inliers
+    }
+    if (lane != 0) return;
+    st->n = n; st->niters = niters;
+    st->max_good = 0; st->best_iter = -1; st->iters_done = 0; st->next_base = 0;
+    st->phase_hyps = hyps;
+    st->rng = rng;
+}
+
+constexpr size_t kPnpLdsBytes = (size_t)(144 * 64) * sizeof(double);
+// The LDS image is declared dynamic so that the compiler does not know it limits the kernel to two
+// workgroups per CU: it would otherwise hand the single wave all 512 registers of its SIMD, which
+// starves every kernel that overlaps the pose stage (DESIGN.md section 6).  With two waves per EU
+// as the target it gets 256 (architectural + accumulation; spills go to the latter, not to memory).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void pnp_hyp_kernel(PnpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double pnp_smem[];
+    const int lane = threadIdx.x, b = blockIdx.y;
+    PnpState *st = a.state + b;
+    const int h = blockIdx.x * kHypBlock + lane;             // hypothesis index inside the phase
+    if (st->next_base != a.phase_base) return;               // phase not needed
+    if (blockIdx.x == gridDim.x - 1) {
+        // the drawer: subsets of the NEXT phase into the other buffer (see pnp_begin_kernel)
+        const int next = a.phase_base + a.phase_cap, niters = a.iterations > 1 ? a.iterations : 1;
+        const int n = st->n;
+        if (next < niters && n > 5 && st->phase_hyps > 0) {
+            const int more = niters - next < kPhaseHyps ? niters - next : kPhaseHyps;
+            const uint64_t rng = draw_subsets(st->rng, n, more, a.subsets + ((int64_t)b * 2 + (a.phase_index + 1) % 2) * kPhaseHyps * 5, lane);
+            if (lane == 0) st->rng = rng;
+        }
+        return;
+    }
+    if (blockIdx.x * kHypBlock >= st->phase_hyps) return;    // block beyond the phase
+    if (h >= st->phase_hyps) return;                         // EPnP is lane-private: idle lanes just leave
+    const float *X3 = a.X3 + (int64_t)b * a.stride * 3;
+    const float2 *img = a.img + (int64_t)b * a.stride;
+    const int *my = a.subsets + (((int64_t)b * 2 + a.phase_index % 2) * kPhaseHyps + h) * 5;
+    const double fx = a.fx, fy = a.fy, cx = a.cx, cy = a.cy;
+    // PnPRansacCallback::runKernel: solvePnP(EPNP) on the 5 samples
+    Epnp5 e;
+    e.fu = fx; e.fv = fy; e.uc = cx; e.vc = cy;
+    for (int i = 0; i < 5; i++) {
+        const int s = my[i];
+        e.pws[3 * i] = (double)X3[3 * s]; e.pws[3 * i + 1] = (double)X3[3 * s + 1]; e.pws[3 * i + 2] = (double)X3[3 * s + 2];
+        const float2 m = img[s];
+        // undistortPoints (float output, zero distortion), then epnp::init_points' x*fu + uc
+        const float xn = (float)(((double)m.x - cx) * (1. / fx));
+        const float yn = (float)(((double)m.y - cy) * (1. / fy));
+        e.us[2 * i] = (double)xn * fx + cx;
+        e.us[2 * i + 1] = (double)yn * fy + cy;
+    }
+    PnpHyp out;
+    epnp5_d(e, pnp_smem + lane, 64, out.R, out.t);
+    a.hyp[(int64_t)b * kPhaseHyps + h] = out;
+}
+
+// findInliers for the hypotheses of the phase: grid (blocks of 64 hypotheses, items, point chunks),
+// 256 threads; lane = hypothesis, the workgroup's points are staged in LDS 256 at a time and every
+// wave takes a quarter of them (LDS broadcast reads).
+constexpr int kScoreChunk = 1024;              // points per workgroup (grid.z chunks)
+__global__ __launch_bounds__(256) void pnp_score_kernel(PnpArgs a)
+{
+    __shared__ float sP[256 * 5];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const PnpState *st = a.state + b;
+    const int n = st->n;
+    const int h = blockIdx.x * kHypBlock + lane;
+    if (st->next_base != a.phase_base || blockIdx.x * kHypBlock >= st->phase_hyps || n <= 5) return;
+    const int i0 = blockIdx.z * kScoreChunk, i1 = min(n, i0 + kScoreChunk);
+    if (i0 >= n) return;
+    const float *X3 = a.X3 + (int64_t)b * a.stride * 3;
+    const float2 *img = a.img + (int64_t)b * a.stride;
+    const bool active = h < st->phase_hyps;
+    PnpHyp H;
+    if (active) H = a.hyp[(int64_t)b * kPhaseHyps + h];
+    else { for (int q = 0; q < 9; q++) H.R[q] = 0; H.t[0] = H.t[1] = H.t[2] = 0; }
+    const float thr2 = (float)((double)a.reproj_err * (double)a.reproj_err);
+    int good = 0;
+    for (int c0 = i0; c0 < i1; c0 += 256) {
+        __syncthreads();
+        const int i = c0 + threadIdx.x;
+        if (i < i1) {
+            const float2 m = img[i];
+            sP[threadIdx.x * 5] = X3[3 * i]; sP[threadIdx.x * 5 + 1] = X3[3 * i + 1]; sP[threadIdx.x * 5 + 2] = X3[3 * i + 2];
+            sP[threadIdx.x * 5 + 3] = m.x; sP[threadIdx.x * 5 + 4] = m.y;
+        }
+        __syncthreads();
+        const int cnt = min(256, i1 - c0);
+        for (int k = wave; k < cnt; k += 4) {
+            const float *q = sP + k * 5;
+            good += reproj_err2_d(H.R, H.t, a.fx, a.fy, a.cx, a.cy, q[0], q[1], q[2], q[3], q[4]) <= thr2;
+        }
+    }
+    if (active && good) atomicAdd(a.counts + (int64_t)b * kPhaseHyps + h, good);
+}
+
+__global__ __launch_bounds__(64) void pnp_select_kernel(PnpArgs a)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    PnpState *st = a.state + b;
+    if (st->next_base != a.phase_base || st->phase_hyps <= 0) return;
+    int *counts = a.counts + (int64_t)b * kPhaseHyps;
+    const int n = st->n, model_points = 5;
+    const int hyps = st->phase_hyps;
+    if (lane == 0) {
+        int niters = st->niters, max_good = st->max_good, best_iter = st->best_iter, iters_done = st->iters_done, owner = -1;
+        for (int h = 0; h < hyps; h++) {
+            const int it = a.phase_base + h;
+            if (it >= niters) break;
+            const int g = n == model_points ? n : counts[h];
+            iters_done = it + 1;
+            if (n == model_points || g > (max_good > model_points - 1 ? max_good : model_points - 1)) {
+                max_good = g; best_iter = it; owner = h;
+                if (n == model_points) { niters = it + 1; break; }
+                niters = ransac_update_iters_d(a.confidence, (double)(n - g) / n, model_points, niters);
+            }
+        }
+        if (owner >= 0) {
+            const PnpHyp *H = a.hyp + (int64_t)b * kPhaseHyps + owner;
+            for (int i = 0; i < 9; i++) st->bestRt[i] = H->R[i];
+            for (int i = 0; i < 3; i++) st->bestRt[9 + i] = H->t[i];
+        }
+        st->niters = niters; st->max_good = max_good; st->best_iter = best_iter; st->iters_done = iters_done;
+        // the next phase, if the rule still wants hypotheses beyond this one (its subsets were drawn
+        // beside this phase's EPnP blocks)
+        const int next = a.phase_base + a.phase_cap;
+        int more = 0;
+        if (next < niters && n > model_points) more = niters - next < kPhaseHyps ? niters - next : kPhaseHyps;
+        st->phase_hyps = more;
+        st->next_base = more > 0 ? next : -1;
+    }
+    __syncthreads();
+    for (int i = lane; i < kPhaseHyps; i += 64) counts[i] = 0;          // ready for the next phase's atomics
+}
+
+// One LM evaluation over the masked points by a 256-thread workgroup: err norm^2, optionally
+// J^T J (upper, 21) and J^T e (6).  Partial sums per thread (points tid, tid + 256, ...), wave
+// butterfly, then the four wave sums added in wave order by every thread: all threads hold
+// bit-identical totals and take the same branches.
+constexpr int kRefitThreads = 256;
 __device__ inline double lm_eval(const double param[6], const float *X3, const float2 *img,
                                  const uint8_t *mask, int n, double fx, double fy, double cx, double cy,
-                                 int lane, double *JtJ, double *JtErr)
+                                 double *red /* LDS: 4 x 28 */, double *JtJ, double *JtErr)
 {
     double R[9], dRdr[27];
     rodrigues_vec2mat_d(param, R, JtJ ? dRdr : nullptr);
@@ -88,7 +320,7 @@ __device__ inline double lm_eval(const double param[6], const float *X3, const f
     double acc[28];
     const int nacc = JtJ ? 28 : 1;
     for (int k = 0; k < nacc; k++) acc[k] = 0;
-    for (int i = lane; i < n; i += 64) {
+    for (int i = threadIdx.x; i < n; i += kRefitThreads) {
         if (!mask[i]) continue;
         double X = X3[3 * i], Y = X3[3 * i + 1], Z = X3[3 * i + 2];
         double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
@@ -120,7 +352,14 @@ __device__ inline double lm_eval(const double param[6], const float *X3, const f
             for (int r = 0; r < 6; r++) acc[q++] += Jx[r] * ex + Jy[r] * ey;
         }
     }
-    for (int k = 0; k < nacc; k++) acc[k] = wave_allsum_f64(acc[k]);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();                                        // `red` may still be read from the previous call
+    for (int k = 0; k < nacc; k++) {
+        const double w = wave_allsum_f64(acc[k]);
+        if (lane == 0) red[wave * 28 + k] = w;
+    }
+    __syncthreads();
+    for (int k = 0; k < nacc; k++) acc[k] = ((red[k] + red[28 + k]) + red[56 + k]) + red[84 + k];
     if (JtJ) {
         int q = 1;
         for (int r = 0; r < 6; r++)
@@ -130,129 +369,57 @@ __device__ inline double lm_eval(const double param[6], const float *X3, const f
     return acc[0];
 }
 
-constexpr size_t kPnpLdsBytes = (size_t)(144 * 64 + 16) * sizeof(double);
-// The LDS image is declared dynamic so that the compiler does not know it limits the kernel to two
-// workgroups per CU: it would otherwise hand the single wave all 512 registers of its SIMD, which
-// starves every kernel that overlaps the pose stage (DESIGN.md section 6).  With two waves per EU
-// as the target it gets 256 (architectural + accumulation; spills go to the latter, not to memory).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void pnp_ransac_kernel(PnpArgs a)
+constexpr size_t kRefitLdsBytes = (size_t)(72 * 64 + 4 * 28 + 8) * sizeof(double);
+__global__ __launch_bounds__(kRefitThreads) void pnp_refit_kernel(PnpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double pnp_smem[];
-    double *big = pnp_smem;                   // lane-interleaved 12x12 work matrices (73,728 B)
-    double *bestRt = pnp_smem + 144 * 64;
-    const int lane = threadIdx.x, b = blockIdx.x;
-    const int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
+    double *ws = pnp_smem;                    // lane-interleaved 6x6 SVD workspace of wave 0 (36,864 B)
+    double *red = pnp_smem + 72 * 64;         // 4 x 28 wave sums
+    double *bcast = red + 4 * 28;             // 6 parameters + flags handed from wave 0 to the others
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const PnpState *st = a.state + b;
+    const int n = st->n;
     const float *X3 = a.X3 + (int64_t)b * a.stride * 3;
     const float2 *img = a.img + (int64_t)b * a.stride;
     uint8_t *mask = a.mask + (int64_t)b * a.stride;
     PnpRecord *out = a.out + b;
     const int model_points = 5;
-
-    if (n < model_points) {       // npoints == 4 would take OpenCV's P3P kernel: out of scope, no solution
-        if (lane == 0) {
+    const int max_good = st->max_good;
+    if (n < model_points || max_good <= 0) {
+        // npoints == 4 would take OpenCV's P3P kernel: out of scope, no solution.  max_good == 0:
+        // solvePnPRansac returns false, rvec/tvec stay at the caller's zeros, no inliers
+        if (tid == 0) {
             for (int i = 0; i < 3; i++) { out->rvec[i] = 0; out->tvec[i] = 0; }
             for (int i = 0; i < 9; i++) out->R[i] = (i % 4 == 0) ? 1.0 : 0.0;
-            out->n_inliers = 0; out->ransac_iters = 0; out->best_iter = -1; out->lm_iters = 0; out->ok = 0; out->n = n;
+            out->n_inliers = 0; out->ransac_iters = n < model_points ? 0 : st->iters_done; out->best_iter = -1;
+            out->lm_iters = 0; out->ok = 0; out->n = n;
         }
-        for (int i = lane; i < n; i += 64) mask[i] = 0;
+        for (int i = tid; i < n; i += kRefitThreads) mask[i] = 0;
         return;
     }
     const double fx = a.fx, fy = a.fy, cx = a.cx, cy = a.cy;
     const float thr2 = (float)((double)a.reproj_err * (double)a.reproj_err);
-    int niters = a.iterations > 1 ? a.iterations : 1;
-    int max_good = 0, best_iter = -1, iters_done = 0;
-    uint64_t rng = ~0ull;
-
-    for (int base = 0; base < niters; base += 64) {
-        // ---- RANSACPointSetRegistrator::getSubset for hypotheses base .. base+63
-        int my[5] = {0, 1, 2, 3, 4};
-        if (n > model_points) {
-            for (int h = 0; h < 64; h++) {
-                int idx[5];
-                for (int i = 0; i < model_points;) {
-                    int j, idx_i;
-                    for (;;) {
-                        idx_i = idx[i] = (int)(rng_next_d(rng) % (unsigned)n);
-                        for (j = 0; j < i; j++) if (idx_i == idx[j]) break;
-                        if (j == i) break;
-                    }
-                    i++;
-                }
-                if (h == lane) { my[0] = idx[0]; my[1] = idx[1]; my[2] = idx[2]; my[3] = idx[3]; my[4] = idx[4]; }
-            }
-        }
-        // ---- PnPRansacCallback::runKernel: solvePnP(EPNP) on the 5 samples
-        Epnp5 e;
-        e.fu = fx; e.fv = fy; e.uc = cx; e.vc = cy;
-        for (int i = 0; i < model_points; i++) {
-            const int s = my[i];
-            e.pws[3 * i] = (double)X3[3 * s]; e.pws[3 * i + 1] = (double)X3[3 * s + 1]; e.pws[3 * i + 2] = (double)X3[3 * s + 2];
-            const float2 m = img[s];
-            // undistortPoints (float output, zero distortion), then epnp::init_points' x*fu + uc
-            const float xn = (float)(((double)m.x - cx) * (1. / fx));
-            const float yn = (float)(((double)m.y - cy) * (1. / fy));
-            e.us[2 * i] = (double)xn * fx + cx;
-            e.us[2 * i + 1] = (double)yn * fy + cy;
-        }
-        double R[9], t[3];
-        epnp5_d(e, big + lane, 64, R, t);
-        // ---- findInliers
-        int good = 0;
-        if (n > model_points) {
-            for (int i = 0; i < n; i++) {
-                const float2 m = img[i];
-                good += reproj_err2_d(R, t, fx, fy, cx, cy, X3[3 * i], X3[3 * i + 1], X3[3 * i + 2], m.x, m.y) <= thr2;
-            }
-        } else {
-            good = n;
-        }
-        // ---- replay the serial model-selection rule over this round's hypotheses
-        int owner = -1;
-        for (int h = 0; h < 64; h++) {
-            const int it = base + h;
-            if (it >= niters) break;
-            const int g = __builtin_amdgcn_readlane(good, h);
-            iters_done = it + 1;
-            if (n == model_points || g > (max_good > model_points - 1 ? max_good : model_points - 1)) {
-                max_good = g; best_iter = it; owner = h;
-                if (n == model_points) { niters = it + 1; break; }
-                niters = ransac_update_iters_d(a.confidence, (double)(n - g) / n, model_points, niters);
-            }
-        }
-        if (owner >= 0) {
-            wave_lds_fence();
-            if (lane == owner) {
-                for (int i = 0; i < 9; i++) bestRt[i] = R[i];
-                for (int i = 0; i < 3; i++) bestRt[9 + i] = t[i];
-            }
-            wave_lds_fence();
-        }
-    }
-
-    if (max_good <= 0) {
-        // solvePnPRansac returns false: rvec/tvec stay at the caller's zeros, no inliers
-        if (lane == 0) {
-            for (int i = 0; i < 3; i++) { out->rvec[i] = 0; out->tvec[i] = 0; }
-            for (int i = 0; i < 9; i++) out->R[i] = (i % 4 == 0) ? 1.0 : 0.0;
-            out->n_inliers = 0; out->ransac_iters = iters_done; out->best_iter = -1; out->lm_iters = 0; out->ok = 0; out->n = n;
-        }
-        for (int i = lane; i < n; i += 64) mask[i] = 0;
-        return;
-    }
     double bR[9], bt[3];
-    for (int i = 0; i < 9; i++) bR[i] = bestRt[i];
-    for (int i = 0; i < 3; i++) bt[i] = bestRt[9 + i];
-    for (int i = lane; i < n; i += 64) {
+    for (int i = 0; i < 9; i++) bR[i] = st->bestRt[i];
+    for (int i = 0; i < 3; i++) bt[i] = st->bestRt[9 + i];
+    for (int i = tid; i < n; i += kRefitThreads) {
         const float2 m = img[i];
         mask[i] = (n == model_points) ? 1
                   : (uint8_t)(reproj_err2_d(bR, bt, fx, fy, cx, cy, X3[3 * i], X3[3 * i + 1], X3[3 * i + 2], m.x, m.y) <= thr2);
     }
     __threadfence_block();
-    wave_lds_fence();
+    __syncthreads();
 
-    // ---- refit on the inliers: solvePnP(ITERATIVE, useExtrinsicGuess) == CvLevMarq on 6 params
+    // ---- refit on the inliers: solvePnP(ITERATIVE, useExtrinsicGuess) == CvLevMarq on 6 params.
+    // Every thread carries the same scalars; the 6x6 SVD solves run on wave 0 (lane-interleaved LDS
+    // workspace, all its lanes redundantly) and the new parameters reach the other waves through LDS.
     double param[6], prevParam[6], JtJ[36], JtErr[6];
-    rodrigues_mat2vec_d(bR, param, big + lane, 64);
+    if (wave == 0) {
+        rodrigues_mat2vec_d(bR, param, ws + lane, 64);
+        if (lane == 0) for (int i = 0; i < 3; i++) bcast[i] = param[i];
+    }
+    __syncthreads();
+    for (int i = 0; i < 3; i++) param[i] = bcast[i];
     param[3] = bt[0]; param[4] = bt[1]; param[5] = bt[2];
     const double POW10[33] = {1e-16, 1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6,
                               1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8,
@@ -262,18 +429,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double prevErrNorm = 1.7976931348623157e308, errNorm;
     int lambdaLg10 = -3, iters = 0;
     for (;;) {
-        double e2 = lm_eval(param, X3, img, mask, n, fx, fy, cx, cy, lane, JtJ, JtErr);
+        double e2 = lm_eval(param, X3, img, mask, n, fx, fy, cx, cy, red, JtJ, JtErr);
         for (int i = 0; i < 6; i++) prevParam[i] = param[i];
         if (iters == 0) prevErrNorm = sqrt(e2);
         bool done = false;
         for (;;) {
-            double A[36], x[6];
             const double lambda = POW10[lambdaLg10 + 16];
-            for (int i = 0; i < 36; i++) A[i] = JtJ[i];
-            for (int i = 0; i < 6; i++) A[i * 6 + i] *= 1. + lambda;
-            svd_solve_d<6, 6>(A, JtErr, x, big + lane, 64);
-            for (int i = 0; i < 6; i++) param[i] = prevParam[i] - x[i];
-            errNorm = sqrt(lm_eval(param, X3, img, mask, n, fx, fy, cx, cy, lane, nullptr, nullptr));
+            __syncthreads();                                 // bcast is free again
+            if (wave == 0) {
+                double A[36], x[6];
+                for (int i = 0; i < 36; i++) A[i] = JtJ[i];
+                for (int i = 0; i < 6; i++) A[i * 6 + i] *= 1. + lambda;
+                svd_solve_d<6, 6>(A, JtErr, x, ws + lane, 64);
+                if (lane == 0) for (int i = 0; i < 6; i++) bcast[i] = prevParam[i] - x[i];
+            }
+            __syncthreads();
+            for (int i = 0; i < 6; i++) param[i] = bcast[i];
+            errNorm = sqrt(lm_eval(param, X3, img, mask, n, fx, fy, cx, cy, red, nullptr, nullptr));
             if (errNorm > prevErrNorm) {
                 if (++lambdaLg10 <= 16) continue;
             }
@@ -289,12 +461,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         if (done) break;
     }
-    if (lane == 0) {
+    if (tid == 0) {
         double Rf[9];
         rodrigues_vec2mat_d(param, Rf, nullptr);
         for (int i = 0; i < 3; i++) { out->rvec[i] = param[i]; out->tvec[i] = param[3 + i]; }
         for (int i = 0; i < 9; i++) out->R[i] = Rf[i];
-        out->n_inliers = max_good; out->ransac_iters = iters_done; out->best_iter = best_iter;
+        out->n_inliers = max_good; out->ransac_iters = st->iters_done; out->best_iter = st->best_iter;
         out->lm_iters = iters; out->ok = 1; out->n = n;
     }
 }
@@ -464,24 +636,59 @@ int stage_chain_relative(svo_ctx *ctx, const double *T, const int32_t *ok, int n
 }
 
 // ------------------------------------------------------------------------------------------
-// workspace layout inside ctx->pnp_ws: [PnpRecord x items][mask bytes x items*cap]
-static size_t ws_off_mask(int n_items) { return ((sizeof(PnpRecord) * (size_t)n_items) + 255) / 256 * 256; }
-static size_t ws_end(const svo_config &cfg, int n_items)
-{
-    return (ws_off_mask(n_items) + (size_t)n_items * cfg.max_keypoints + 255) / 256 * 256;
-}
+// workspace layout inside ctx->pnp_ws (n = max_batch items):
+//   [PnpRecord x n][mask bytes x n*cap][PnpState x n][PnpHyp x n*448][counts x n*448][subsets x n*2*448*5]
+static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+static size_t ws_off_mask(int n_items) { return al256(sizeof(PnpRecord) * (size_t)n_items); }
+static size_t ws_off_state(const svo_config &cfg, int n_items) { return al256(ws_off_mask(n_items) + (size_t)n_items * cfg.max_keypoints); }
+static size_t ws_off_hyp(const svo_config &cfg, int n_items) { return al256(ws_off_state(cfg, n_items) + sizeof(PnpState) * (size_t)n_items); }
+static size_t ws_off_counts(const svo_config &cfg, int n_items) { return al256(ws_off_hyp(cfg, n_items) + sizeof(PnpHyp) * (size_t)n_items * kPhaseHyps); }
+static size_t ws_off_subsets(const svo_config &cfg, int n_items) { return al256(ws_off_counts(cfg, n_items) + sizeof(int) * (size_t)n_items * kPhaseHyps); }
+static size_t ws_end(const svo_config &cfg, int n_items) { return al256(ws_off_subsets(cfg, n_items) + sizeof(int) * 2 * 5 * (size_t)n_items * kPhaseHyps); }
 
 // RANSAC inlier flags of batch item 0 (the online pair): max_keypoints bytes
 const uint8_t *pnp_inlier_mask(const svo_ctx *ctx) { return (const uint8_t *)ctx->pnp_ws + ws_off_mask(ctx->cfg.max_batch); }
 
 int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
 {
-    // called once per context at creation: the pose solver needs more dynamic LDS than the default limit
-    if (hipFuncSetAttribute((const void *)pnp_ransac_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    // called once per context at creation: the EPnP and refit kernels need more dynamic LDS than the default limit
+    if (hipFuncSetAttribute((const void *)pnp_hyp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPnpLdsBytes) != hipSuccess)
+        return SVO_ERR_HIP;
+    if (hipFuncSetAttribute((const void *)pnp_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kRefitLdsBytes) != hipSuccess)
         return SVO_ERR_HIP;
     *bytes = ws_end(cfg, n_items) + 256;
     return SVO_OK;
+}
+
+// The launch sequence of one solvePnPRansac for n_items items (see the kernel comments above).
+// max_pts bounds the points of any item (grid.z of the scoring kernel).
+static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pts, hipStream_t st)
+{
+    const svo_config &cfg = ctx->cfg;
+    char *ws = (char *)ctx->pnp_ws;
+    const int B = cfg.max_batch;
+    a.out = (PnpRecord *)ws;
+    a.state = (PnpState *)(ws + ws_off_state(cfg, B));
+    a.hyp = (PnpHyp *)(ws + ws_off_hyp(cfg, B));
+    a.counts = (int *)(ws + ws_off_counts(cfg, B));
+    a.subsets = (int *)(ws + ws_off_subsets(cfg, B));
+    hipLaunchKernelGGL(pnp_begin_kernel, dim3(n_items), dim3(64), 0, st, a);
+    const int niters = a.iterations > 1 ? a.iterations : 1;
+    const int zchunks = max_pts > 0 ? (max_pts + kScoreChunk - 1) / kScoreChunk : 1;
+    int phase = 0;
+    for (int base = 0; base < niters; phase++) {
+        const int cap = base == 0 ? kHypBlock : kPhaseHyps;
+        const int hyps = niters - base < cap ? niters - base : cap;
+        const int blocks = (hyps + kHypBlock - 1) / kHypBlock;
+        a.phase_base = base; a.phase_cap = cap; a.phase_index = phase;
+        hipLaunchKernelGGL(pnp_hyp_kernel, dim3(blocks + 1, n_items), dim3(64), kPnpLdsBytes, st, a);     // + the drawer
+        hipLaunchKernelGGL(pnp_score_kernel, dim3(blocks, n_items, zchunks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(pnp_select_kernel, dim3(n_items), dim3(64), 0, st, a);
+        base += cap;
+    }
+    hipLaunchKernelGGL(pnp_refit_kernel, dim3(n_items), dim3(kRefitThreads), kRefitLdsBytes, st, a);
 }
 
 void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const float2 *x1, const float2 *x2,
@@ -506,8 +713,7 @@ void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n
     a.iterations = ctx->cfg.iterations; a.reproj_err = ctx->cfg.reproj_err;
     a.confidence = (double)ctx->cfg.confidence;
     a.mask = (uint8_t *)ctx->pnp_ws + ws_off_mask(ctx->cfg.max_batch);
-    a.out = (PnpRecord *)ctx->pnp_ws;
-    hipLaunchKernelGGL(pnp_ransac_kernel, dim3(n_items), dim3(64), kPnpLdsBytes, st, a);
+    launch_pnp_pipeline(ctx, a, n_items, ctx->cfg.max_keypoints, st);
 }
 
 void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur, const int *ovf,
@@ -569,7 +775,6 @@ int stage_pnp_ransac(svo_ctx *ctx, const svo_pt3f *obj, const svo_pt2f *img, int
     a.fx = K[0]; a.fy = K[4]; a.cx = K[2]; a.cy = K[5];
     a.iterations = iterations; a.reproj_err = reproj_err; a.confidence = confidence;
     uint8_t *ws_mask = (uint8_t *)ctx->pnp_ws + ws_off_mask(ctx->cfg.max_batch);
-    a.out = (PnpRecord *)ctx->pnp_ws;
     if (mem == SVO_MEM_HOST) {
         if (n > 0) {
             SVO_HIP(hipMemcpyAsync(ctx->X3, obj, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
@@ -579,7 +784,7 @@ int stage_pnp_ransac(svo_ctx *ctx, const svo_pt3f *obj, const svo_pt2f *img, int
     } else {
         a.X3 = (const float *)obj; a.img = (const float2 *)img; a.mask = inlier_mask ? inlier_mask : ws_mask;
     }
-    hipLaunchKernelGGL(pnp_ransac_kernel, dim3(1), dim3(64), kPnpLdsBytes, ctx->stream, a);
+    launch_pnp_pipeline(ctx, a, 1, n, ctx->stream);
     SVO_HIP(hipGetLastError());
     PnpRecord *h = (PnpRecord *)((char *)ctx->h_pinned + 256);
     SVO_HIP(hipMemcpyAsync(h, ctx->pnp_ws, sizeof(PnpRecord), hipMemcpyDeviceToHost, ctx->stream));
