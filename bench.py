@@ -1,22 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- stereo pairs/s of the MI355X-native LK-mode hot path on BASELINE.json's config #2
+"""bench.py -- stereo pairs/s of the MI355X-native hot path on BASELINE.json's config #2
 ("KITTI-00 full seq, FAST+LK, 1xMI355X") using the synthetic KITTI-like sequence S0 (1241x376;
 there is no KITTI data offline).
 
-One "step" = one svo_track_batch call = B consecutive stereo pairs (B+1 frames resident in HBM
-before the timed region) through pyramid -> FAST -> 4-call circular LK -> compaction ->
-triangulation -> RANSAC-EPnP+LM -> gates -> pose chain.  Every consecutive frame pair of the
-reference is independent, so the full sequence is B-pair batches back to back.
+One "step" = one svo_track_batch call = B consecutive stereo pairs through pyramid -> FAST -> 4-call
+circular LK -> compaction -> triangulation -> RANSAC-EPnP + LM -> gates -> pose chain.  Every
+consecutive frame pair of the reference is independent, so a sequence is B-pair
+batches back to back; step k tracks chunk k of the rendered sequence (DISTINCT frames every step; at
+most --chunks chunks are rendered and cycled).
 
-N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); rank r tracks its own
-sequence (seed 100 + r), no data-path collective; rank 0 gathers the poses only (16 doubles per
-pair) once per step.  scaling = "weak".
+What the one JSON line holds (rank 0):
+  value            whole-job pairs/s with the frames RESIDENT IN HBM when the timed region starts (the
+                   task contract's definition of `value`)
+  m1               SURVEY.md 8(d) M1: the same steps with the frames in PAGE-LOCKED HOST memory, the
+                   host-to-device copies INSIDE the timed region (double-buffered on a copy stream),
+                   from the first svo_track_* call to the last record on the host       (N = 1 only)
+  online           config #2 "single-stream": svo_add_frame, one pair per call, host frames (N = 1 only)
+  roofline         lk_kernel: algorithmic HBM bytes per launch / launch time (HIP events on the launch
+                   stream) against the 8 TB/s roof, the PMC-measured HBM traffic, and the VALU issue
+                   roof the kernel actually sits under (measured instruction issue rates:
+                   profiles/r02_valu_roof.txt); the profile-derived fields are stamped with the hash
+                   of the kernel source they were measured on and nulled when it differs
+  cpu_baseline     the CPU oracle on this host: 1 thread and all usable cores, bounded samples
 
-Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the LK
-kernel (HIP-event timed on the launch stream, algorithmic bytes per SURVEY.md 8d) and
-`cpu_baseline` (the CPU oracle timed on this host on a bounded sample of the same frames).
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); no data-path collective.
+  --shard sequences  (default) rank r tracks its own sequence; poses only gathered to rank 0.  weak.
+  --shard pairs      ONE sequence cut into per-rank chunks of frame pairs (one-frame halo); relative
+                     motions gathered, prefix product on rank 0.
+  --config5          BASELINE config #5 as stated: the 8 KITTI sequence lengths (271..4661 frames) dealt
+                     to the ranks; every rank runs ceil((len-1)/B) steps per sequence (so --steps is
+                     ignored), per-rank busy time and the imbalance are reported.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,6 +47,7 @@ import __graft_entry__ as entry  # noqa: E402
 W, H, PITCH = 1241, 376, 1280
 LK_BYTES_PER_POINT_CALL = 4 * (24 * 24 + 22 * 22) + 17      # 4257 B
 HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8 TB/s spec
+N_SIMD, CLOCK_GHZ = 1024, 2.4                               # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md peak clock
 
 
 def parse():
@@ -39,22 +56,39 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="stereo pairs per step (per GPU)")
-    ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--chunks", type=int, default=4, help="distinct B-pair chunks of the sequence rendered (steps cycle through them)")
+    ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs of the 1-thread cpu_baseline sample (0 = skip cpu_baseline)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the m1 / online legs (value, roofline, cpu_baseline only)")
     ap.add_argument("--no-timing-marks", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the pose stage in stream order")
     ap.add_argument("--mode", choices=["lk", "orb"], default="lk",
                     help="lk = BASELINE config #2 (FAST+LK, the quoted metric); orb = config #3 (ORB extractor + "
                          "descriptor match path, the reference's shipped default track_mode)")
-    ap.add_argument("--shard", choices=["sequences", "pairs"], default="sequences",
-                    help="N > 1: one independent sequence per GPU (default, BASELINE config #5), or ONE sequence cut "
-                         "into contiguous chunks of frame pairs with a one-frame halo, relative motions gathered "
-                         "and chained on rank 0 (SURVEY.md 8e granularity 2)")
+    ap.add_argument("--shard", choices=["sequences", "pairs"], default="sequences")
+    ap.add_argument("--config5", action="store_true", help="KITTI 00-07 sequence lengths dealt to the ranks (see the docstring)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1: nccl (= RCCL, the real path) or gloo (rehearsal of the "
                          "multi-rank control flow with several ranks sharing one GPU: collectives on CPU copies)")
     ap.add_argument("--frames-cache", default="", help="torch file to load/save the rendered S0 frames "
                     "(keeps profiler traces free of the renderer's torch kernels)")
     return ap.parse_args()
+
+
+def kernel_source_hash():
+    """sha256 over the sources lk_kernel is built from: profile-derived numbers are only valid for them."""
+    h = hashlib.sha256()
+    for f in ("lk.hip", "svo_device.h", "svo_kernels.h"):
+        with open(os.path.join(entry.PKG_DIR, "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def usable_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 64))
 
 
 def main():
@@ -85,12 +119,21 @@ def main():
     mg = importlib.import_module(entry.PKG_NAME + ".multigpu")
 
     B = args.batch
-    F = B + 1
     dev = torch.device("cuda", local_rank)
-    # ---- synthetic S0 frames, resident in HBM before the timed region -----------------------
+    coll_dev = torch.device("cpu") if gloo else dev
     by_pairs = args.shard == "pairs"
+    # ---- how many steps this rank runs, and on which chunks --------------------------------------
+    steps = args.steps
+    my_seqs = None
+    if args.config5:
+        deal = mg.deal_sequences(mg.KITTI_LENGTHS, world)
+        my_seqs = deal[rank]
+        steps = mg.steps_for(mg.KITTI_LENGTHS, my_seqs, B)
+    NC = max(1, min(args.chunks, max(steps, 1)))
+    F = NC * B + 1
+    # ---- synthetic S0 frames: NC chunks of B pairs (+ the halo frame), resident in HBM ----------
     seed = mg.sequence_seed(0, 1) if by_pairs else mg.sequence_seed(rank, world)
-    first_frame = mg.shard_pairs(world * B + 1, world, rank)[0] if by_pairs else 0
+    first_frame = mg.shard_pairs(world * NC * B + 1, world, rank)[0] if by_pairs else 0
     seq = synth.StereoSequence(width=W, height=H, n_frames=first_frame + F, seed=seed, device=dev)
     cache = args.frames_cache if world == 1 else ""
     if cache and os.path.exists(cache):
@@ -106,7 +149,6 @@ def main():
             R[f, :, :W] = r
         if cache:
             torch.save({"L": L.cpu(), "R": R.cpu(), "seed": seed}, cache)
-    Lv, Rv = L[:, :, :W], R[:, :, :W]
     P1, P2 = seq.proj()
     mode_kw = {}
     if args.mode == "orb":       # config/default.yaml:75,87-93: ORB_stereof2f_pnp, minmove 0.05, maxmove 10
@@ -122,6 +164,10 @@ def main():
     trel_off, ok_off = pkg.STEP_DTYPE.fields["T_rel_inv"][1], pkg.STEP_DTYPE.fields["ok"][1]
     state = {"k": 0}
 
+    def chunk(k):
+        c = k % NC
+        return L[c * B:c * B + B + 1, :, :W], R[c * B:c * B + B + 1, :, :W]
+
     def collect(res):
         """The only inter-GPU traffic: per pair 16 doubles (poses) or 17 (relative motion + ok) to rank 0."""
         host = (lambda t: t.cpu()) if gloo else (lambda t: t)
@@ -129,12 +175,13 @@ def main():
             g = mg.gather_relative(host(mg.field_view(res, trel_off, B, 16)), host(mg.int_field(res, ok_off, B)), rank, world, dst=0)
             if rank == 0:
                 ctx.chain_relative(g[0].to(dev), g[1].to(dev))
-        elif world > 1:
+        elif world > 1 and not args.config5:
             mg.gather_poses(host(mg.poses_view(res, pose_off, B)), rank, world, dst=0)
 
     def step():
         k = state["k"]
-        ctx.track_batch(Lv, Rv, results=res_buf[k & 1])
+        Lk, Rk = chunk(k)
+        ctx.track_batch(Lk, Rk, results=res_buf[k & 1])
         # svo_track_batch(k) has already ordered the context's stream after the pose stage of batch
         # k-1 (it reuses that stage's buffers), so batch k-1's records are complete here
         if k > 0 and (world > 1 or by_pairs):
@@ -159,57 +206,99 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     drain()                                       # every step's records are collected inside the timed region
     torch.cuda.synchronize()
+    busy = time.perf_counter() - t0               # this rank's own busy time (config #5: ranks differ)
     if world > 1:
         dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    elapsed = mg.max_over_ranks(elapsed, torch.device("cpu") if gloo else dev, world)
+    elapsed = time.perf_counter() - t0
+    elapsed = mg.max_over_ranks(elapsed, coll_dev, world)
 
     ctx.sync()
     stage_ms = dict(ctx.get_timing()) if not args.no_timing_marks else {}
     ctx.enable_timing(False)
-    results = res_buf[(args.steps - 1) & 1]
-    res = np.frombuffer(results.cpu().numpy().tobytes(), dtype=pkg.STEP_DTYPE)
+    last = res_buf[(steps - 1) & 1] if steps > 0 else res_buf[0]
+    res = np.frombuffer(last.cpu().numpy().tobytes(), dtype=pkg.STEP_DTYPE)
     n_ok = int(res["ok"].sum())
     pts_total = int(res["n_prev_kps"].sum())
 
+    # ---- config #5: per-rank busy time and the ragged pose gather --------------------------------
+    per_rank = None
+    if args.config5:
+        mine = torch.tensor([[float(rank), float(steps), busy, float(sum(mg.KITTI_LENGTHS[s] for s in my_seqs))]],
+                            dtype=torch.float64, device=coll_dev)
+        rows = mg.gather_ragged(mine, rank, world, dst=0)
+        # the poses of a rank's LAST step stand in for its sequences' pose files: ragged lengths
+        n_keep = min(B, max(1, (mg.KITTI_LENGTHS[my_seqs[-1]] - 1) % B or B)) if my_seqs else 0
+        poses = mg.poses_view(last, pose_off, B)[:n_keep]
+        got = mg.gather_ragged(poses.cpu() if gloo else poses, rank, world, dst=0)
+        if rank == 0:
+            tab = torch.cat(rows, 0).cpu().numpy()
+            per_rank = [{"rank": int(r[0]), "sequences": mg.deal_sequences(mg.KITTI_LENGTHS, world)[int(r[0])],
+                         "frames": int(r[3]), "steps": int(r[1]), "busy_s": round(float(r[2]), 4)} for r in tab]
+            assert [g.shape[0] for g in got] == [min(B, max(1, (mg.KITTI_LENGTHS[d[-1]] - 1) % B or B)) if d else 0
+                                                 for d in mg.deal_sequences(mg.KITTI_LENGTHS, world)]
+
+    out = None
     if rank == 0:
-        pairs = world * B * args.steps
+        if args.config5:
+            all_steps = sum(mg.steps_for(mg.KITTI_LENGTHS, d, B) for d in mg.deal_sequences(mg.KITTI_LENGTHS, world))
+            pairs = all_steps * B
+        else:
+            pairs = world * B * steps
         value = pairs / elapsed
+        wl = ("S0 synthetic KITTI-like stereo sequence 1241x376 (config #2 stand-in), FAST+LK track_mode LK_stereof2f_pnp"
+              if args.mode == "lk" else
+              "S0 synthetic KITTI-like stereo sequence 1241x376 (config #3 stand-in), ORB extractor + descriptor match path "
+              "track_mode ORB_stereof2f_pnp")
         out = {
             "metric": "stereo frames/sec on KITTI-00 1241x376; LK-kernel achieved HBM GB/s vs peak",
-            "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(steps, 1), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": ("S0 synthetic KITTI-like stereo sequence 1241x376 (config #2 stand-in), "
-                                    "FAST+LK track_mode LK_stereof2f_pnp, batched frame pairs, frames resident in HBM")
-                       if args.mode == "lk" else
-                       ("S0 synthetic KITTI-like stereo sequence 1241x376 (config #3 stand-in), ORB extractor + "
-                        "descriptor match path track_mode ORB_stereof2f_pnp, batched frame pairs, frames resident in HBM"),
+            "config": {"workload": wl + f", batched frame pairs ({B} per step, {NC} distinct chunks cycled), frames resident in HBM "
+                                      "for `value`; `m1` = host-resident frames, H2D included",
                        "pairs_per_step_per_gpu": B, "mean_keypoints_per_pair": round(pts_total / B, 1),
                        "pairs_ok_last_step": n_ok, "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
                        "parallelism": ((f"one sequence in {world} chunks of frame pairs (1-frame halo), RCCL gather of "
                                         f"relative motions, prefix product on rank 0") if by_pairs else
                                        (f"sequence-per-GPU x{world}, RCCL gather of poses only" if world > 1 else "1 GPU"))},
         }
+        if args.config5:
+            busys = [p["busy_s"] for p in per_rank]
+            out["config"]["config5"] = {"kitti_lengths": list(mg.KITTI_LENGTHS), "per_rank": per_rank,
+                                        "imbalance_max_over_mean": round(max(busys) / (sum(busys) / len(busys)), 3),
+                                        "note": "--steps ignored: every rank runs ceil((len-1)/B) steps per sequence; frames are the "
+                                                "rank's rendered chunks cycled (sequence LENGTHS are modelled, not their content)"}
+        src_hash = kernel_source_hash()
         lk_ms = stage_ms.get("lk")
         if lk_ms:
             alg_bytes = pts_total * 4 * LK_BYTES_PER_POINT_CALL       # 4 fused calls per launch
             achieved = alg_bytes / (lk_ms * 1e-3) / 1e9
-            # HBM bytes per launch from the rocprofv3 PMC passes of this command (profiles/), if present
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_lk_traffic.json")
+            # HBM bytes and VALU instructions per launch from the rocprofv3 PMC passes of this command
+            # (profiles/), valid only for the kernel source they were measured on
+            traffic, valu = None, None
+            tpath = os.path.join(ROOT, "profiles", "r02_lk_pmc.json")
             if os.path.exists(tpath) and B == 256:
-                traffic = json.load(open(tpath)).get("traffic_bytes")
+                prof = json.load(open(tpath))
+                if prof.get("source_sha256_16") == src_hash:
+                    traffic = prof.get("traffic_bytes")
+                    n_valu = prof.get("valu_wave_instructions")
+                    peak = prof.get("valu_peak_wave_instr_per_cycle_per_simd")
+                    if n_valu and peak:
+                        rate = n_valu / (lk_ms * 1e-3 * N_SIMD * CLOCK_GHZ * 1e9)
+                        valu = {"achieved": round(rate, 4), "peak": peak, "unit": "wave-instructions/cycle/SIMD",
+                                "frac": round(rate / peak, 4), "clock_ghz_assumed": CLOCK_GHZ,
+                                "note": "peak = measured issue rate of v_dot2 / v_perm / v_pk_* / DPP / v_cndmask (4 cycles per "
+                                        "wave-instruction); profiles/r02_valu_roof.txt"}
             out["roofline"] = {"bound": "hbm", "kernel": "lk_kernel (4-call circular chain, one launch per step)",
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                               "launch_ms": round(lk_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
+                               "launch_ms": round(lk_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                               "limiting_resource": "valu-issue", "valu": valu, "kernel_source_sha256_16": src_hash}
         elif stage_ms.get("orb_cellfast"):
             # ORB mode: the largest kernel group is the per-cell FAST over the 8-level pyramid
             # (3.09 W H bytes read per image; the candidate records are negligible)
@@ -222,24 +311,85 @@ def main():
                                "launch_ms": round(cf_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
         else:
             out["roofline"] = None
-        # ---- cpu_baseline: the oracle (CPU restatement of the reference path) on a bounded sample
+
+    # ---- secondary legs (N = 1): M1 with H2D inside the timed region, and the online path ---------
+    if world == 1 and not args.no_secondary and not args.config5:
+        ctx.set_overlap(False)
+        hostL = [ctx.host_frames(B + 1, PITCH) for _ in range(NC)]
+        hostR = [ctx.host_frames(B + 1, PITCH) for _ in range(NC)]
+        for c in range(NC):
+            hostL[c][:] = L[c * B:c * B + B + 1].cpu().numpy()
+            hostR[c][:] = R[c * B:c * B + B + 1].cpu().numpy()
+
+        def m1_run(n_steps):
+            ctx.upload_frames(0, hostL[0], hostR[0])
+            recs = None
+            for k in range(n_steps):
+                ctx.track_uploaded_async(k & 1, B + 1)              # returns at once
+                if k + 1 < n_steps:                                 # next chunk crosses PCIe beside this batch's kernels
+                    c = (k + 1) % NC
+                    ctx.upload_frames((k + 1) & 1, hostL[c], hostR[c])
+                recs = ctx.collect_results(B)                       # records of step k on the host
+            return recs
+
+        m1_run(min(2, args.warmup + 1))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        recs = m1_run(steps)
+        m1_el = time.perf_counter() - t0
+        out["m1"] = {"value": round(B * steps / m1_el, 2), "unit": "stereo pairs/s", "ms_per_step": round(1e3 * m1_el / steps, 4),
+                     "definition": "SURVEY.md 8(d) M1: page-locked host frames, H2D inside the timed region (double-buffered "
+                                   "svo_upload_frames beside the previous batch's kernels), first svo_track_* call to last record on the host",
+                     "h2d_bytes_per_step": int(2 * (B + 1) * H * PITCH), "pairs_ok_last_step": int(recs["ok"].sum())}
+        for c in range(NC):
+            ctx.host_free(hostL[c])
+            ctx.host_free(hostR[c])
+        # online: one pair per svo_add_frame call, frames in (pageable) host memory
+        n_on = min(64, F)
+        octx = pkg.Context(W, H, device=local_rank, max_batch=1, P1=P1, P2=P2, **mode_kw)
+        fl = [L[f, :, :W].cpu().numpy().copy() for f in range(n_on)]
+        fr = [R[f, :, :W].cpu().numpy().copy() for f in range(n_on)]
+        lat, ok_on = [], 0
+        for f in range(n_on):
+            t0 = time.perf_counter()
+            rc, _ = octx.add_frame(fl[f], fr[f])
+            lat.append(time.perf_counter() - t0)
+            ok_on += int(rc == 0)
+        octx.close()
+        lat = np.array(lat[8:]) * 1e3
+        out["online"] = {"ms_per_pair_median": round(float(np.median(lat)), 3), "ms_per_pair_p90": round(float(np.percentile(lat, 90)), 3),
+                         "pairs_per_s": round(1e3 / float(np.mean(lat)), 1), "pairs": len(lat), "pairs_ok": ok_on - 8,
+                         "definition": "config #2 single-stream: svo_add_frame per stereo pair, frames in host memory, result on the host"}
+
+    if rank == 0:
+        # ---- cpu_baseline: the oracle (CPU restatement of the reference path) on bounded samples
         if args.cpu_pairs > 0 and world == 1 and args.mode == "lk":
             O = entry.load_oracle()
             O.build()
-            n = min(args.cpu_pairs, B)
-            fl = Lv[:n + 1].cpu().numpy()
-            fr = Rv[:n + 1].cpu().numpy()
             prm = O.make_params(P1, P2)
-            kps = O.fast(fl[0])
-            pose = np.eye(4)
-            c0 = time.perf_counter()
-            for t in range(1, n + 1):
-                _, kps, pose = O.lk_track_step(prm, fl[t - 1], fr[t - 1], fl[t], fr[t], kps, pose, threads=1)
-            c1 = time.perf_counter()
-            out["cpu_baseline"] = {"value": round(n / (c1 - c0), 3), "unit": "stereo pairs/s", "cores": 1,
-                                   "kind": "port",
-                                   "sample": f"first {n} pairs of the same S0 frames, oracle/ (CPU restatement of the "
-                                             f"reference OpenCV path), 1 thread, {os.cpu_count()} host cpus visible"}
+            cores = usable_cores()
+
+            def cpu_run(n, threads):
+                fl = L[:n + 1, :, :W].cpu().numpy()
+                fr = R[:n + 1, :, :W].cpu().numpy()
+                kps = O.fast(fl[0])
+                pose = np.eye(4)
+                c0 = time.perf_counter()
+                for t in range(1, n + 1):
+                    _, kps, pose = O.lk_track_step(prm, fl[t - 1], fr[t - 1], fl[t], fr[t], kps, pose, threads=threads)
+                return n / (time.perf_counter() - c0)
+
+            n1 = min(args.cpu_pairs, B)
+            v1 = cpu_run(n1, 1)
+            nn = min(4 * args.cpu_pairs, B)
+            vn = cpu_run(nn, cores)
+            out["cpu_baseline"] = {"value": round(v1, 3), "unit": "stereo pairs/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {n1} pairs of the same S0 frames, oracle/ (CPU restatement of the "
+                                             f"reference OpenCV path, not the reference binary), 1 thread",
+                                   "all_cores": {"value": round(vn, 3), "cores": cores,
+                                                 "sample": f"first {nn} pairs, OpenMP over the LK points, {cores} threads "
+                                                           f"({os.cpu_count()} host cpus visible)"}}
+            out["vs_cpu_baseline_1_thread"] = round(out["value"] / v1, 1)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -95,6 +95,9 @@ def load_library():
     lib.svo_upload_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]
     lib.svo_wait_upload.argtypes = [C.c_void_p, C.c_int]
     lib.svo_track_uploaded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    lib.svo_track_uploaded_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.svo_collect_results.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.svo_set_pose.argtypes = [C.c_void_p, C.c_void_p]
     _LIB = lib
     return lib
 
@@ -407,6 +410,23 @@ class Context:
         out = np.zeros(int(n_frames) - 1, dtype=STEP_DTYPE)
         self._check(self.lib.svo_track_uploaded(self.h, int(buf), int(n_frames), p0, C.c_void_p(out.ctypes.data), MEM_HOST))
         return out
+
+    def track_uploaded_async(self, buf, n_frames, pose0=None):
+        """svo_track_uploaded without waiting for the GPU; the records are fetched by collect_results()."""
+        p0 = None
+        if pose0 is not None:
+            pose0 = np.ascontiguousarray(pose0, np.float64).reshape(16)
+            p0 = C.c_void_p(pose0.ctypes.data)
+        self._check(self.lib.svo_track_uploaded_async(self.h, int(buf), int(n_frames), p0))
+
+    def collect_results(self, n_pairs):
+        out = np.zeros(int(n_pairs), dtype=STEP_DTYPE)
+        self._check(self.lib.svo_collect_results(self.h, C.c_void_p(out.ctypes.data), int(n_pairs)))
+        return out
+
+    def set_pose(self, pose):
+        pose = np.ascontiguousarray(pose, np.float64).reshape(16)
+        self._check(self.lib.svo_set_pose(self.h, C.c_void_p(pose.ctypes.data)))
 
     def chain_relative(self, T_rel_inv, ok, pose0=None):
         """poses[p] = pose0 * prod_{q<=p, ok[q]} T[q] (svo_chain_relative).  numpy arrays or torch cuda

@@ -28,29 +28,31 @@ struct TriArgs {
     const int *n_pts; int n_fixed;
 };
 
+// grid.x workgroups per item walk its points in strides (the launch is sized from the batch, not
+// from the keypoint capacity: most items hold far fewer points than max_keypoints)
 __global__ __launch_bounds__(64) void triangulate_kernel(TriArgs a)
 {
     const int b = blockIdx.y;
     const int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    const int64_t o = (int64_t)b * a.stride + i;
-    const float2 p1 = a.x1[o], p2 = a.x2[o];
-    const double xs[2] = {(double)p1.x, (double)p2.x}, ys[2] = {(double)p1.y, (double)p2.y};
-    double A[16], At[16], W[4], Vt[16];
-    for (int j = 0; j < 2; j++) {
-        const double *P = j == 0 ? a.P1 : a.P2;
-        for (int k = 0; k < 4; k++) {
-            A[(j * 2 + 0) * 4 + k] = xs[j] * P[8 + k] - P[k];
-            A[(j * 2 + 1) * 4 + k] = ys[j] * P[8 + k] - P[4 + k];
+    for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) {
+        const int64_t o = (int64_t)b * a.stride + i;
+        const float2 p1 = a.x1[o], p2 = a.x2[o];
+        const double xs[2] = {(double)p1.x, (double)p2.x}, ys[2] = {(double)p1.y, (double)p2.y};
+        double A[16], At[16], W[4], Vt[16];
+        for (int j = 0; j < 2; j++) {
+            const double *P = j == 0 ? a.P1 : a.P2;
+            for (int k = 0; k < 4; k++) {
+                A[(j * 2 + 0) * 4 + k] = xs[j] * P[8 + k] - P[k];
+                A[(j * 2 + 1) * 4 + k] = ys[j] * P[8 + k] - P[4 + k];
+            }
         }
+        for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) At[k * 4 + j] = A[j * 4 + k];
+        jacobi_svd_d<4, 4>(At, 1, W, Vt, 1, false);
+        // 4 x N CV_32F homogeneous result, then convertPointsFromHomogeneous in float
+        const float X = (float)Vt[12], Y = (float)Vt[13], Z = (float)Vt[14], Wh = (float)Vt[15];
+        const float scale = Wh != 0.f ? 1.f / Wh : 1.f;
+        a.out3[o * 3 + 0] = X * scale; a.out3[o * 3 + 1] = Y * scale; a.out3[o * 3 + 2] = Z * scale;
     }
-    for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) At[k * 4 + j] = A[j * 4 + k];
-    jacobi_svd_d<4, 4>(At, 1, W, Vt, 1, false);
-    // 4 x N CV_32F homogeneous result, then convertPointsFromHomogeneous in float
-    const float X = (float)Vt[12], Y = (float)Vt[13], Z = (float)Vt[14], Wh = (float)Vt[15];
-    const float scale = Wh != 0.f ? 1.f / Wh : 1.f;
-    a.out3[o * 3 + 0] = X * scale; a.out3[o * 3 + 1] = Y * scale; a.out3[o * 3 + 2] = Z * scale;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -544,32 +546,10 @@ __global__ void finalize_kernel(FinalizeArgs a)
 // frame_pose_ = frame_pose_ * T^-1 over consecutive pairs; failed steps are skipped (:59-68).
 // The seed pose travels BY VALUE in the kernel argument block: a launch queued behind many others
 // (callers of svo_track_batch with device results never synchronise) keeps the seed it was given.
+// One wave: lanes (i, j) hold P[i][j], row elements travel by quad DPP broadcast (see
+// chain_relative_kernel below: same association order -- k ascending, separate multiply and add --
+// as a plain triple loop, so chunked and whole-sequence chaining agree bit for bit).
 struct Pose16 { double m[16]; };
-__global__ void chain_kernel(svo_step_result *res, int n_pairs, Pose16 pose0)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double P[16];
-    for (int i = 0; i < 16; i++) P[i] = pose0.m[i];
-    for (int p = 0; p < n_pairs; p++) {
-        if (res[p].ok) {
-            double Q[16];
-            const double *T = res[p].T_rel_inv;
-            for (int i = 0; i < 4; i++)
-                for (int j = 0; j < 4; j++) {
-                    double s = 0;
-                    for (int k = 0; k < 4; k++) s += P[i * 4 + k] * T[k * 4 + j];
-                    Q[i * 4 + j] = s;
-                }
-            for (int i = 0; i < 16; i++) P[i] = Q[i];
-        }
-        for (int i = 0; i < 16; i++) res[p].pose[i] = P[i];
-    }
-}
-
-// The same product for relative motions gathered from independently tracked chunks (other
-// launches, contexts or GPUs): lanes (i, j) of one wave hold P[i][j]; row elements travel by quad
-// broadcast, the T matrices are staged through LDS 64 pairs at a time.  Same association order
-// as chain_kernel (k ascending, separate multiply and add).
 template <int K>
 __device__ __forceinline__ double quad_bcast_f64(double v)
 {
@@ -577,6 +557,26 @@ __device__ __forceinline__ double quad_bcast_f64(double v)
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), K * 0x55, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+__global__ __launch_bounds__(64) void chain_kernel(svo_step_result *res, int n_pairs, Pose16 pose0)
+{
+    const int lane = threadIdx.x, i = (lane >> 2) & 3, j = lane & 3;
+    double P = pose0.m[i * 4 + j];
+    for (int p = 0; p < n_pairs; p++) {
+        const double p0 = quad_bcast_f64<0>(P), p1 = quad_bcast_f64<1>(P), p2 = quad_bcast_f64<2>(P), p3 = quad_bcast_f64<3>(P);
+        if (res[p].ok) {
+            const double *t = res[p].T_rel_inv + j;
+            double s = 0;
+            s += p0 * t[0]; s += p1 * t[4]; s += p2 * t[8]; s += p3 * t[12];
+            P = s;
+        }
+        if (lane < 16) res[p].pose[lane] = P;
+    }
+}
+
+// The same product for relative motions gathered from independently tracked chunks (other
+// launches, contexts or GPUs): lanes (i, j) of one wave hold P[i][j]; row elements travel by quad
+// broadcast, the T matrices are staged through LDS 64 pairs at a time.  Same association order
+// as chain_kernel (k ascending, separate multiply and add).
 
 __global__ __launch_bounds__(64) void chain_relative_kernel(const double *T, const int *ok, int n, Pose16 pose0,
                                                             double *out)
@@ -700,7 +700,10 @@ void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const floa
     a.x1 = x1; a.x2 = x2; a.out3 = ctx->X3; a.stride = ctx->cfg.max_keypoints;
     a.n_pts = n_pts; a.n_fixed = n_fixed;
     if (max_pts <= 0) return;
-    hipLaunchKernelGGL(triangulate_kernel, dim3((max_pts + 63) / 64, n_items), dim3(64), 0, ctx->stream, a);
+    int gx = (8192 + n_items - 1) / n_items;                 // ~8 k workgroups per launch
+    gx = gx < 2 ? 2 : gx;
+    gx = gx > (max_pts + 63) / 64 ? (max_pts + 63) / 64 : gx;
+    hipLaunchKernelGGL(triangulate_kernel, dim3(gx, n_items), dim3(64), 0, ctx->stream, a);
 }
 
 void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n_pts, int n_fixed, hipStream_t st)

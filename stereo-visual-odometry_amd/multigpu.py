@@ -20,6 +20,45 @@ def shard_sequences(n_sequences, world, rank):
     return [s for s in range(n_sequences) if s % world == rank]
 
 
+def deal_sequences(lengths, world):
+    """Longest-processing-time-first deal of sequences to ranks (BASELINE config #5: 8 KITTI sequences of
+    271..4661 frames on 8 GPUs are imbalanced by construction; with fewer ranks the greedy deal
+    evens the load out).  Returns a list of `world` lists of sequence indices; deterministic (ties:
+    lower sequence index first, lower rank first)."""
+    order = sorted(range(len(lengths)), key=lambda s: (-lengths[s], s))
+    load = [0] * world
+    mine = [[] for _ in range(world)]
+    for s in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        mine[r].append(s)
+        load[r] += max(lengths[s] - 1, 0)
+    return mine
+
+
+def steps_for(lengths, seqs, batch):
+    """Batched steps a rank needs for its sequences: ceil((len - 1) / batch) launches per sequence."""
+    return sum((max(lengths[s] - 1, 0) + batch - 1) // batch for s in seqs)
+
+
+def gather_ragged(x, rank, world, dst=0):
+    """Gathers per-rank tensors of DIFFERENT leading length (n_r, k) to dst: lengths are exchanged
+    first, messages are padded to the longest, the padding is cut off again on dst.  Returns the
+    list of world tensors on dst, None elsewhere."""
+    if world == 1:
+        return [x]
+    n = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
+    lens = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(lens, n)
+    nmax = max(int(v.item()) for v in lens)
+    msg = torch.zeros((nmax,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    msg[:x.shape[0]] = x
+    buf = [torch.empty_like(msg) for _ in range(world)] if rank == dst else None
+    dist.gather(msg, buf, dst=dst)
+    if rank != dst:
+        return None
+    return [buf[r][:int(lens[r].item())] for r in range(world)]
+
+
 def shard_pairs(n_frames, world, rank):
     """Frame-pair-granular sharding of ONE sequence (SURVEY.md 8e granularity 2 / 8f rank 1): the
     n_frames - 1 consecutive pairs are cut into `world` contiguous chunks, chunk c -> rank c, with

@@ -73,6 +73,16 @@ def _worker(rank, world, port, out_dir):
         ok = ok and np.array_equal(g[1].numpy(), okall)
     else:
         ok = ok and g is None
+    # BASELINE config #5: unequal sequence lengths dealt to the ranks, ragged result gather
+    deal = mg.deal_sequences(mg.KITTI_LENGTHS, world)
+    n_mine = mg.steps_for(mg.KITTI_LENGTHS, deal[rank], 256)
+    ragged = torch.arange(n_mine * 16, dtype=torch.float64).view(n_mine, 16) + 1e6 * rank
+    gr = mg.gather_ragged(ragged, rank, world, dst=0)
+    if rank == 0:
+        ok = ok and [g.shape[0] for g in gr] == [mg.steps_for(mg.KITTI_LENGTHS, d, 256) for d in deal]
+        ok = ok and all(float(gr[r][0, 0]) == 1e6 * r and float(gr[r][-1, -1]) == gr[r].shape[0] * 16 - 1 + 1e6 * r for r in range(world))
+    else:
+        ok = ok and gr is None
     ok = ok and mg.shard_pairs(10, 3, 0) == (0, 4) and mg.shard_pairs(10, 3, 1) == (3, 4) and mg.shard_pairs(10, 3, 2) == (6, 4)
     ok = ok and mg.shard_pairs(3, 4, 3) == (2, 0)
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
@@ -91,6 +101,27 @@ def test_pose_gather_and_sharding_world2(tmp_path):
     assert r0[2] == "0,2,4,6" and r1[2] == "1,3,5,7"             # KITTI 00-07 dealt round-robin
 
 
+def test_deal_sequences_balances_kitti_lengths(pkg):
+    """Longest-first greedy deal of the KITTI 00-07 lengths: every sequence exactly once; with 8 ranks it
+    is one sequence per rank (the imbalance BASELINE config #5 has by construction: the wall time is
+    sequence 02's), with fewer ranks the loads even out."""
+    import importlib
+    mg = importlib.import_module(conftest.entry.PKG_NAME + ".multigpu")
+    Ls = mg.KITTI_LENGTHS
+    for world in (1, 2, 3, 4, 8, 12):
+        deal = mg.deal_sequences(Ls, world)
+        assert len(deal) == world and sorted(s for d in deal for s in d) == list(range(8))
+        loads = [sum(Ls[s] - 1 for s in d) for d in deal]
+        if world == 8:
+            assert all(len(d) == 1 for d in deal) and max(loads) == 4660
+        if world <= 4:
+            assert max(loads) <= 1.25 * (sum(loads) / world)         # LPT: within 25 % of perfect balance here
+    assert mg.deal_sequences(Ls, 2) == [[2, 1, 6, 7, 4], [0, 5, 3]]
+    assert mg.steps_for(Ls, [0], 256) == 18 and mg.steps_for(Ls, [4], 256) == 2 and mg.steps_for(Ls, [], 256) == 0
+    x = torch.arange(6.0).view(3, 2)
+    assert mg.gather_ragged(x, 0, 1)[0] is x
+
+
 def test_single_rank_is_identity(pkg):
     import importlib
     mg = importlib.import_module(conftest.entry.PKG_NAME + ".multigpu")
@@ -106,6 +137,26 @@ import subprocess
 import sys
 
 import pytest
+
+
+@pytest.mark.gpu
+def test_bench_config5_two_ranks_rehearsal_on_one_gpu():
+    """bench.py --config5 (the KITTI 00-07 lengths dealt to the ranks, unequal step counts, per-rank busy
+    time, ragged gather) with two ranks sharing the test box's GPU over gloo; a large batch keeps it short."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(conftest.ROOT, "bench.py"), "--gpus", "2", "--warmup", "1",
+           "--batch", "24", "--chunks", "1", "--cpu-pairs", "0", "--dist-backend", "gloo", "--config5", "--no-timing-marks"]
+    r = subprocess.run(cmd, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    c5 = out["config"]["config5"]
+    assert [p["sequences"] for p in c5["per_rank"]] == [[2, 1, 6, 7, 4], [0, 5, 3]]
+    assert [p["steps"] for p in c5["per_rank"]] == [(4660 + 23) // 24 + 3 * ((1100 + 23) // 24) + (270 + 23) // 24,
+                                                     (4540 + 23) // 24 + (2760 + 23) // 24 + (800 + 23) // 24]
+    assert out["value"] > 0 and c5["imbalance_max_over_mean"] >= 1.0 and all(p["busy_s"] > 0 for p in c5["per_rank"])
 
 
 @pytest.mark.gpu
