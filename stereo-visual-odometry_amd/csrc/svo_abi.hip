@@ -113,6 +113,14 @@ extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
     if (cfg->width < 32 || cfg->height < 32 || cfg->max_keypoints < 64 || cfg->max_batch < 1 ||
         cfg->num_slots < 4 || cfg->width > 16384 || cfg->height > 16384)
         return SVO_ERR_ARG;
+    if (cfg->num_features_tracking < 5) {
+        // with fewer than 5 tracks required, a pair with exactly 4 would reach cv::solvePnPRansac's
+        // npoints == 4 branch (P3P kernel), which this library does not implement: refuse the
+        // configuration instead of answering "no solution" where the reference would solve
+        fprintf(stderr, "svo_create: num_features_tracking = %d < 5 is not supported (the 4-point P3P branch of "
+                        "cv::solvePnPRansac is out of scope)\n", cfg->num_features_tracking);
+        return SVO_ERR_ARG;
+    }
     svo_ctx *ctx = new (std::nothrow) svo_ctx();
     if (!ctx) return SVO_ERR_NOMEM;
     ctx->cfg = *cfg;
