@@ -437,20 +437,26 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
     outPt = make_float2(nx, ny);
 }
 
-// Grid: blockIdx.y = batch item; the gridDim.x workgroups of an item walk its points in strides of
-// gridDim.x * 16 (four waves x four slots), so the launch is sized from the batch, not from the
-// keypoint CAPACITY: cv::FAST is uncapped and the capacity is generous, a grid of capacity / 16
-// workgroups per item was mostly empty waves.  No workgroup barrier anywhere: each wave loops on its own.
+// Grid: ONE dimension, a.gx workgroups per batch item; the workgroups of an item walk its points in
+// strides of a.gx * 16 (four waves x four slots), so the launch is sized from the batch, not from
+// the keypoint CAPACITY (cv::FAST is uncapped and the capacity is generous: a grid of capacity / 16
+// workgroups per item was mostly empty waves).  XCD-aware mapping: consecutive workgroup ids go
+// round-robin to the 8 XCDs, each with its own 4 MB L2, so item = (id / 8 / gx) * 8 + id % 8 keeps
+// every XCD on its own items -- an XCD then has about one item's four pyramids (3.3 MB) in flight
+// instead of slices of all items that are in flight anywhere on the chip (L2 hit rate 63 % -> see
+// DESIGN.md).  No workgroup barrier anywhere: each wave loops on its own.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void lk_kernel(LkArgs a)
 {
     __shared__ uint32_t lds[4 * kLdsDwPerWave];
-    const int b = blockIdx.y;
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+    const int b = (slot_id / a.gx) * 8 + xcd, bx = slot_id % a.gx;
+    if (b >= a.batch) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slot = (lane >> 2) & 3;
     int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
     n = min(n, a.cap);
     uint32_t *my = lds + wave * kLdsDwPerWave;
-    for (int first = (blockIdx.x * 4 + wave) * kSlots; first < n; first += gridDim.x * 4 * kSlots) {
+    for (int first = (bx * 4 + wave) * kSlots; first < n; first += a.gx * 4 * kSlots) {
         const int idx = first + slot;
         const bool valid = idx < n;
         const bool writer = valid && lane == 4 * slot;         // one lane per slot stores results
@@ -523,17 +529,17 @@ __global__ __launch_bounds__(1024) void compact_kernel(CompactArgs a)
     if (threadIdx.x == 0) a.m_out[b] = base_s;
 }
 
-void launch_lk(const LkArgs &a, int batch, int max_pts, hipStream_t st)
+void launch_lk(const LkArgs &a0, int batch, int max_pts, hipStream_t st)
 {
     if (max_pts <= 0 || batch <= 0) return;
-    // about 8 k workgroups per launch (8 per CU-slot of the 256 CUs x 4), at least 4 and at most
-    // capacity / 16 per item: a single pair (online) still spreads over the whole chip, a 256-pair
-    // batch launches 32 workgroups per pair that each walk ~5 chunks of 16 points
+    // up to 192 workgroups per item (3072 points per pass: a KITTI frame's ~2.5 k corners in one pass,
+    // a few workgroups leave at once; denser frames loop), never more than capacity / 16
     const int chunks = (max_pts + 4 * kSlots - 1) / (4 * kSlots);
-    int gx = (8192 + batch - 1) / batch;
-    gx = gx < 4 ? 4 : gx;
-    gx = gx > chunks ? chunks : gx;
-    dim3 grid(gx, batch, 1), blk(256, 1, 1);
+    LkArgs a = a0;
+    a.gx = chunks < 192 ? chunks : 192;
+    a.batch = batch;
+    const int groups = (batch + 7) / 8;                     // items are dealt to the 8 XCDs in groups of 8
+    dim3 grid(groups * 8 * a.gx, 1, 1), blk(256, 1, 1);
     hipLaunchKernelGGL(lk_kernel, grid, blk, 0, st, a);
 }
 
