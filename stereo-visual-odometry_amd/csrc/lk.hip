@@ -376,7 +376,7 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
             int cx = inx - tx0, cy = iny - ty0;
             const bool restage = it_on && ((unsigned)cx > 17u || (unsigned)cy > 10u);
             if (restage) { tx0 = (inx - 8) & ~3; ty0 = iny - 5; cx = inx - tx0; cy = iny - ty0; }
-            const int joff = cy * (kTileJDw * 4) + cx;          // slot part of the J sample offset (bytes)
+            const int joff = (int)__umul24((unsigned)cy, kTileJDw * 4) + cx;   // slot part of the J sample offset (bytes); 0 <= cy <= 10
             const unsigned long long m_it = __ballot(it_on), m_rs = __ballot(restage);
             int pb[kSlots][2];
 #pragma unroll
