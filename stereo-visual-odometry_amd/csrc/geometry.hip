@@ -559,17 +559,28 @@ __device__ __forceinline__ double quad_bcast_f64(double v)
 }
 __global__ __launch_bounds__(64) void chain_kernel(svo_step_result *res, int n_pairs, Pose16 pose0)
 {
+    __shared__ double sT[64 * 16];
+    __shared__ int sOk[64];
     const int lane = threadIdx.x, i = (lane >> 2) & 3, j = lane & 3;
     double P = pose0.m[i * 4 + j];
-    for (int p = 0; p < n_pairs; p++) {
-        const double p0 = quad_bcast_f64<0>(P), p1 = quad_bcast_f64<1>(P), p2 = quad_bcast_f64<2>(P), p3 = quad_bcast_f64<3>(P);
-        if (res[p].ok) {
-            const double *t = res[p].T_rel_inv + j;
-            double s = 0;
-            s += p0 * t[0]; s += p1 * t[4]; s += p2 * t[8]; s += p3 * t[12];
-            P = s;
+    for (int base = 0; base < n_pairs; base += 64) {
+        // the records of 64 pairs are fetched together (one dependent global load per pair made the
+        // serial product cost a memory round trip per step)
+        const int cnt = min(64, n_pairs - base);
+        __syncthreads();
+        for (int e = lane; e < cnt * 16; e += 64) sT[e] = res[base + (e >> 4)].T_rel_inv[e & 15];
+        if (lane < cnt) sOk[lane] = res[base + lane].ok;
+        __syncthreads();
+        for (int p = 0; p < cnt; p++) {
+            const double p0 = quad_bcast_f64<0>(P), p1 = quad_bcast_f64<1>(P), p2 = quad_bcast_f64<2>(P), p3 = quad_bcast_f64<3>(P);
+            if (sOk[p]) {
+                const double *t = sT + p * 16 + j;
+                double s = 0;
+                s += p0 * t[0]; s += p1 * t[4]; s += p2 * t[8]; s += p3 * t[12];
+                P = s;
+            }
+            if (lane < 16) res[base + p].pose[lane] = P;
         }
-        if (lane < 16) res[p].pose[lane] = P;
     }
 }
 
