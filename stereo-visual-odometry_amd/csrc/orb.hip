@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
     const int plane = (kCellPitch * (g.hCell[l] + 6) + 15) & ~15;
     uint8_t *raw = cf_smem, *V = cf_smem + plane, *keep = cf_smem + 2 * plane;
     uint16_t *list = (uint16_t *)(cf_smem + 3 * plane);
-    __shared__ int s_any, s_found, s_nlist, s_ncand;
+    __shared__ int s_any, s_found, s_nlist, s_ncand, s_run, s_wtot[4];
     const int b = blockIdx.z, cell = blockIdx.x;
     const int W = g.w[l], H = g.h[l], pitch = g.pitch[l];
     const int minBX = 16, minBY = 16, maxBX = W - 16, maxBY = H - 16;
@@ -172,51 +172,83 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
     if (maxX > maxBX) maxX = (float)maxBX;
     const int x0 = (int)iniX, y0 = (int)iniY, cw = (int)maxX - x0, ch = (int)maxY - y0;
     if (skip || cw < 7 || ch < 7) { if (tid == 0) *cnt = 0; return; }
-    // i / cw for 0 <= i < 66 * 66 without an integer division (a runtime divisor costs ~25 vector
-    // instructions, and every loop below needs one): (i + 0.5) / cw is never within 1e-3 of an
-    // integer, far above the float error, so the truncation is exact
+    // (row, column) of a linear index without an integer division (a runtime divisor costs ~25 vector
+    // instructions): (i + 0.5) / n is never within 1e-3 of an integer for the i, n that occur here,
+    // far above the float error, so truncating (i + 0.5) * (1 / n) is exact
     const int lowTh = min(iniTh, minTh);
-    const float inv_cw = 1.0f / (float)cw;
-    auto row_of = [&](int i) { return (int)(((float)i + 0.5f) * inv_cw); };
     const uint8_t *img = slots + (int64_t)b * slot_stride + g.origin[l];
-    if (tid == 0) { s_any = 0; s_found = 0; s_nlist = 0; s_ncand = 0; }
+    if (tid == 0) { s_any = 0; s_found = 0; s_nlist = 0; s_ncand = 0; s_run = 0; }
+    // V and keep start at zero everywhere (the two planes are contiguous)
+    for (int i = tid; i < plane / 2; i += 256) ((uint32_t *)V)[i] = 0;
     // the cell as aligned dwords (rows of the level are 4-byte aligned; the cell's first column
     // sits `ox` bytes into its first dword, so every LDS row is shifted by ox: rawc = raw + ox)
     const int ox = x0 & 3, nd = (ox + cw + 3) >> 2;
+    const float inv_nd = 1.0f / (float)nd;
     {
-        const float inv_nd = 1.0f / (float)nd;
         const uint8_t *src = img + (int64_t)y0 * pitch + (x0 - ox);
         for (int i = tid; i < nd * ch; i += 256) {
             const int y = (int)(((float)i + 0.5f) * inv_nd), c = i - y * nd;
             ((uint32_t *)(raw + y * kCellPitch))[c] = *(const uint32_t *)(src + (int64_t)y * pitch + 4 * c);
         }
     }
+    const uint32_t *rawd = (const uint32_t *)raw;           // aligned dword view, kCellPitch / 4 dwords per row
     raw += ox;
     __syncthreads();
     // Cornerness only matters where it can reach minTh: a corner at threshold t needs one pixel
     // of each opposite pair (0,8), (4,12) beyond t, so positions failing that 4-pixel test at minTh
     // keep V = 0, and the full arc min/max runs over a compacted list of the survivors.
-    for (int i = tid; i < (cw * ch + 255) / 256 * 256; i += 256) {
-        bool alive = false;
-        int pos = 0;
-        if (i < cw * ch) {
-            const int y = row_of(i), x = i - y * cw;
-            pos = y * kCellPitch + x;
-            V[pos] = 0; keep[pos] = 0;
-            if (x >= 3 && x < cw - 3 && y >= 3 && y < ch - 3) {
-                const uint8_t *c = &raw[pos];
-                const int v = c[0], t = lowTh;
-                const int d0 = v - c[3 * kCellPitch], d8 = v - c[-3 * kCellPitch], d4 = v - c[3], d12 = v - c[-3];
-                alive = ((d0 > t || d8 > t) && (d4 > t || d12 > t)) || ((d0 < -t || d8 < -t) && (d4 < -t || d12 < -t));
+    // The test runs on FOUR pixels per thread (one aligned LDS dword of row y and its neighbours
+    // three rows up / down and three columns left / right: five dword reads instead of twenty byte
+    // reads), in packed 16-bit arithmetic on the even and the odd bytes:
+    //   alive <=> max( min(v - min(p0,p8), v - min(p4,p12)),  min(max(p0,p8) - v, max(p4,p12) - v) ) > t
+    {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        const int rows = ch - 6, ngroups = nd * rows;
+        const s16x2 T1 = {(short)(lowTh + 1), (short)(lowTh + 1)};
+        constexpr int RD = kCellPitch / 4;
+        for (int i0 = 0; i0 < ngroups; i0 += 256) {
+            const int i = i0 + tid;
+            uint32_t m4 = 0;
+            int y = 0, xb = 0;
+            if (i < ngroups) {
+                const int yy = (int)(((float)i + 0.5f) * inv_nd), gq = i - yy * nd;
+                y = yy + 3; xb = 4 * gq - ox;                            // cell x of the dword's first byte
+                const uint32_t *r = rawd + y * RD + gq;
+                const uint32_t C = r[0], U = r[-3 * RD], D = r[3 * RD], Lf = gq > 0 ? r[-1] : 0u, Rt = r[1];
+                const uint32_t Lv = __builtin_amdgcn_alignbyte(C, Lf, 1);    // x - 3 neighbours of the four pixels
+                const uint32_t Rv = __builtin_amdgcn_alignbyte(Rt, C, 3);    // x + 3 neighbours
+                uint32_t sgn[2];
+#pragma unroll
+                for (int hb = 0; hb < 2; hb++) {                          // even bytes (pixels 0, 2), odd bytes (1, 3)
+                    auto half = [&](uint32_t w) { return __builtin_bit_cast(s16x2, (hb ? w >> 8 : w) & 0x00FF00FFu); };
+                    const s16x2 v = half(C), u = half(U), d = half(D), l = half(Lv), rr = half(Rv);
+                    const s16x2 mnA = __builtin_elementwise_min(u, d), mxA = __builtin_elementwise_max(u, d);
+                    const s16x2 mnB = __builtin_elementwise_min(l, rr), mxB = __builtin_elementwise_max(l, rr);
+                    const s16x2 dark = __builtin_elementwise_min(v - mnA, v - mnB);
+                    const s16x2 bright = __builtin_elementwise_min(mxA - v, mxB - v);
+                    sgn[hb] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(dark, bright) - T1);   // sign set <=> not alive
+                }
+                const uint32_t dead = ((sgn[0] >> 15) & 1u) | ((sgn[1] >> 14) & 2u) | ((sgn[0] >> 29) & 4u) | ((sgn[1] >> 28) & 8u);
+                // pixels inside [3, cw - 3)
+                const int lo = max(0, 3 - xb), hi = min(4, cw - 3 - xb);
+                const uint32_t inside = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+                m4 = ~dead & inside;
             }
-        }
-        const unsigned long long m = __ballot(alive);
-        if (m) {
+            // survivors -> list (any order): one LDS atomic per wave and step
             const int lane = tid & 63;
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&s_nlist, __popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (alive) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const unsigned long long b0 = __ballot(m4 & 1u), b1 = __ballot(m4 & 2u), b2 = __ballot(m4 & 4u), b3 = __ballot(m4 & 8u);
+            const int c0 = __popcll(b0), c1 = __popcll(b1), c2 = __popcll(b2), c3 = __popcll(b3);
+            if (c0 + c1 + c2 + c3) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_nlist, c0 + c1 + c2 + c3);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int pos = y * kCellPitch + xb;
+                if (m4 & 1u) list[base + __popcll(b0 & lt)] = (uint16_t)pos;
+                if (m4 & 2u) list[base + c0 + __popcll(b1 & lt)] = (uint16_t)(pos + 1);
+                if (m4 & 4u) list[base + c0 + c1 + __popcll(b2 & lt)] = (uint16_t)(pos + 2);
+                if (m4 & 8u) list[base + c0 + c1 + c2 + __popcll(b3 & lt)] = (uint16_t)(pos + 3);
+            }
         }
     }
     __syncthreads();
@@ -272,24 +304,46 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
         thr = minTh;
         __syncthreads();
     }
-    // ordered (row-major) emission by wave 0
-    if (tid < 64) {
+    // ordered (row-major) emission: the keep plane is scanned as dwords (four pixels per thread),
+    // block-wide exclusive scan of the per-thread counts (three ballots per wave + the wave totals
+    // through LDS) gives every keypoint its slot
+    {
         float4 *out = cell_cand + (int64_t)b * cand_img_stride + ((int64_t)g.cell_off[l] + cell) * kCellCap;
-        int n = 0;
-        for (int i0 = 0; i0 < cw * ch; i0 += 64) {
+        constexpr int RD = kCellPitch / 4;
+        const int nq = (cw + 3) >> 2, ngroups = nq * ch;
+        const float inv_nq = 1.0f / (float)nq;
+        const int lane = tid & 63, wv = tid >> 6;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int i0 = 0; i0 < ngroups; i0 += 256) {
             const int i = i0 + tid;
-            int y = 0, x = 0, k = 0;
-            if (i < cw * ch) { y = row_of(i); x = i - y * cw; k = keep[y * kCellPitch + x]; }
-            const unsigned long long m = __ballot(k != 0);
-            if (k) {
-                const int idx = n + __popcll(m & ((1ull << tid) - 1ull));
-                if (idx < kCellCap)
-                    out[idx] = make_float4((float)x + (float)(cj * wCell), (float)y + (float)(ci * hCell),
-                                           (float)V[y * kCellPitch + x], 0.f);
+            uint32_t kd = 0;
+            int y = 0, xq = 0;
+            if (i < ngroups) {
+                y = (int)(((float)i + 0.5f) * inv_nq); xq = 4 * (i - y * nq);
+                kd = ((const uint32_t *)keep)[y * RD + (xq >> 2)];
             }
-            n += __popcll(m);
+            const int c = (kd & 0xFFu ? 1 : 0) + (kd & 0xFF00u ? 1 : 0) + (kd & 0xFF0000u ? 1 : 0) + (kd & 0xFF000000u ? 1 : 0);
+            const unsigned long long b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4);
+            const int pre = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+            if (lane == 0) s_wtot[wv] = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+            __syncthreads();
+            int idx = s_run + pre, tot = 0;
+            for (int q = 0; q < 4; q++) { const int t = s_wtot[q]; if (q < wv) idx += t; tot += t; }
+            if (c) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if ((kd >> (8 * j)) & 0xFFu) {
+                        if (idx < kCellCap)
+                            out[idx] = make_float4((float)(xq + j) + (float)(cj * wCell), (float)y + (float)(ci * hCell),
+                                                   (float)V[y * kCellPitch + xq + j], 0.f);
+                        idx++;
+                    }
+            }
+            __syncthreads();
+            if (tid == 0) s_run += tot;
+            __syncthreads();
         }
-        if (tid == 0) *cnt = n;          // may exceed kCellCap: checked on the host side of the stage API
+        if (tid == 0) *cnt = s_run;          // may exceed kCellCap: flagged by orb_gather_kernel
     }
 }
 
