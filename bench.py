@@ -297,6 +297,8 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "lk_kernel (4-call circular chain, one launch per step)",
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                               "frac_measured_traffic": (round(traffic / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                                                         if traffic else None),
                                "launch_ms": round(lk_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
                                "limiting_resource": "valu-issue", "valu": valu, "kernel_source_sha256_16": src_hash}
         elif stage_ms.get("orb_cellfast"):
