@@ -10,7 +10,7 @@ python bench.py --steps 2 --warmup 1 $BARGS > gpurun_out/bench_cache.log 2>&1; e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --kernel-include-regex "svo::" --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 10 --warmup 2 $BARGS > $R/gpurun_out/prof_stats.log 2>&1; echo "stats exit=$?"
-tail -1 $R/gpurun_out/prof_stats.log > $R/gpurun_out/prof_bench_line.json
+grep '^{' $R/gpurun_out/prof_stats.log | tail -1 > $R/gpurun_out/prof_bench_line.json
 f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/prof_kernel_stats.csv && cat "$f" | cut -c1-160
 i=0
 for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU" \
