@@ -186,9 +186,8 @@ constexpr size_t kPnpLdsBytes = (size_t)(144 * 64) * sizeof(double);
 // workgroups per CU: it would otherwise hand the single wave all 512 registers of its SIMD, which
 // starves every kernel that overlaps the pose stage.  With two waves per EU
 // as the target it gets 256 (architectural + accumulation; spills go to the latter, not to memory).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void pnp_hyp_kernel(PnpArgs a)
+__device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem)
 {
-    extern __shared__ __attribute__((aligned(16))) double pnp_smem[];
     const int lane = threadIdx.x, b = blockIdx.y;
     PnpState *st = a.state + b;
     const int h = blockIdx.x * kHypBlock + lane;             // hypothesis index inside the phase
@@ -226,6 +225,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     PnpHyp out;
     epnp5_d(e, pnp_smem + lane, 64, out.R, out.t);
     a.hyp[(int64_t)b * kPhaseHyps + h] = out;
+}
+
+// Two builds of the same body.  The 12x12 EPnP wants far more than 256 registers (Epnp5 alone is 88
+// doubles): with one wave per SIMD (512 registers, spills go to the accumulation half) a single
+// hypothesis block is ~20 % faster -- what the ONLINE path wants, where one pair's 64 hypotheses are
+// all there is.  A batch launches thousands of blocks beside the next batch's front end; there a
+// 512-register wave owns a whole SIMD's register file and starves the kernels it overlaps (ORB mode:
+// +1 ms per 256 pairs), so the batched path uses the 256-register build (two waves per SIMD).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void pnp_hyp_kernel_wide(PnpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double pnp_smem_w[];
+    pnp_hyp_body(a, pnp_smem_w);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void pnp_hyp_kernel(PnpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double pnp_smem[];
+    pnp_hyp_body(a, pnp_smem);
 }
 
 // findInliers for the hypotheses of the phase: grid (blocks of 64 hypotheses, items, point chunks),
@@ -664,6 +680,8 @@ int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
 {
     // called once per context at creation: the EPnP and refit kernels need more dynamic LDS than the default limit
     if (hipFuncSetAttribute((const void *)pnp_hyp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kPnpLdsBytes) != hipSuccess ||
+        hipFuncSetAttribute((const void *)pnp_hyp_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPnpLdsBytes) != hipSuccess)
         return SVO_ERR_HIP;
     if (hipFuncSetAttribute((const void *)pnp_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -694,7 +712,10 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
         const int hyps = niters - base < cap ? niters - base : cap;
         const int blocks = (hyps + kHypBlock - 1) / kHypBlock;
         a.phase_base = base; a.phase_cap = cap; a.phase_index = phase;
-        hipLaunchKernelGGL(pnp_hyp_kernel, dim3(blocks + 1, n_items), dim3(64), kPnpLdsBytes, st, a);     // + the drawer
+        if ((blocks + 1) * n_items <= 256)     // the chip is not full: latency matters, registers are free
+            hipLaunchKernelGGL(pnp_hyp_kernel_wide, dim3(blocks + 1, n_items), dim3(64), kPnpLdsBytes, st, a);   // + the drawer
+        else
+            hipLaunchKernelGGL(pnp_hyp_kernel, dim3(blocks + 1, n_items), dim3(64), kPnpLdsBytes, st, a);
         hipLaunchKernelGGL(pnp_score_kernel, dim3(blocks, n_items, zchunks), dim3(256), 0, st, a);
         hipLaunchKernelGGL(pnp_select_kernel, dim3(n_items), dim3(64), 0, st, a);
         base += cap;

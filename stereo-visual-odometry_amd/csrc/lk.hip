@@ -448,9 +448,17 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void lk_kernel(LkArgs a)
 {
     __shared__ uint32_t lds[4 * kLdsDwPerWave];
-    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
-    const int b = (slot_id / a.gx) * 8 + xcd, bx = slot_id % a.gx;
-    if (b >= a.batch) return;
+    // items in whole groups of 8 are dealt one per XCD; the last (batch % 8) items -- the single pair of
+    // the online path among them -- are spread over all XCDs in the plain order
+    const int n_aware = (a.batch & ~7) * a.gx;
+    int b, bx;
+    if ((int)blockIdx.x < n_aware) {
+        const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+        b = (slot_id / a.gx) * 8 + xcd; bx = slot_id % a.gx;
+    } else {
+        const int r = blockIdx.x - n_aware;
+        b = (a.batch & ~7) + r / a.gx; bx = r % a.gx;
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slot = (lane >> 2) & 3;
     int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
@@ -538,8 +546,7 @@ void launch_lk(const LkArgs &a0, int batch, int max_pts, hipStream_t st)
     LkArgs a = a0;
     a.gx = chunks < 192 ? chunks : 192;
     a.batch = batch;
-    const int groups = (batch + 7) / 8;                     // items are dealt to the 8 XCDs in groups of 8
-    dim3 grid(groups * 8 * a.gx, 1, 1), blk(256, 1, 1);
+    dim3 grid(batch * a.gx, 1, 1), blk(256, 1, 1);
     hipLaunchKernelGGL(lk_kernel, grid, blk, 0, st, a);
 }
 
