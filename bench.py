@@ -316,7 +316,6 @@ def main():
 
     # ---- secondary legs (N = 1): M1 with H2D inside the timed region, and the online path ---------
     if world == 1 and not args.no_secondary and not args.config5:
-        ctx.set_overlap(False)
         hostL = [ctx.host_frames(B + 1, PITCH) for _ in range(NC)]
         hostR = [ctx.host_frames(B + 1, PITCH) for _ in range(NC)]
         for c in range(NC):
@@ -324,14 +323,18 @@ def main():
             hostR[c][:] = R[c * B:c * B + B + 1].cpu().numpy()
 
         def m1_run(n_steps):
+            """upload(0) track(0) | upload(k+1) track(k+1) collect(k) ...: two batches outstanding, so chunk k+1's
+            H2D and (overlap mode) chunk k's pose stage run beside chunk k+1's front end; every step's records
+            reach the host; the pose chain continues across the chunks on the device."""
             ctx.upload_frames(0, hostL[0], hostR[0])
+            ctx.track_uploaded_async(0, B + 1)
             recs = None
-            for k in range(n_steps):
-                ctx.track_uploaded_async(k & 1, B + 1)              # returns at once
-                if k + 1 < n_steps:                                 # next chunk crosses PCIe beside this batch's kernels
-                    c = (k + 1) % NC
-                    ctx.upload_frames((k + 1) & 1, hostL[c], hostR[c])
-                recs = ctx.collect_results(B)                       # records of step k on the host
+            for k in range(1, n_steps):
+                c = k % NC
+                ctx.upload_frames(k & 1, hostL[c], hostR[c])
+                ctx.track_uploaded_async(k & 1, B + 1, continue_chain=True)
+                recs = ctx.collect_results(B)                       # records of step k - 1 on the host
+            recs = ctx.collect_results(B)                           # ... and of the last step
             return recs
 
         m1_run(min(2, args.warmup + 1))

@@ -215,11 +215,14 @@ int svo_wait_upload(svo_ctx *ctx, int buf);
 int svo_track_uploaded(svo_ctx *ctx, int buf, int n_frames, const double *pose0,
                        svo_step_result *results, int results_mem);
 /* The same without waiting for the GPU (ABI v4): the n_frames - 1 step records stay in the context
- * until svo_collect_results copies them to a HOST array (it waits for the batch).  Between the two
- * calls the caller is free to decode and svo_upload_frames the NEXT chunk into the other buffer, so
- * that its host-to-device copy runs beside this batch's kernels.  One batch may be outstanding:
- * collect before the next svo_track_* call on the context. */
-int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, const double *pose0);
+ * until svo_collect_results copies them to a HOST array (it waits for that batch only).  Up to TWO
+ * batches may be outstanding, collected in launch order, so a caller keeps the GPU busy like this:
+ *     upload(0); track_async(0);  upload(1); track_async(1); collect(0);  upload(2); track_async(2); collect(1); ...
+ * -- the upload of chunk k+1 and, in overlap mode, the pose stage of chunk k run beside chunk k+1's
+ * front end, and the host only ever waits for a batch that has a successor queued behind it.
+ * continue_chain != 0 seeds the pose chain with the LAST pose of the previous async batch on the device
+ * (no host round trip; pose0 is ignored); 0 seeds it with pose0 (NULL = identity). */
+int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, const double *pose0, int continue_chain);
 int svo_collect_results(svo_ctx *ctx, svo_step_result *results, int n_pairs);
 
 /* Read-back of the online state (after svo_add_frame), for callers that keep the reference's

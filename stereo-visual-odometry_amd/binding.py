@@ -95,7 +95,7 @@ def load_library():
     lib.svo_upload_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]
     lib.svo_wait_upload.argtypes = [C.c_void_p, C.c_int]
     lib.svo_track_uploaded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
-    lib.svo_track_uploaded_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.svo_track_uploaded_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     lib.svo_collect_results.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.svo_set_pose.argtypes = [C.c_void_p, C.c_void_p]
     _LIB = lib
@@ -411,13 +411,14 @@ class Context:
         self._check(self.lib.svo_track_uploaded(self.h, int(buf), int(n_frames), p0, C.c_void_p(out.ctypes.data), MEM_HOST))
         return out
 
-    def track_uploaded_async(self, buf, n_frames, pose0=None):
-        """svo_track_uploaded without waiting for the GPU; the records are fetched by collect_results()."""
+    def track_uploaded_async(self, buf, n_frames, pose0=None, continue_chain=False):
+        """svo_track_uploaded without waiting for the GPU; the records are fetched by collect_results()
+        (up to two batches outstanding, collected in launch order)."""
         p0 = None
         if pose0 is not None:
             pose0 = np.ascontiguousarray(pose0, np.float64).reshape(16)
             p0 = C.c_void_p(pose0.ctypes.data)
-        self._check(self.lib.svo_track_uploaded_async(self.h, int(buf), int(n_frames), p0))
+        self._check(self.lib.svo_track_uploaded_async(self.h, int(buf), int(n_frames), p0, int(bool(continue_chain))))
 
     def collect_results(self, n_pairs):
         out = np.zeros(int(n_pairs), dtype=STEP_DTYPE)

@@ -573,12 +573,12 @@ __device__ __forceinline__ double quad_bcast_f64(double v)
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), K * 0x55, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
-__global__ __launch_bounds__(64) void chain_kernel(svo_step_result *res, int n_pairs, Pose16 pose0)
+__global__ __launch_bounds__(64) void chain_kernel(svo_step_result *res, int n_pairs, Pose16 pose0, const double *seed_dev)
 {
     __shared__ double sT[64 * 16];
     __shared__ int sOk[64];
     const int lane = threadIdx.x, i = (lane >> 2) & 3, j = lane & 3;
-    double P = pose0.m[i * 4 + j];
+    double P = seed_dev ? seed_dev[i * 4 + j] : pose0.m[i * 4 + j];     // device seed: the previous batch's last pose
     for (int base = 0; base < n_pairs; base += 64) {
         // the records of 64 pairs are fetched together (one dependent global load per pair made the
         // serial product cost a memory round trip per step)
@@ -763,7 +763,7 @@ void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const i
     hipLaunchKernelGGL(finalize_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, f);
     Pose16 p0;
     for (int i = 0; i < 16; i++) p0.m[i] = pose0_host ? pose0_host[i] : ((i % 5 == 0) ? 1.0 : 0.0);
-    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, st, ctx->d_results, n_pairs, p0);
+    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, st, ctx->d_results, n_pairs, p0, ctx->seed_dev);
 }
 
 // ---- stage API ------------------------------------------------------------------------------

@@ -98,6 +98,11 @@ static void free_all(svo_ctx *c)
         if (c->ev_fb_free[k]) (void)hipEventDestroy(c->ev_fb_free[k]);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (int k = 0; k < 2; k++) {
+        F(c->d_async[k]);
+        if (c->ev_async[k]) (void)hipEventDestroy(c->ev_async[k]);
+    }
+    if (c->fetch_stream) (void)hipStreamDestroy(c->fetch_stream);
     orb_free(c);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -731,33 +736,59 @@ extern "C" int svo_track_uploaded(svo_ctx *ctx, int buf, int n_frames, const dou
     return rc;
 }
 
-extern "C" int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, const double *pose0)
+extern "C" int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, const double *pose0, int continue_chain)
 {
     if (!ctx) return SVO_ERR_ARG;
     SVO_ARG(buf == 0 || buf == 1, "buf must be 0 or 1");
     SVO_ARG(n_frames >= 2 && n_frames <= ctx->fb_frames[buf], "n_frames exceeds what was uploaded");
+    SVO_ARG(ctx->async_tail - ctx->async_head < 2, "two batches are already outstanding: collect one first");
     SVO_HIP(hipSetDevice(ctx->device));
+    const int r = (int)(ctx->async_tail & 1), n_pairs = n_frames - 1;
+    if (!ctx->d_async[0]) {
+        for (int k = 0; k < 2; k++) {
+            SVO_HIP(hipMalloc(&ctx->d_async[k], sizeof(svo_step_result) * (size_t)ctx->cfg.max_batch));
+            SVO_HIP(hipEventCreateWithFlags(&ctx->ev_async[k], hipEventDisableTiming));
+        }
+        SVO_HIP(hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking));
+    }
+    if (continue_chain) {
+        SVO_ARG(ctx->async_tail > 0, "continue_chain needs a previous async batch");
+        const int pr = r ^ 1;
+        SVO_ARG(ctx->async_last_pairs > 0, "continue_chain needs a previous async batch");
+        ctx->seed_dev = ctx->d_async[pr][ctx->async_last_pairs - 1].pose;
+    }
     const size_t fbytes = (size_t)ctx->stage_pitch * ctx->cfg.height, per_cam = fbytes * (size_t)(ctx->cfg.max_batch + 1);
     SVO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_up[buf], 0));
     int rc = pipeline_track_batch(ctx, ctx->fb[buf], ctx->fb[buf] + per_cam, ctx->stage_pitch, (int64_t)fbytes, n_frames,
-                                  pose0, nullptr, SVO_MEM_DEVICE);
+                                  continue_chain ? nullptr : pose0, ctx->d_async[r], SVO_MEM_DEVICE);
+    ctx->seed_dev = nullptr;
     if (rc < 0) return rc;
     SVO_HIP(hipEventRecord(ctx->ev_fb_free[buf], ctx->stream));
     ctx->fb_used[buf] = true;
-    ctx->async_pairs = n_frames - 1;
+    // the records land in d_async[r] at the end of the pose stage, wherever that ran
+    SVO_HIP(hipEventRecord(ctx->ev_async[r], ctx->back_pending ? ctx->side_stream : ctx->stream));
+    ctx->async_n[r] = n_pairs;
+    ctx->async_last_pairs = n_pairs;
+    ctx->async_tail++;
     return rc;
 }
 
 extern "C" int svo_collect_results(svo_ctx *ctx, svo_step_result *results, int n_pairs)
 {
     if (!ctx) return SVO_ERR_ARG;
-    SVO_ARG(results && n_pairs >= 1 && n_pairs <= ctx->async_pairs, "no outstanding batch with that many pairs");
+    SVO_ARG(ctx->async_tail != ctx->async_head, "no outstanding batch");
+    const int r = (int)(ctx->async_head & 1);
+    SVO_ARG(results && n_pairs >= 1 && n_pairs <= ctx->async_n[r], "the oldest outstanding batch has fewer pairs");
     SVO_HIP(hipSetDevice(ctx->device));
+    // wait for THAT batch only (its successor may be running), then fetch on a stream of its own: the
+    // copy stream may be busy with the next chunk's upload
+    SVO_HIP(hipEventSynchronize(ctx->ev_async[r]));
     svo_step_result *h = (svo_step_result *)((char *)ctx->h_pinned + 4096);
-    SVO_HIP(hipMemcpyAsync(h, ctx->d_results, sizeof(svo_step_result) * (size_t)n_pairs, hipMemcpyDeviceToHost, ctx->stream));
-    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    SVO_HIP(hipMemcpyAsync(h, ctx->d_async[r], sizeof(svo_step_result) * (size_t)n_pairs, hipMemcpyDeviceToHost, ctx->fetch_stream));
+    SVO_HIP(hipStreamSynchronize(ctx->fetch_stream));
     memcpy(results, h, sizeof(svo_step_result) * (size_t)n_pairs);
-    ctx->async_pairs = 0;
+    ctx->async_n[r] = 0;
+    ctx->async_head++;
     return SVO_OK;
 }
 

@@ -68,7 +68,14 @@ struct svo_ctx {
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_fb_free[2] = {nullptr, nullptr};
     bool fb_used[2] = {false, false};
     int fb_frames[2] = {0, 0};
-    int async_pairs = 0;              // pairs of the batch launched by svo_track_uploaded_async, not yet collected
+    // svo_track_uploaded_async: two result buffers, collected in launch order
+    svo_step_result *d_async[2] = {nullptr, nullptr};
+    hipEvent_t ev_async[2] = {nullptr, nullptr};
+    int async_n[2] = {0, 0};          // pairs of the outstanding batch in each buffer (0 = free)
+    unsigned async_head = 0, async_tail = 0;   // next to collect / next to launch
+    int async_last_pairs = 0;         // pairs of the most recently launched async batch
+    const double *seed_dev = nullptr; // device-side seed pose of the next chain launch (continue_chain)
+    hipStream_t fetch_stream = nullptr;
     hipEvent_t ev_front = nullptr, ev_back = nullptr;
     bool back_pending = false;
     int *kp_n_snap = nullptr;         // n_prev / n_cur (/ ORB capacity flags) of the batch the pose stage works on: 3 x max_batch
@@ -115,5 +122,5 @@ int orb_match_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipS
 void orb_snapshot_counts(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipStream_t st);
 void orb_launch_match_fixed(svo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, hipStream_t st);
 void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur, const int *ovf,
-                           const double *pose0_host, hipStream_t st);
+                           const double *pose0_host, hipStream_t st);      // ctx->seed_dev != null: seed read on the device
 }  // namespace svo

@@ -48,7 +48,10 @@ public:
     bool TrackUploaded(int buf, int n_frames, std::vector<svo_step_result> &out);
     // the same in two halves: launch without waiting for the GPU, then (after the caller has decoded and
     // uploaded the next chunk, whose copy then overlaps this batch's kernels) collect the records
-    bool TrackUploadedAsync(int buf, int n_frames);
+    // (up to two chunks may be outstanding, collected in launch order; continue_chain seeds the pose chain on
+    // the device with the previous chunk's last pose, so a chunk can be launched before its predecessor's
+    // records have come back)
+    bool TrackUploadedAsync(int buf, int n_frames, bool continue_chain = false);
     bool CollectUploaded(std::vector<svo_step_result> &out);
 
 private:
@@ -70,7 +73,9 @@ private:
     double Px_ = 0, Py_ = 0, Pz_ = 0;
 
     svo_ctx *ctx_ = nullptr;
-    int ctx_w_ = 0, ctx_h_ = 0, ctx_batch_ = 0, async_pairs_ = 0;
+    int ctx_w_ = 0, ctx_h_ = 0, ctx_batch_ = 0;
+    int async_pairs_[2] = {0, 0};
+    unsigned async_head_ = 0, async_tail_ = 0;
     svo_step_result last_;
     bool fill_features_ = false;
 

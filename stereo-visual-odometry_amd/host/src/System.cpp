@@ -306,33 +306,45 @@ void System::RunBatched(int B, int decode_threads)
     current_image_index_ = cur_n > 0 ? 1 : 0;
     if (cur_n > 0) WritePose();                             // frame 0: StereoInit_f2f, pose = identity
     std::vector<svo_step_result> recs;
+    auto flush = [&](double seconds, int pairs) {           // the oldest outstanding chunk's records -> pose file
+        recs.clear();
+        if (!tracking_->CollectUploaded(recs)) return false;
+        if (getenv("LZB_VIO_VERBOSE")) LZB_LOG("INFO", "VO cost time: %f seconds for %d pairs", seconds, pairs);
+        for (const auto &r : recs) { WritePoseRow(r.pose); current_image_index_++; }
+        return true;
+    };
     bool ok = cur_n >= 2 && upload(0, cur_n);
+    int outstanding = 0, chunk = 0;
+    auto t_prev = std::chrono::steady_clock::now();
     while (ok) {
         int nn = 0;
         std::thread bg;
-        if (cur_n == B + 1)                                 // a full chunk: there may be more frames
+        if (cur_n == B + 1) {                               // a full chunk: there may be more frames
+            // the other page-locked buffer is the source of the upload issued one iteration ago
+            if (chunk > 0 && svo_wait_upload(ctx, k ^ 1) != SVO_OK) { ok = false; break; }
             bg = std::thread([&]() {
                 for (int cam = 0; cam < 2; cam++)
                     memcpy(pin[k ^ 1][cam], pin[k][cam] + (size_t)B * fbytes, fbytes);
                 nn = 1 + decode(k ^ 1, 1, next, B);
             });
-        recs.clear();
-        auto t1 = std::chrono::steady_clock::now();
-        ok = tracking_->TrackUploadedAsync(k, cur_n);       // returns at once: the GPU works on chunk c ...
+        }
+        // returns at once: the GPU works on chunk c (its pose chain continues from chunk c-1's last pose
+        // on the device) while chunk c-1's records are fetched and chunk c+1 is decoded
+        ok = tracking_->TrackUploadedAsync(k, cur_n, chunk > 0);
+        if (ok) outstanding++;
+        auto t_now = std::chrono::steady_clock::now();
+        if (ok && outstanding == 2) { ok = flush(std::chrono::duration<double>(t_now - t_prev).count(), B); outstanding--; }
+        t_prev = t_now;
         if (bg.joinable()) bg.join();
-        // ... while chunk c+1, decoded meanwhile, already crosses PCIe on the copy stream
+        // chunk c+1 crosses PCIe on the copy stream beside chunk c's kernels
         const bool more = ok && nn >= 2 && upload(k ^ 1, nn);
-        ok = ok && tracking_->CollectUploaded(recs);
-        auto t2 = std::chrono::steady_clock::now();
-        if (!ok) break;
-        if (getenv("LZB_VIO_VERBOSE"))
-            LZB_LOG("INFO", "VO cost time: %f seconds for %d pairs", std::chrono::duration<double>(t2 - t1).count(), cur_n - 1);
-        for (const auto &r : recs) { WritePoseRow(r.pose); current_image_index_++; }
-        if (!more) break;
+        if (!ok || !more) break;
         next += nn - 1;
         k ^= 1;
         cur_n = nn;
+        chunk++;
     }
+    while (ok && outstanding > 0) { ok = flush(0.0, 0); outstanding--; }
     svo_sync(ctx);
     for (int q = 0; q < 2; q++)
         for (int cam = 0; cam < 2; cam++) svo_host_free(ctx, pin[q][cam]);

@@ -248,25 +248,27 @@ bool Tracking::TrackUploaded(int buf, int n_frames, std::vector<svo_step_result>
     return TrackUploadedAsync(buf, n_frames) && CollectUploaded(out);
 }
 
-bool Tracking::TrackUploadedAsync(int buf, int n_frames)
+bool Tracking::TrackUploadedAsync(int buf, int n_frames, bool continue_chain)
 {
-    if (!ctx_ || n_frames < 2) return false;
-    int rc = svo_track_uploaded_async(ctx_, buf, n_frames, frame_pose_.m);
+    if (!ctx_ || n_frames < 2 || async_tail_ - async_head_ >= 2) return false;
+    int rc = svo_track_uploaded_async(ctx_, buf, n_frames, frame_pose_.m, continue_chain ? 1 : 0);
     if (rc < 0) {
         LZB_LOG("ERROR", "svo_track_uploaded_async: %s", svo_last_error(ctx_));
         return false;
     }
-    async_pairs_ = n_frames - 1;
+    async_pairs_[async_tail_ & 1] = n_frames - 1;
+    async_tail_++;
     return true;
 }
 
 bool Tracking::CollectUploaded(std::vector<svo_step_result> &out)
 {
-    if (!ctx_ || async_pairs_ < 1) return false;
+    if (!ctx_ || async_tail_ == async_head_) return false;
+    const int n = async_pairs_[async_head_ & 1];
     const size_t first = out.size();
-    out.resize(first + (size_t)async_pairs_);
-    int rc = svo_collect_results(ctx_, out.data() + first, async_pairs_);
-    async_pairs_ = 0;
+    out.resize(first + (size_t)n);
+    int rc = svo_collect_results(ctx_, out.data() + first, n);
+    async_head_++;
     if (rc < 0) {
         LZB_LOG("ERROR", "svo_collect_results: %s", svo_last_error(ctx_));
         out.resize(first);

@@ -301,6 +301,57 @@ def test_host_frame_batches_match_track_batch(pkg, oracle, tc, small_seq):
     c.close()
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_async_uploaded_chunks_continue_the_chain_on_the_device(pkg, tc, small_seq, overlap):
+    """svo_track_uploaded_async with two batches outstanding and continue_chain: three one-pair chunks
+    (one-frame halo) launched ahead of their predecessors' records give, record for record, what ONE
+    svo_track_batch over the four frames gives -- poses included (the seed of chunk c is chunk c-1's last
+    pose, read on the device)."""
+    seq, frames = small_seq
+    h, w = frames[0][0].shape
+    P1, P2 = seq.proj()
+    c = pkg.Context(w, h, device=0, max_batch=4, P1=P1, P2=P2)
+    L = tc.from_numpy(np.stack([f[0] for f in frames])).cuda()
+    R = tc.from_numpy(np.stack([f[1] for f in frames])).cuda()
+    pose0 = np.eye(4)
+    pose0[:3, 3] = [4.0, -1.0, 2.0]
+    whole = c.track_batch(L, R, pose0=pose0)
+    c.set_overlap(overlap)
+    pitch = (w + 255) // 256 * 256
+    chunks = []
+    for k in range(3):
+        hl, hr = c.host_frames(2, pitch), c.host_frames(2, pitch)
+        for i in range(2):
+            hl[i, :, :w] = frames[k + i][0]
+            hr[i, :, :w] = frames[k + i][1]
+        chunks.append((hl, hr))
+    got = []
+    c.upload_frames(0, *chunks[0])
+    c.track_uploaded_async(0, 2, pose0=pose0)
+    for k in (1, 2):
+        c.upload_frames(k & 1, *chunks[k])
+        c.track_uploaded_async(k & 1, 2, continue_chain=True)     # launched before chunk k-1 was collected
+        got.append(c.collect_results(1))
+    got.append(c.collect_results(1))
+    with pytest.raises(pkg.SvoError):
+        c.collect_results(1)                                       # nothing outstanding any more
+    got = np.concatenate(got)
+    assert got.tobytes() == whole.tobytes()
+    # a third launch without a collect is refused, not silently queued over live results
+    c.upload_frames(0, *chunks[0])
+    c.track_uploaded_async(0, 2)
+    c.upload_frames(1, *chunks[1])
+    c.track_uploaded_async(1, 2, continue_chain=True)
+    with pytest.raises(pkg.SvoError):
+        c.track_uploaded_async(0, 2, continue_chain=True)
+    c.collect_results(1)
+    c.collect_results(1)
+    for hl, hr in chunks:
+        c.host_free(hl)
+        c.host_free(hr)
+    c.close()
+
+
 def test_pair_sharding_chains_to_the_whole_sequence(pkg, tc, small_seq):
     """Chunks of frame pairs tracked independently (one-frame halo) + svo_chain_relative over the
     gathered relative motions == the whole sequence tracked in one batch."""
