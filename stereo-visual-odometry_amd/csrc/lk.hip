@@ -231,17 +231,25 @@ __device__ __forceinline__ int dot2_v(uint32_t a, uint32_t b, int c)      // a .
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ int dot2_sv(uint32_t a, uint32_t b_uniform, int c)   // b wave-uniform (SGPR), c in a VGPR
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
 // `off` = byte offset of the lane's first J sample inside the slot's tile: (cy + row) * 40 + cx + seg * 7
 // (the slot part is one value broadcast from its control lane, the lane part a constant)
-__device__ __forceinline__ void mismatch_slot(const uint32_t *tileJ, int off, uint32_t Wa, uint32_t Wb,
+// `vround` = 2^8 held in a VGPR: a VOP3P instruction can read ONE scalar operand, and that one is the
+// slot's weight (an SGPR from v_readlane); a scalar rounding constant cost a v_mov per slot and iteration
+__device__ __forceinline__ void mismatch_slot(const uint32_t *tile_base, int off, uint32_t Wa, uint32_t Wb,
                                               const uint32_t (&IxP)[4], const uint32_t (&IyP)[4], int nIIx, int nIIy,
-                                              int &pb1, int &pb2)
+                                              int vround, int &pb1, int &pb2)
 {
     // (ds_read_u8_d16 / _d16_hi straight into register halves would spare the perms, but with
     //  SRAM-ECC on -- gfx950 -- a d16 load zeroes the other half instead of preserving it)
     uint32_t a0, b0, a1, b1;                 // row 0 / row 1: bytes 0-3 (a), 4-7 (b)
     {
-        const uint32_t *p = tileJ + (off >> 2);
+        const uint32_t *p = tile_base + (off >> 2);   // `off` already holds the slot's tile offset (a multiple of 4)
         const int sh = off & 3;              // rows are 40 bytes apart: the same shift for both
         const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], e0 = p[kTileJDw], e1 = p[kTileJDw + 1], e2 = p[kTileJDw + 2];
         a0 = __builtin_amdgcn_alignbyte(d1, d0, sh); b0 = __builtin_amdgcn_alignbyte(d2, d1, sh);
@@ -255,7 +263,7 @@ __device__ __forceinline__ void mismatch_slot(const uint32_t *tileJ, int off, ui
     }
     int d[7];
 #pragma unroll
-    for (int k = 0; k < 7; k++) d[k] = dot2(C[k + 1], Wb, dot2_k(C[k], Wa, 1 << (W_BITS - 5 - 1)));
+    for (int k = 0; k < 7; k++) d[k] = dot2(C[k + 1], Wb, dot2_sv(C[k], Wa, vround));
     // J samples d >> 9 (0 <= d < 2^22): bytes 1-2 of two sums side by side, then one packed shift
     const u16x2 one = {1, 1};
 #pragma unroll
@@ -272,7 +280,8 @@ __device__ __forceinline__ void mismatch_slot(const uint32_t *tileJ, int off, ui
 // One cv::calcOpticalFlowPyrLK call for the wave's four points.  Control values (prevPt, outPt,
 // status, live) are per lane = per slot (lane >> 2) & 3.
 __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI, const uint8_t *slotJ, float2 prevPt,
-                                         float2 &outPt, int &status, bool live, uint32_t *lds, int lane)
+                                         float2 &outPt, int &status, bool live, uint32_t *lds, const uint32_t *lds_wg,
+                                         int wave_off, int lane)
 {
     PixLane pl;
     pl.row = min(lane / 3, kWin - 1); pl.seg = lane - (lane / 3) * 3; pl.on = lane < 63;
@@ -281,7 +290,10 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
 
     uint32_t IxP[kSlots][4], IyP[kSlots][4];
     int nIIx[kSlots], nIIy[kSlots];
-    const int lane_off = pl.row * (kTileJDw * 4) + pl.seg * 7;     // lane part of the J sample offset
+    // lane part of the J sample offset, the wave's LDS region included (bytes from the workgroup array)
+    const int lane_off = pl.row * (kTileJDw * 4) + pl.seg * 7 + wave_off;
+    int vround = 1 << (W_BITS - 5 - 1);
+    asm volatile("" : "+v"(vround));                          // keep it in a VGPR (see mismatch_slot)
     status = 1;
     float nx = 0.f, ny = 0.f;                    // nextPts[i]
     for (int level = g.nlevels - 1; level >= 0; --level) {
@@ -376,7 +388,8 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
             int cx = inx - tx0, cy = iny - ty0;
             const bool restage = it_on && ((unsigned)cx > 17u || (unsigned)cy > 10u);
             if (restage) { tx0 = (inx - 8) & ~3; ty0 = iny - 5; cx = inx - tx0; cy = iny - ty0; }
-            const int joff = (int)__umul24((unsigned)cy, kTileJDw * 4) + cx;   // slot part of the J sample offset (bytes); 0 <= cy <= 10
+            // slot part of the J sample offset (bytes; 0 <= cy <= 10), tile position of the slot included
+            const int joff = (int)__umul24((unsigned)cy, kTileJDw * 4) + cx + (int)(((unsigned)lane >> 2) & 3u) * (kSlotDw * 4);
             const unsigned long long m_it = __ballot(it_on), m_rs = __ballot(restage);
             int pb[kSlots][2];
 #pragma unroll
@@ -396,7 +409,7 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
                 }
                 const int joffs = __builtin_amdgcn_readlane(joff, 4 * s);
                 const uint32_t Was = __builtin_amdgcn_readlane(Wa, 4 * s), Wbs = __builtin_amdgcn_readlane(Wb, 4 * s);
-                mismatch_slot(tile, joffs + lane_off, Was, Wbs, IxP[s], IyP[s], nIIx[s], nIIy[s], pb[s][0], pb[s][1]);
+                mismatch_slot(lds_wg, joffs + lane_off, Was, Wbs, IxP[s], IyP[s], nIIx[s], nIIy[s], vround, pb[s][0], pb[s][1]);
             }
             float b1f, b2f;
             {
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const uint8_t *sI = a.prev[c] + (int64_t)b * a.slot_stride;
             const uint8_t *sJ = a.next[c] + (int64_t)b * a.slot_stride;
             int st;
-            lk_call4(a.g, sI, sJ, cur, nxt, st, live, my, lane);
+            lk_call4(a.g, sI, sJ, cur, nxt, st, live, my, lds, wave * (kLdsDwPerWave * 4), lane);
             if (writer && live) {
                 a.pts_out[c][po] = nxt;
                 a.status[c][po] = (uint8_t)st;

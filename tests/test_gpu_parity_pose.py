@@ -301,6 +301,29 @@ def test_host_frame_batches_match_track_batch(pkg, oracle, tc, small_seq):
     c.close()
 
 
+def test_set_pose_seeds_the_online_chain(pkg, tc, small_seq):
+    """svo_set_pose: a context created in the middle of a run (e.g. rebuilt for another frame size by the
+    host mirror) continues frame_pose_ instead of restarting from the identity."""
+    seq, frames = small_seq
+    h, w = frames[0][0].shape
+    P1, P2 = seq.proj()
+    a = pkg.Context(w, h, device=0, P1=P1, P2=P2)
+    for f in frames[:3]:
+        a.add_frame(*f)
+    mid = a.get_pose().copy()
+    rc, ra = a.add_frame(*frames[3])
+    b = pkg.Context(w, h, device=0, P1=P1, P2=P2)
+    b.set_pose(mid)
+    rc0, r0 = b.add_frame(*frames[2])                      # initialises only: the pose is the seed
+    assert rc0 == 0 and np.array_equal(b.get_pose(), mid) and np.array_equal(r0["pose"].reshape(4, 4), mid)
+    rcb, rb = b.add_frame(*frames[3])
+    assert rcb == rc and rb["pose"].tobytes() == ra["pose"].tobytes() and np.array_equal(b.get_pose(), a.get_pose())
+    b.reset()
+    assert np.array_equal(b.get_pose(), np.eye(4))
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_async_uploaded_chunks_continue_the_chain_on_the_device(pkg, tc, small_seq, overlap):
     """svo_track_uploaded_async with two batches outstanding and continue_chain: three one-pair chunks
