@@ -170,20 +170,23 @@ __device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane 
         Q12[j] = perm_b32(R[2][j >> 2], R[1][j >> 2], sel);
         Q23[j] = perm_b32(R[3][j >> 2], R[2][j >> 2], sel);
     }
-    // vertical Scharr passes, rows A | B packed
+    // vertical Scharr passes, rows A | B packed.  Both passes carry a factor 4 (coefficients 12 / 40
+    // instead of 3 / 10; |4 d| <= 16320 still fits 16 bits): the interpolated derivative
+    // (sum + 2^13) >> 14 then equals (4 sum + 2^15) >> 16, i.e. the HIGH half of the accumulator, and
+    // the pack below picks bytes 2-3 directly instead of shifting every value first.
     uint32_t T0[10], T1[10];
-    const u16x2 k3 = {3, 3}, k10 = {10, 10};
+    const u16x2 k12 = {12, 12}, k40 = {40, 40};
 #pragma unroll
     for (int j = 0; j < 10; j++) {
-        T0[j] = as_u32((as_u16x2(Q01[j]) + as_u16x2(Q23[j])) * k3 + as_u16x2(Q12[j]) * k10);
-        T1[j] = as_u32(as_u16x2(Q23[j]) - as_u16x2(Q01[j]));
+        T0[j] = as_u32((as_u16x2(Q01[j]) + as_u16x2(Q23[j])) * k12 + as_u16x2(Q12[j]) * k40);       // 4 t0
+        T1[j] = as_u32(as_u16x2(Q23[j]) - as_u16x2(Q01[j]));                                          // t1
     }
     // horizontal passes: derivative column c = 0..7 (image column ipx+seg*7+c) from tile columns c..c+2
     uint32_t DX[8], DY[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        DX[c] = as_u32(as_u16x2(T0[c + 2]) - as_u16x2(T0[c]));
-        DY[c] = as_u32((as_u16x2(T1[c]) + as_u16x2(T1[c + 2])) * k3 + as_u16x2(T1[c + 1]) * k10);
+        DX[c] = as_u32(as_u16x2(T0[c + 2]) - as_u16x2(T0[c]));                                        // 4 dx
+        DY[c] = as_u32((as_u16x2(T1[c]) + as_u16x2(T1[c + 2])) * k12 + as_u16x2(T1[c + 1]) * k40);    // 4 dy
     }
     // the derivative image's border is BORDER_CONSTANT 0: mask positions outside the image
     // (only possible when the window hangs over the edge: the EDGE instantiation)
@@ -197,21 +200,21 @@ __device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane 
             DX[c] &= mk; DY[c] &= mk;
         }
     }
-    int iv[8], ix[8], iy[8];
+    int iv[8], ix[8], iy[8];                                    // ix, iy: value << 16 | rounding residue
     iv[7] = ix[7] = iy[7] = 0;
 #pragma unroll
     for (int k = 0; k < 7; k++) {
         iv[k] = dot2(Q12[k + 2], Wb, dot2_k(Q12[k + 1], Wa, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-        ix[k] = dot2(DX[k + 1], Wb, dot2_k(DX[k], Wa, 1 << (W_BITS - 1))) >> W_BITS;
-        iy[k] = dot2(DY[k + 1], Wb, dot2_k(DY[k], Wa, 1 << (W_BITS - 1))) >> W_BITS;
+        ix[k] = dot2(DX[k + 1], Wb, dot2_k(DX[k], Wa, 1 << (W_BITS + 1)));
+        iy[k] = dot2(DY[k + 1], Wb, dot2_k(DY[k], Wa, 1 << (W_BITS + 1)));
     }
     pA11 = 0; pA12 = 0; pA22 = 0;
     int sIIx = 0, sIIy = 0;
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         IvP[m] = perm_b32((uint32_t)iv[2 * m + 1], (uint32_t)iv[2 * m], 0x05040100u);
-        IxP[m] = perm_b32((uint32_t)ix[2 * m + 1], (uint32_t)ix[2 * m], 0x05040100u);
-        IyP[m] = perm_b32((uint32_t)iy[2 * m + 1], (uint32_t)iy[2 * m], 0x05040100u);
+        IxP[m] = perm_b32((uint32_t)ix[2 * m + 1], (uint32_t)ix[2 * m], 0x07060302u);      // the two high halves
+        IyP[m] = perm_b32((uint32_t)iy[2 * m + 1], (uint32_t)iy[2 * m], 0x07060302u);
         pA11 = dot2(IxP[m], IxP[m], pA11);
         pA12 = dot2(IxP[m], IyP[m], pA12);
         pA22 = dot2(IyP[m], IyP[m], pA22);
