@@ -50,18 +50,9 @@ __device__ __forceinline__ bool has_arc9(unsigned m16)
 //   quick : every position -- any 9-arc of the 16-circle contains at least one pixel of each
 //           opposite pair (k, k+8), so a pixel whose pairs (0,8) and (4,12) cannot both be
 //           "brighter" or both be "darker" is rejected after 4 loads (cv::FAST's high-speed test);
+//           four pixels per thread in packed 16-bit arithmetic, see the kernel;
 //   arc   : survivors of quick -- the full 16-pixel contiguous-arc test;
 //   score : corners only -- cornerScore<16>.
-__device__ __forceinline__ bool fast_quick(const uint8_t *c, int thr)
-{
-    constexpr int P = kRawW;
-    const int v = c[0];
-    const int d0 = v - c[3 * P], d8 = v - c[-3 * P], d4 = v - c[3], d12 = v - c[-3];
-    const bool dk = (d0 > thr || d8 > thr) && (d4 > thr || d12 > thr);
-    const bool br = (d0 < -thr || d8 < -thr) && (d4 < -thr || d12 < -thr);
-    return dk || br;
-}
-
 __device__ __forceinline__ bool fast_arc(const uint8_t *c, int thr)
 {
     int d[16];
@@ -150,16 +141,61 @@ __global__ __launch_bounds__(256) void fast_score_kernel(FastArgs a)
     for (int i = tid; i < (int)sizeof(sc) / 4; i += 256) ((uint32_t *)sc)[i] = 0;
     __syncthreads();
 
-    // quick test over the tile and its 1-pixel ring (the NMS neighbours)
-    for (int i0 = 0; i0 < kScH * kScW; i0 += 256) {
-        const int i = i0 + tid;
-        const bool in = i < kScH * kScW;
-        const int ii = in ? i : 0;
-        const int sy = ii / kScW, sx = ii - sy * kScW;
-        const int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
-        const bool valid = in && gx >= 3 && gx < a.w - 3 && gy >= 3 && gy < a.h - 3;
-        const bool alive = valid && fast_quick(&raw[(sy + kHalo - 1) * kRawW + sx + kHalo - 1], a.thr);
-        list_push(alive, ii, cand, &n_cand);
+    // quick test over the tile and its 1-pixel ring (the NMS neighbours), FOUR pixels per thread: one
+    // aligned LDS dword of raw row ry and its neighbours three rows up / down and three columns left /
+    // right (five dword reads instead of twenty byte reads), packed 16-bit arithmetic on the even and the
+    // odd bytes:   alive <=> max( min(v - min(p0,p8), v - min(p4,p12)),  min(max(p0,p8) - v, max(p4,p12) - v) ) > thr
+    {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        constexpr int RD = kRawW / 4;                          // 18 dwords per raw row
+        const uint32_t *rawd = (const uint32_t *)raw;
+        const s16x2 T1 = {(short)(a.thr + 1), (short)(a.thr + 1)};
+        for (int i0 = 0; i0 < kScH * RD; i0 += 256) {
+            const int i = i0 + tid;
+            uint32_t m4 = 0;
+            int sy = 0, sxb = 0;
+            if (i < kScH * RD) {
+                sy = i / RD;
+                const int gq = i - sy * RD;
+                sxb = 4 * gq - (kHalo - 1);                    // score-map x of the dword's first byte
+                const uint32_t *r = rawd + (sy + kHalo - 1) * RD + gq;
+                const uint32_t C = r[0], U = r[-3 * RD], D = r[3 * RD], Lf = gq > 0 ? r[-1] : 0u, Rt = gq < RD - 1 ? r[1] : 0u;
+                const uint32_t Lv = __builtin_amdgcn_alignbyte(C, Lf, 1);    // x - 3 neighbours of the four pixels
+                const uint32_t Rv = __builtin_amdgcn_alignbyte(Rt, C, 3);    // x + 3 neighbours
+                uint32_t sgn[2];
+#pragma unroll
+                for (int hb = 0; hb < 2; hb++) {                          // even bytes (pixels 0, 2), odd bytes (1, 3)
+                    auto half = [&](uint32_t w) { return __builtin_bit_cast(s16x2, (hb ? w >> 8 : w) & 0x00FF00FFu); };
+                    const s16x2 v = half(C), u = half(U), d = half(D), l = half(Lv), rr = half(Rv);
+                    const s16x2 mnA = __builtin_elementwise_min(u, d), mxA = __builtin_elementwise_max(u, d);
+                    const s16x2 mnB = __builtin_elementwise_min(l, rr), mxB = __builtin_elementwise_max(l, rr);
+                    const s16x2 dark = __builtin_elementwise_min(v - mnA, v - mnB);
+                    const s16x2 bright = __builtin_elementwise_min(mxA - v, mxB - v);
+                    sgn[hb] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(dark, bright) - T1);   // sign set <=> rejected
+                }
+                const uint32_t dead = ((sgn[0] >> 15) & 1u) | ((sgn[1] >> 14) & 2u) | ((sgn[0] >> 29) & 4u) | ((sgn[1] >> 28) & 8u);
+                // positions inside the score map [0, 66) and inside the image's testable area [3, w-3) x [3, h-3)
+                const int gy = y0 - 1 + sy, gxb = x0 - 1 + sxb;
+                const int lo = max(max(0, -sxb), 3 - gxb), hi = min(min(4, kScW - sxb), a.w - 3 - gxb);
+                const uint32_t inside = (hi > lo && gy >= 3 && gy < a.h - 3) ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+                m4 = ~dead & inside;
+            }
+            // survivors -> list (any order): one LDS atomic per wave and step
+            const int lane = threadIdx.x;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const unsigned long long b0 = __ballot(m4 & 1u), b1 = __ballot(m4 & 2u), b2 = __ballot(m4 & 4u), b3 = __ballot(m4 & 8u);
+            const int c0 = __popcll(b0), c1 = __popcll(b1), c2 = __popcll(b2), c3 = __popcll(b3);
+            if (c0 + c1 + c2 + c3) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&n_cand, c0 + c1 + c2 + c3);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int pos = sy * kScW + sxb;
+                if (m4 & 1u) cand[base + __popcll(b0 & lt)] = (uint16_t)pos;
+                if (m4 & 2u) cand[base + c0 + __popcll(b1 & lt)] = (uint16_t)(pos + 1);
+                if (m4 & 4u) cand[base + c0 + c1 + __popcll(b2 & lt)] = (uint16_t)(pos + 2);
+                if (m4 & 8u) cand[base + c0 + c1 + c2 + __popcll(b3 & lt)] = (uint16_t)(pos + 3);
+            }
+        }
     }
     __syncthreads();
     const int nc = n_cand;
