@@ -120,6 +120,91 @@ __device__ inline void jacobi_svd_d(double *At, int as, double *W, double *Vt, i
     }
 }
 
+// The right-singular vector of the SMALLEST singular value of a 4x4 matrix (cv::SVD::compute +
+// "last row of V^T", what cv::triangulatePoints needs) with everything in registers.  Same rotation
+// sequence, same expressions and the same selection sort as jacobi_svd_d<4, 4> -- so the same bits
+// -- but the pair loops are fully unrolled and the sort moves (value, row index) pairs instead of
+// rows, so no array is ever indexed with a run-time value: the generic routine's row swaps forced
+// At / Vt into scratch memory, and every rotation then paid a memory round trip (0.37 ms per 256 ORB
+// pairs for a few hundred points each).  At: the transposed input (row i = column i of A).
+__device__ inline void jacobi_null4_d(double (&At)[16], double (&X)[4])
+{
+    const double eps = SVO_DBL_EPS * 10;
+    double W[4], Vt[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sd += At[i * 4 + k] * At[i * 4 + k];
+        W[i] = sd;
+#pragma unroll
+        for (int k = 0; k < 4; k++) Vt[i * 4 + k] = (i == k) ? 1.0 : 0.0;
+    }
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = i + 1; j < 4; j++) {
+                double a = W[i], p = 0, b = W[j], c, s;
+#pragma unroll
+                for (int k = 0; k < 4; k++) p += At[i * 4 + k] * At[j * 4 + k];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = sqrt(p * p + beta * beta);
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const double x = At[i * 4 + k], y = At[j * 4 + k];
+                    const double t0 = c * x + s * y, t1 = -s * x + c * y;
+                    At[i * 4 + k] = t0; At[j * 4 + k] = t1;
+                    a += t0 * t0; b += t1 * t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = true;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const double x = Vt[i * 4 + k], y = Vt[j * 4 + k];
+                    Vt[i * 4 + k] = c * x + s * y; Vt[j * 4 + k] = -s * x + c * y;
+                }
+            }
+        if (!changed) break;
+    }
+    int row[4] = {0, 1, 2, 3};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sd += At[i * 4 + k] * At[i * 4 + k];
+        W[i] = sqrt(sd);
+    }
+    // selection sort, descending ("j = i; for k > i: if (W[j] < W[k]) j = k; swap(i, j)") on (W, row)
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double best = W[i];
+        int bj = i;
+#pragma unroll
+        for (int k = i + 1; k < 4; k++) if (best < W[k]) { best = W[k]; bj = k; }
+#pragma unroll
+        for (int k = i + 1; k < 4; k++)
+            if (bj == k) {
+                const double tw = W[i]; W[i] = W[k]; W[k] = tw;
+                const int tr = row[i]; row[i] = row[k]; row[k] = tr;
+            }
+    }
+    const int r = row[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) X[k] = r == 0 ? Vt[k] : r == 1 ? Vt[4 + k] : r == 2 ? Vt[8 + k] : Vt[12 + k];
+}
+
 // cv::solve(A, b, x, DECOMP_SVD), A m x n row-major (m >= n, n <= 6, m <= 6), one right-hand side.
 // ws: workspace of >= 72 elements with element stride st (the lane-interleaved LDS image when the
 // caller has one: private arrays with run-time indexing live in scratch memory, which is what

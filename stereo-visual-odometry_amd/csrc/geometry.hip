@@ -38,18 +38,19 @@ __global__ __launch_bounds__(64) void triangulate_kernel(TriArgs a)
         const int64_t o = (int64_t)b * a.stride + i;
         const float2 p1 = a.x1[o], p2 = a.x2[o];
         const double xs[2] = {(double)p1.x, (double)p2.x}, ys[2] = {(double)p1.y, (double)p2.y};
-        double A[16], At[16], W[4], Vt[16];
+        double At[16], V4[4];
+#pragma unroll
         for (int j = 0; j < 2; j++) {
             const double *P = j == 0 ? a.P1 : a.P2;
-            for (int k = 0; k < 4; k++) {
-                A[(j * 2 + 0) * 4 + k] = xs[j] * P[8 + k] - P[k];
-                A[(j * 2 + 1) * 4 + k] = ys[j] * P[8 + k] - P[4 + k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {                   // A row (2j) and (2j + 1), stored transposed
+                At[k * 4 + 2 * j] = xs[j] * P[8 + k] - P[k];
+                At[k * 4 + 2 * j + 1] = ys[j] * P[8 + k] - P[4 + k];
             }
         }
-        for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) At[k * 4 + j] = A[j * 4 + k];
-        jacobi_svd_d<4, 4>(At, 1, W, Vt, 1, false);
+        jacobi_null4_d(At, V4);
         // 4 x N CV_32F homogeneous result, then convertPointsFromHomogeneous in float
-        const float X = (float)Vt[12], Y = (float)Vt[13], Z = (float)Vt[14], Wh = (float)Vt[15];
+        const float X = (float)V4[0], Y = (float)V4[1], Z = (float)V4[2], Wh = (float)V4[3];
         const float scale = Wh != 0.f ? 1.f / Wh : 1.f;
         a.out3[o * 3 + 0] = X * scale; a.out3[o * 3 + 1] = Y * scale; a.out3[o * 3 + 2] = Z * scale;
     }
