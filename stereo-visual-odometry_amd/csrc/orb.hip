@@ -853,12 +853,20 @@ struct OrbDescArgs {
     int *overflow;                                                   // per image
 };
 
-// one wave per keypoint: lanes 0..31 compute one descriptor byte each; the angle is computed by
-// the whole wave (749 patch pixels reduced with exact integer sums)
+// TWO keypoints per wave (one per 32-lane half): the orientation sums use 31 lanes and the
+// descriptor 32, so with one keypoint per wave half of every instruction in those phases -- and
+// all of the per-keypoint scalar work (level search, fastAtan2, the f64 sincos, the record) -- was
+// issued for idle lanes; the kernel is VALU bound (80 % of the issue roof).  The 749 patch pixels
+// are reduced with exact integer sums.
+__device__ __forceinline__ int half_sum_i32(int v)               // sum over the 32 lanes of this half-wave
+{
+    v = row_allsum_i32(v);
+    return v + __shfl_xor(v, 16, 64);
+}
 __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
 {
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int gidx = blockIdx.x * 4 + (threadIdx.x >> 6);            // keypoint index in the image's output
+    const int b = blockIdx.y, lane = threadIdx.x & 63, half = lane >> 5, sl = lane & 31;
+    const int gidx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;   // keypoint index in the image's output
     // locate level: prefix over the per-level selected counts
     int l = 0, base = 0, total = 0;
     for (int q = 0; q < a.g.nlevels; q++) total += a.sel_cnt[b * a.g.nlevels + q];
@@ -866,27 +874,30 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
         a.n_out[b] = min(total, a.out_cap);
         if (total > a.out_cap) atomicOr(a.overflow + b, 4);          // more keypoints than max_keypoints
     }
-    if (gidx >= total || gidx >= a.out_cap) return;
-    for (l = 0; l < a.g.nlevels; l++) {
+    const bool valid = gidx < total && gidx < a.out_cap;
+    if (__ballot(valid) == 0ull) return;
+    const int gq = valid ? gidx : 0;                                  // an idle half shadows keypoint 0, stores nothing
+    for (l = 0; l < a.g.nlevels - 1; l++) {
         const int c = a.sel_cnt[b * a.g.nlevels + l];
-        if (gidx < base + c) break;
+        if (gq < base + c) break;
         base += c;
     }
     const int inst = b * a.g.nlevels + l;
-    const float4 cand = a.lvl_cand[(int64_t)inst * a.cand_cap + a.sel[(int64_t)inst * a.sel_cap + (gidx - base)]];
+    const float4 cand = a.lvl_cand[(int64_t)inst * a.cand_cap + a.sel[(int64_t)inst * a.sel_cap + (gq - base)]];
     const float x = cand.x + 16.f, y = cand.y + 16.f;                // += minBorderX / minBorderY
     const int ix = __float2int_rn(x), iy = __float2int_rn(y);
     const int pitch = a.g.pitch[l], w = a.g.w[l];
     // Both gathers (749-pixel circular patch of the level, <= 39x39 footprint of the rotated pattern
-    // in the blurred level) go through LDS: the wave fetches the two windows as aligned dwords with
+    // in the blurred level) go through LDS: a half-wave fetches its two windows as aligned dwords with
     // all loads in flight at once, then reads single bytes from LDS.
-    __shared__ uint32_t s_raw[4][31 * 9], s_blr[4][39 * 11];
-    uint32_t *raw = s_raw[threadIdx.x >> 6], *blr = s_blr[threadIdx.x >> 6];
+    __shared__ uint32_t s_raw[8][31 * 9], s_blr[8][39 * 11];
+    const int hw = (threadIdx.x >> 6) * 2 + half;
+    uint32_t *raw = s_raw[hw], *blr = s_blr[hw];
     const uint8_t *lvl = a.slots + (int64_t)b * a.slot_stride + a.g.origin[l];     // 4-byte aligned rows
     const int rx0 = (ix - 15) & ~3, roff = (ix - 15) - rx0;
 #pragma unroll
-    for (int t = 0; t < 5; t++) {
-        const int i = lane + 64 * t;
+    for (int t = 0; t < 9; t++) {
+        const int i = sl + 32 * t;
         if (i < 31 * 9) {
             const int r = i / 9, c = i - r * 9;
             raw[i] = *(const uint32_t *)(lvl + (int64_t)(iy - 15 + r) * pitch + rx0 + 4 * c);
@@ -896,8 +907,8 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     const int64_t bsize = (int64_t)w * a.g.h[l];
     // rows of the tight blurred image are not aligned: align each row's start down, keep its offset
 #pragma unroll
-    for (int t = 0; t < 7; t++) {
-        const int i = lane + 64 * t;
+    for (int t = 0; t < 14; t++) {
+        const int i = sl + 32 * t;
         if (i < 39 * 11) {
             const int r = i / 11, c = i - r * 11;
             const int64_t o = (int64_t)(iy - 19 + r) * w + (ix - 19);        // byte offset of the row's first pixel
@@ -911,9 +922,9 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     wave_lds_fence();
     // IC_Angle: m10 = sum u * I, m01 = sum v * I over the circular patch (rows v = -15..15)
     int m10 = 0, m01 = 0;
-    if (lane < 31) {
-        const int v = lane - 15, d = a.g.umax[v < 0 ? -v : v];
-        const uint8_t *row = (const uint8_t *)(raw + lane * 9) + roff + 15;
+    if (sl < 31) {
+        const int v = sl - 15, d = a.g.umax[v < 0 ? -v : v];
+        const uint8_t *row = (const uint8_t *)(raw + sl * 9) + roff + 15;
         int s = 0, su = 0;
 #pragma unroll
         for (int u = -15; u <= 15; ++u) {
@@ -922,7 +933,7 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
         }
         m10 = su; m01 = v * s;
     }
-    m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
+    m10 = half_sum_i32(m10); m01 = half_sum_i32(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // computeOrbDescriptor on the blurred level
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
@@ -930,8 +941,8 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     double sd, cd;                                 // one shared argument reduction for both
     sincos((double)ang, &sd, &cd);
     const float ca = (float)cd, sb = (float)sd;
-    if (lane < 32) {
-        const signed char *pat = c_pattern + lane * 32;
+    {
+        const signed char *pat = c_pattern + sl * 32;
         const int balign = (int)((uintptr_t)bimg & 3);
         auto sample = [&](int dyy, int dxx) -> int {
             const int64_t o = (int64_t)(iy + dyy) * w + (ix - 19);            // row start in the tight image
@@ -946,9 +957,9 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
             const int t1 = sample(__float2int_rn(xb * sb + yb * ca), __float2int_rn(xb * ca - yb * sb));
             val |= (t0 < t1) << k;
         }
-        a.desc[((int64_t)b * a.out_cap + gidx) * 32 + lane] = (uint8_t)val;
+        if (valid) a.desc[((int64_t)b * a.out_cap + gidx) * 32 + sl] = (uint8_t)val;
     }
-    if (lane == 0) {
+    if (sl == 0 && valid) {
         svo_keypoint kp;
         const float sc = a.g.scale[l];
         kp.x = l != 0 ? x * sc : x; kp.y = l != 0 ? y * sc : y;
@@ -1324,7 +1335,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     int max_kp = 0;
     for (int l = 0; l < L; l++) max_kp += g.quota[l] + 8;
     if (max_kp > ctx->orb_kp_cap) max_kp = ctx->orb_kp_cap;
-    hipLaunchKernelGGL(orb_describe_kernel, dim3((max_kp + 3) / 4, n_img), blk, 0, st, e);
+    hipLaunchKernelGGL(orb_describe_kernel, dim3((max_kp + 7) / 8, n_img), blk, 0, st, e);      // two keypoints per wave
     timing_mark(ctx, "orb_describe");
     return SVO_OK;
 }
