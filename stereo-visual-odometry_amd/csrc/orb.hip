@@ -67,49 +67,67 @@ __global__ __launch_bounds__(256) void orb_border_kernel(OrbGeom g, uint8_t *slo
 // The per-column (sx, alpha) and per-row (sy0, sy1, beta) tables are built once on the host
 // (orb_make_tables: upstream builds the same tables per call), so a thread is four byte loads and
 // the 11-bit fixed-point blend; four output pixels per thread, one dword store.
-constexpr int kResizeDw = 520;               // source dwords staged per row: 1024 output pixels at scale <= 2
+constexpr int kResizeRows = 6;               // output rows per workgroup
+// A workgroup produces a 1024-pixel-wide strip of kResizeRows output rows: the source rows they
+// sample (kResizeRows * scale + 2 of them) are staged ONCE as aligned dwords (the byte gathers of a
+// 1.2x resample would otherwise be 16 scattered loads per thread and row), a thread keeps its four
+// columns' table entries in registers for all rows.  One row per workgroup (the first version) was
+// bound by workgroup turnaround: 1.4 M short workgroups per 256 pairs, each load -> barrier -> blend.
+// The LDS image is sized for THIS level's scale (11 KB at 1.2): in overlap mode the previous batch's
+// EPnP workgroups hold 147 of a CU's 160 KB, and a resize workgroup has to fit beside them.
 __global__ __launch_bounds__(256) void orb_resize_kernel(OrbGeom g, uint8_t *slots, int64_t slot_stride, int l,
-                                                         const int2 *xtab, const int4 *ytab)
+                                                         const int2 *xtab, const int4 *ytab, int src_rows_cap, int kResizeDw)
 {
-    __shared__ uint32_t rows[2][kResizeDw];
-    const int b = blockIdx.z, dy = blockIdx.y, tid = threadIdx.x;
-    const int dw = g.w[l], sp = g.pitch[l - 1];
+    extern __shared__ __attribute__((aligned(16))) uint32_t rs_rows[];       // src_rows_cap x kResizeDw
+    const int b = blockIdx.z, tid = threadIdx.x;
+    const int dw = g.w[l], dh = g.h[l], sp = g.pitch[l - 1];
+    const int dy0 = blockIdx.y * kResizeRows, dy1 = min(dy0 + kResizeRows, dh);
     const int dx_first = blockIdx.x * 1024, dx_last = min(dx_first + 1023, dw - 1);
     uint8_t *slot = slots + (int64_t)b * slot_stride;
     const uint8_t *src = slot + g.origin[l - 1];
-    const int4 yt = ytab[g.ytab_off[l] + dy];                  // y0, y1, b0, b1
-    const uint8_t *S0 = src + (int64_t)yt.x * sp, *S1 = src + (int64_t)yt.y * sp;
     const int2 *xt = xtab + g.xtab_off[l];
-    // the two source row segments this block samples, as aligned dwords (the byte gathers of a
-    // 1.2x resample would otherwise be 16 scattered loads per thread)
+    const int4 *yt = ytab + g.ytab_off[l];
+    // source rows [sy_first, sy_last] (the table's rows are monotone), columns [s0, s0 + 4 ndw)
+    const int sy_first = yt[dy0].x, sy_last = yt[dy1 - 1].y;
+    const int nsrc = sy_last - sy_first + 1;
     const int s0 = (xt[dx_first].x & 0xFFFF) & ~3;
     const int ndw = (((xt[dx_last].x >> 16) - s0) >> 2) + 1;
-    const bool staged = ndw <= kResizeDw;
+    const bool staged = ndw <= kResizeDw && nsrc <= src_rows_cap;
     if (staged) {
-        for (int i = tid; i < ndw; i += 256) {
-            rows[0][i] = *(const uint32_t *)(S0 + s0 + 4 * i);
-            rows[1][i] = *(const uint32_t *)(S1 + s0 + 4 * i);
+        const float inv_ndw = 1.0f / (float)ndw;
+        for (int i = tid; i < nsrc * ndw; i += 256) {
+            const int r = (int)(((float)i + 0.5f) * inv_ndw), c = i - r * ndw;
+            rs_rows[r * kResizeDw + c] = *(const uint32_t *)(src + (int64_t)(sy_first + r) * sp + s0 + 4 * c);
         }
         __syncthreads();
     }
     const int dx0 = dx_first + tid * 4;
     if (dx0 >= dw) return;
-    uint32_t out = 0;
-    auto blend = [&](const auto *R0, const auto *R1, int base) {
+    int sx[4], sx1[4], a0[4], a1[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (dx0 + q >= dw) break;
-            const int2 t = xt[dx0 + q];                         // sx | sx1 << 16, a0 | a1 << 16
-            const int sx = (t.x & 0xFFFF) - base, sx1 = (t.x >> 16) - base, a0 = (short)(t.y & 0xFFFF), a1 = t.y >> 16;
-            const int r0 = R0[sx] * a0 + R0[sx1] * a1, r1 = R1[sx] * a0 + R1[sx1] * a1;
-            out |= (uint32_t)((((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2) << (8 * q);
-        }
-    };
-    if (staged) blend((const uint8_t *)rows[0], (const uint8_t *)rows[1], s0);
-    else blend(S0, S1, 0);
-    uint8_t *d = slot + g.origin[l] + (int64_t)dy * g.pitch[l] + dx0;       // origin and pitch are 4-byte aligned
-    if (dx0 + 4 <= dw) *(uint32_t *)d = out;
-    else for (int q = 0; dx0 + q < dw; q++) d[q] = (uint8_t)(out >> (8 * q));
+    for (int q = 0; q < 4; q++) {
+        const int2 t = xt[min(dx0 + q, dw - 1)];                    // sx | sx1 << 16, a0 | a1 << 16
+        sx[q] = t.x & 0xFFFF; sx1[q] = t.x >> 16; a0[q] = (short)(t.y & 0xFFFF); a1[q] = t.y >> 16;
+    }
+    for (int dy = dy0; dy < dy1; dy++) {
+        const int4 ty = yt[dy];                                     // y0, y1, b0, b1
+        uint32_t out = 0;
+        auto blend = [&](const auto *R0, const auto *R1, int base) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int r0 = R0[sx[q] - base] * a0[q] + R0[sx1[q] - base] * a1[q];
+                const int r1 = R1[sx[q] - base] * a0[q] + R1[sx1[q] - base] * a1[q];
+                out |= (uint32_t)((((ty.z * (r0 >> 4)) >> 16) + ((ty.w * (r1 >> 4)) >> 16) + 2) >> 2) << (8 * q);
+            }
+        };
+        if (staged)
+            blend((const uint8_t *)(rs_rows + (ty.x - sy_first) * kResizeDw), (const uint8_t *)(rs_rows + (ty.y - sy_first) * kResizeDw), s0);
+        else
+            blend(src + (int64_t)ty.x * sp, src + (int64_t)ty.y * sp, 0);
+        uint8_t *d = slot + g.origin[l] + (int64_t)dy * g.pitch[l] + dx0;       // origin and pitch are 4-byte aligned
+        if (dx0 + 4 <= dw) *(uint32_t *)d = out;
+        else for (int q = 0; dx0 + q < dw; q++) d[q] = (uint8_t)(out >> (8 * q));
+    }
 }
 
 // ---- per-cell FAST ---------------------------------------------------------------------------
@@ -1293,9 +1311,16 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
                            slots, g.slot_bytes);
     }
     for (int l = 0; l < L; l++) {
-        if (l > 0)
-            hipLaunchKernelGGL(orb_resize_kernel, dim3((g.w[l] + 1023) / 1024, g.h[l], n_img), blk, 0, st, g, slots, g.slot_bytes, l,
-                               (const int2 *)ctx->orb_xtab, (const int4 *)ctx->orb_ytab);
+        if (l > 0) {
+            // source rows a strip of kResizeRows output rows can touch (+3: second tap, rounding), and the
+            // dwords 1024 output columns can span (+3: second tap, alignment slack)
+            int cap_rows = (int)((double)kResizeRows * g.h[l - 1] / g.h[l]) + 3;
+            int row_dw = (int)(1024.0 * g.w[l - 1] / g.w[l] / 4.0) + 3;
+            if ((size_t)cap_rows * row_dw * 4 > 60 * 1024) cap_rows = 60 * 1024 / (row_dw * 4);     // beyond it: the unstaged path
+            hipLaunchKernelGGL(orb_resize_kernel, dim3((g.w[l] + 1023) / 1024, (g.h[l] + kResizeRows - 1) / kResizeRows, n_img), blk,
+                               (size_t)cap_rows * row_dw * 4, st, g, slots, g.slot_bytes, l,
+                               (const int2 *)ctx->orb_xtab, (const int4 *)ctx->orb_ytab, cap_rows, row_dw);
+        }
         hipLaunchKernelGGL(orb_border_kernel, dim3(2 * kPad + (g.h[l] + 3) / 4, n_img), blk, 0, st, g, slots, g.slot_bytes, l);
     }
     // the blurred levels only depend on the pyramid: computed here, before the LDS-hungry kernels,
