@@ -44,11 +44,16 @@
 namespace svo {
 
 constexpr int kSlots = 4;                                 // points per wave
-constexpr int kTileIDw = 8;                               // I tile: 24 rows x 32 bytes (28 used)
+// I tile: 24 rows x 28 bytes of the level, staged as ROW-PAIR COLUMN WORDS: Q[p][c] = byte c of tile
+// row p | byte c of row p + 1 << 16 (23 pairs x 28 columns, one dword each).  The patch build wants
+// exactly these words for the row pairs (r, r+1), (r+1, r+2), (r+2, r+3) of every lane's 10 columns;
+// formed while staging (4 v_perm per staged dword pair, 12 per lane) they replace the 30 v_perm +
+// 12 v_alignbyte every lane spent on its own copy, and the lane's reads become plain dword reads.
+constexpr int kQPairs = 23, kQCols = 28, kQTileDw = kQPairs * kQCols;   // 644 dwords per slot; two slots at a time
 constexpr int kTileJRows = 32, kTileJDw = 10;             // 32 rows x 40 bytes
 constexpr int kSlotDw = kTileJRows * kTileJDw;            // 320 dwords: the I tile (192) and the J tile
                                                           // of a slot alias (I is dead once the patch is in VGPRs)
-constexpr int kLdsDwPerWave = kSlots * kSlotDw;           // 1280 dwords = 5 KB
+constexpr int kLdsDwPerWave = 2 * kQTileDw > kSlots * kSlotDw ? 2 * kQTileDw : kSlots * kSlotDw;   // 1288 dwords
 constexpr int W_BITS = 14;
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -106,27 +111,6 @@ __device__ __forceinline__ PackedWeights bilinear_weights(float a, float b)
     return w;
 }
 
-// 12 aligned bytes starting at byte offset `off` of an LDS row of dwords: bytes 0-3, 4-7, 8-11
-// (aligned dword reads + v_alignbyte: unaligned ds_read_b64 measured 15 % slower end to end)
-__device__ __forceinline__ void load12(const uint32_t *row, int off, uint32_t &lo, uint32_t &mid, uint32_t &hi)
-{
-    const uint32_t *p = row + (off >> 2);
-    uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
-    int sh = off & 3;
-    lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    mid = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    hi = __builtin_amdgcn_alignbyte(d3, d2, sh);
-}
-// 8 aligned bytes
-__device__ __forceinline__ void load8(const uint32_t *row, int off, uint32_t &lo, uint32_t &hi)
-{
-    const uint32_t *p = row + (off >> 2);
-    uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-    int sh = off & 3;
-    lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
-}
-
 // "ix < -win || ix >= w || iy < -win || iy >= h" with two unsigned compares
 __device__ __forceinline__ bool window_oob(int ix, int iy, int w, int h)
 {
@@ -159,16 +143,11 @@ __device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane 
     uint32_t IvP[4];
     // (lane 63 carries no window pixel: zero weights make its I, Ix, Iy and sums vanish)
     const uint32_t Wa = pl.on ? Wau : 0u, Wb = pl.on ? Wbu : 0u;
-    uint32_t R[4][3];
-#pragma unroll
-    for (int r = 0; r < 4; r++) load12(tileI + (pl.row + r) * kTileIDw, offI + pl.seg * 7, R[r][0], R[r][1], R[r][2]);
     uint32_t Q01[10], Q12[10], Q23[10];
+    {
+        const uint32_t *q0 = tileI + pl.row * kQCols + offI + pl.seg * 7;
 #pragma unroll
-    for (int j = 0; j < 10; j++) {
-        const uint32_t sel = 0x0c040c00u + 0x00010001u * (j & 3);
-        Q01[j] = perm_b32(R[1][j >> 2], R[0][j >> 2], sel);
-        Q12[j] = perm_b32(R[2][j >> 2], R[1][j >> 2], sel);
-        Q23[j] = perm_b32(R[3][j >> 2], R[2][j >> 2], sel);
+        for (int j = 0; j < 10; j++) { Q01[j] = q0[j]; Q12[j] = q0[kQCols + j]; Q23[j] = q0[2 * kQCols + j]; }
     }
     // vertical Scharr passes, rows A | B packed.  Both passes carry a factor 4 (coefficients 12 / 40
     // instead of 3 / 10; |4 d| <= 16320 still fits 16 bits): the interpolated derivative
@@ -295,6 +274,12 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
     int nIIx[kSlots], nIIy[kSlots];
     // lane part of the J sample offset, the wave's LDS region included (bytes from the workgroup array)
     const int lane_off = pl.row * (kTileJDw * 4) + pl.seg * 7 + wave_off;
+    int q_pr[3], q_dc4[3], q_dst[3];             // staging item lane + 64 t = row pair * 7 + dword column
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int i = lane + 64 * t;
+        q_pr[t] = i / 7; q_dc4[t] = 4 * (i - q_pr[t] * 7); q_dst[t] = q_pr[t] * kQCols + q_dc4[t];
+    }
     int vround = 1 << (W_BITS - 5 - 1);
     asm volatile("" : "+v"(vround));                          // keep it in a VGPR (see mismatch_slot)
     status = 1;
@@ -318,39 +303,52 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
         const int x0 = (ipx - 1) & ~3;
         const int offI = (ipx - 1) - x0;
 
-        // ---- gather the 24x24 I tile of every active slot
+        // ---- I tiles (as row-pair column words) and patches + A sums, two slots at a time (two Q tiles
+        //      fill the wave's LDS region, which the four J tiles take over afterwards)
         const unsigned long long m_on = __ballot(lvl_on);
-#pragma unroll
-        for (int s = 0; s < kSlots; s++) {
-            if (!((m_on >> (4 * s)) & 1ull)) continue;
-            const int x0s = __builtin_amdgcn_readlane(x0, 4 * s), ipys = __builtin_amdgcn_readlane(ipy, 4 * s);
-            uint32_t *tile = lds + s * kSlotDw;
-            const uint8_t *base = I + (int64_t)(ipys - 1) * pitch + x0s;
-#pragma unroll
-            for (int t = 0; t < 3; t++) {
-                const int i = lane + 64 * t, r = i >> 3, c = i & 7;
-                uint32_t v = 0;
-                if (c < 7) v = *(const uint32_t *)(base + (int64_t)r * pitch + 4 * c);
-                tile[i] = v;
-            }
-        }
-        wave_lds_fence();
-
-        // ---- patches + A sums
         int pA[kSlots][3];
+        uint32_t q_src[3];                       // lane part of the I tile source offsets at this level
 #pragma unroll
-        for (int s = 0; s < kSlots; s++) {
-            pA[s][0] = pA[s][1] = pA[s][2] = 0;
-            if (!((m_on >> (4 * s)) & 1ull)) continue;
-            const int offIs = __builtin_amdgcn_readlane(offI, 4 * s);
-            const uint32_t W01s = __builtin_amdgcn_readlane(WIa, 4 * s), W23s = __builtin_amdgcn_readlane(WIb, 4 * s);
-            const int ipxs = __builtin_amdgcn_readlane(ipx, 4 * s), ipys = __builtin_amdgcn_readlane(ipy, 4 * s);
-            if (__builtin_expect(ipxs < 0 || ipxs + kWin >= w || ipys < 0 || ipys + kWin >= h, 0))
-                patch_slot<true>(lds + s * kSlotDw, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
-                                 pA[s][0], pA[s][1], pA[s][2]);
-            else
-                patch_slot<false>(lds + s * kSlotDw, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
-                                  pA[s][0], pA[s][1], pA[s][2]);
+        for (int t = 0; t < 3; t++) q_src[t] = (uint32_t)(q_pr[t] * pitch + q_dc4[t]);
+#pragma unroll
+        for (int grp = 0; grp < 2; grp++) {
+#pragma unroll
+            for (int s = 2 * grp; s < 2 * grp + 2; s++) {
+                if (!((m_on >> (4 * s)) & 1ull)) continue;
+                const int x0s = __builtin_amdgcn_readlane(x0, 4 * s), ipys = __builtin_amdgcn_readlane(ipy, 4 * s);
+                uint32_t *qt = lds + (s & 1) * kQTileDw;
+                // 32-bit offsets from the slot's (wave-uniform) base: scalar part per slot, lane part per level
+                const uint32_t s_off = (uint32_t)(g.origin[level] + (ipys - 1) * pitch + x0s);
+                const uint8_t *rowA = slotI, *rowB = slotI + pitch;
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    if (lane + 64 * t < kQPairs * 7) {
+                        const uint32_t o = s_off + q_src[t];
+                        const uint32_t top = *(const uint32_t *)(rowA + o), bot = *(const uint32_t *)(rowB + o);
+                        uint4 q;
+                        q.x = perm_b32(bot, top, 0x0c040c00u); q.y = perm_b32(bot, top, 0x0c050c01u);
+                        q.z = perm_b32(bot, top, 0x0c060c02u); q.w = perm_b32(bot, top, 0x0c070c03u);
+                        *(uint4 *)(qt + q_dst[t]) = q;
+                    }
+                }
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int s = 2 * grp; s < 2 * grp + 2; s++) {
+                pA[s][0] = pA[s][1] = pA[s][2] = 0;
+                if (!((m_on >> (4 * s)) & 1ull)) continue;
+                const int offIs = __builtin_amdgcn_readlane(offI, 4 * s);
+                const uint32_t W01s = __builtin_amdgcn_readlane(WIa, 4 * s), W23s = __builtin_amdgcn_readlane(WIb, 4 * s);
+                const int ipxs = __builtin_amdgcn_readlane(ipx, 4 * s), ipys = __builtin_amdgcn_readlane(ipy, 4 * s);
+                const uint32_t *qt = lds + (s & 1) * kQTileDw;
+                if (__builtin_expect(ipxs < 0 || ipxs + kWin >= w || ipys < 0 || ipys + kWin >= h, 0))
+                    patch_slot<true>(qt, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
+                                     pA[s][0], pA[s][1], pA[s][2]);
+                else
+                    patch_slot<false>(qt, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
+                                      pA[s][0], pA[s][1], pA[s][2]);
+            }
+            if (grp == 0) wave_lds_fence();          // the second pair's tiles overwrite the first pair's
         }
         wave_lds_fence();                        // the J tiles reuse the I tiles' LDS
         float A11, A12, A22, D;
