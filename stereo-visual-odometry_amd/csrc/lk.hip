@@ -9,7 +9,7 @@
 // more than half of a one-point-per-wave iteration is per-point SCALAR work (window position,
 // bilinear weights, 2x2 solve, convergence tests) that a wave executes as full vector
 // instructions.  Here that scalar work is done once for four points: lane l carries the control
-// state of slot (l >> 2) & 3, so one vector instruction advances all four points, while the pixel
+// state of slot l >> 4 (its row of 16 lanes), so one vector instruction advances all four points, while the pixel
 // work is done slot after slot by all 63 pixel lanes:
 //   * lane l owns window row l/3, columns (l%3)*7..+6 of EVERY slot (63 lanes x 7 px = 441 px);
 //   * per level, per slot: the 24x24 source tile of I is gathered into LDS with 4-byte aligned
@@ -50,14 +50,19 @@ constexpr int kSlots = 4;                                 // points per wave
 // formed while staging (4 v_perm per staged dword pair, 12 per lane) they replace the 30 v_perm +
 // 12 v_alignbyte every lane spent on its own copy, and the lane's reads become plain dword reads.
 constexpr int kQPairs = 23, kQCols = 28, kQTileDw = kQPairs * kQCols;   // 644 dwords per slot; two slots at a time
-constexpr int kTileJRows = 32, kTileJDw = 10;             // 32 rows x 40 bytes
-constexpr int kSlotDw = kTileJRows * kTileJDw;            // 320 dwords: the I tile (192) and the J tile
-                                                          // of a slot alias (I is dead once the patch is in VGPRs)
-constexpr int kLdsDwPerWave = 2 * kQTileDw > kSlots * kSlotDw ? 2 * kQTileDw : kSlots * kSlotDw;   // 1288 dwords
+// J tile: the same row-pair column words, 27 pairs x 28 columns around the window (3 spare on every side:
+// a window drifts that far at one level only rarely, and then the tile is staged again), stored
+// COLUMN-MAJOR with 29 words per column: lane (row, seg) reads column cx + 7 seg + k, pair cy + row, so
+// the banks of a 32-lane half are 7 * 29 * seg + row = 11 seg + row (mod 32) -- conflict-free; the
+// row-major order is 2-way conflicted for every stride below 53.
+constexpr int kJPairs = 27, kJCols = 28, kJColDw = 29, kJTileDw = kJCols * kJColDw;   // 812 dwords per slot
+constexpr int kJMargin = 3;
+constexpr int kLdsDwPerWave = 2 * kQTileDw > kSlots * kJTileDw ? 2 * kQTileDw : kSlots * kJTileDw;   // 3248 dwords
 constexpr int W_BITS = 14;
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 
 // cvFloor: one instruction (floor + convert; the compiler's __float2int_rd is v_floor_f32 + v_cvt_i32_f32,
 // and on gfx950 conversions issue at half the rate of plain 32-bit adds -- profiles/r02_valu_roof.txt)
@@ -223,26 +228,10 @@ __device__ __forceinline__ int dot2_sv(uint32_t a, uint32_t b_uniform, int c)   
 // (the slot part is one value broadcast from its control lane, the lane part a constant)
 // `vround` = 2^8 held in a VGPR: a VOP3P instruction can read ONE scalar operand, and that one is the
 // slot's weight (an SGPR from v_readlane); a scalar rounding constant cost a v_mov per slot and iteration
-__device__ __forceinline__ void mismatch_slot(const uint32_t *tile_base, int off, uint32_t Wa, uint32_t Wb,
+__device__ __forceinline__ void mismatch_slot(const uint32_t (&C)[8], uint32_t Wa, uint32_t Wb,
                                               const uint32_t (&IxP)[4], const uint32_t (&IyP)[4], int nIIx, int nIIy,
                                               int vround, int &pb1, int &pb2)
 {
-    // (ds_read_u8_d16 / _d16_hi straight into register halves would spare the perms, but with
-    //  SRAM-ECC on -- gfx950 -- a d16 load zeroes the other half instead of preserving it)
-    uint32_t a0, b0, a1, b1;                 // row 0 / row 1: bytes 0-3 (a), 4-7 (b)
-    {
-        const uint32_t *p = tile_base + (off >> 2);   // `off` already holds the slot's tile offset (a multiple of 4)
-        const int sh = off & 3;              // rows are 40 bytes apart: the same shift for both
-        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], e0 = p[kTileJDw], e1 = p[kTileJDw + 1], e2 = p[kTileJDw + 2];
-        a0 = __builtin_amdgcn_alignbyte(d1, d0, sh); b0 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        a1 = __builtin_amdgcn_alignbyte(e1, e0, sh); b1 = __builtin_amdgcn_alignbyte(e2, e1, sh);
-    }
-    uint32_t C[8];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        C[j] = perm_b32(a1, a0, 0x0c040c00u + 0x00010001u * j);
-        C[4 + j] = perm_b32(b1, b0, 0x0c040c00u + 0x00010001u * j);
-    }
     int d[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) d[k] = dot2(C[k + 1], Wb, dot2_sv(C[k], Wa, vround));
@@ -259,8 +248,35 @@ __device__ __forceinline__ void mismatch_slot(const uint32_t *tile_base, int off
     }
 }
 
+// A tile's source dwords for this lane: items lane + 64 t = (row pair, dword column), rows `rowA` (upper) and
+// `rowB` = rowA + pitch, at 32-bit offsets from the wave-uniform base (global_load with an SGPR base)
+__device__ __forceinline__ void tile_loads(uint32_t (&r)[3][2], const uint8_t *rowA, const uint8_t *rowB, uint32_t s_off,
+                                           const uint32_t (&q_src)[3], int lane, int n_items)
+{
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        if (lane + 64 * t < n_items) {
+            const uint32_t o = s_off + q_src[t];
+            r[t][0] = *(const u32_unaligned *)(rowA + o); r[t][1] = *(const u32_unaligned *)(rowB + o);
+        }
+    }
+}
+// ... and their four column words each into a column-major J tile
+__device__ __forceinline__ void tile_store_j(uint32_t *tile, const uint32_t (&r)[3][2], const int (&jq_dst)[3], int lane)
+{
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        if (lane + 64 * t < kJPairs * 7) {
+            const uint32_t top = r[t][0], bot = r[t][1];
+            uint32_t *d = tile + jq_dst[t];
+            d[0] = perm_b32(bot, top, 0x0c040c00u); d[kJColDw] = perm_b32(bot, top, 0x0c050c01u);
+            d[2 * kJColDw] = perm_b32(bot, top, 0x0c060c02u); d[3 * kJColDw] = perm_b32(bot, top, 0x0c070c03u);
+        }
+    }
+}
+
 // One cv::calcOpticalFlowPyrLK call for the wave's four points.  Control values (prevPt, outPt,
-// status, live) are per lane = per slot (lane >> 2) & 3.
+// status, live) are per lane = per slot lane >> 4.
 __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI, const uint8_t *slotJ, float2 prevPt,
                                          float2 &outPt, int &status, bool live, uint32_t *lds, const uint32_t *lds_wg,
                                          int wave_off, int lane)
@@ -273,21 +289,40 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
     uint32_t IxP[kSlots][4], IyP[kSlots][4];
     int nIIx[kSlots], nIIy[kSlots];
     // lane part of the J sample offset, the wave's LDS region included (bytes from the workgroup array)
-    const int lane_off = pl.row * (kTileJDw * 4) + pl.seg * 7 + wave_off;
-    int q_pr[3], q_dc4[3], q_dst[3];             // staging item lane + 64 t = row pair * 7 + dword column
+    const int lane_off = (pl.seg * 7 * kJColDw + pl.row) * 4 + wave_off;
+    int q_pr[3], q_dc4[3], q_dst[3], jq_dst[3];   // staging item lane + 64 t = row pair * 7 + dword column
 #pragma unroll
     for (int t = 0; t < 3; t++) {
         const int i = lane + 64 * t;
-        q_pr[t] = i / 7; q_dc4[t] = 4 * (i - q_pr[t] * 7); q_dst[t] = q_pr[t] * kQCols + q_dc4[t];
+        q_pr[t] = i / 7; q_dc4[t] = 4 * (i - q_pr[t] * 7); q_dst[t] = q_pr[t] * kQCols + q_dc4[t]; jq_dst[t] = q_dc4[t] * kJColDw + q_pr[t];
     }
     int vround = 1 << (W_BITS - 5 - 1);
     asm volatile("" : "+v"(vround));                          // keep it in a VGPR (see mismatch_slot)
     status = 1;
     float nx = 0.f, ny = 0.f;                    // nextPts[i]
+    // The I tiles of a level depend on prevPt only: they are requested one level ahead (the top level's
+    // before the loop), so their latency is covered by the previous level's iterations.
+    uint32_t rI[kSlots][3][2];
+    auto request_I = [&](int level) {
+        const int w = g.w[level], h = g.h[level], pitch = g.pitch[level];
+        const float lscale = 1.f / (float)(1 << level);
+        const int ipx = cv_floor(prevPt.x * lscale - half), ipy = cv_floor(prevPt.y * lscale - half);
+        const unsigned long long m = __ballot(live && !window_oob(ipx, ipy, w, h));
+        const int x0 = (ipx - 1) & ~3;
+        uint32_t src[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) src[t] = (uint32_t)(q_pr[t] * pitch + q_dc4[t]);
+#pragma unroll
+        for (int s = 0; s < kSlots; s++) {
+            if (!((m >> (16 * s)) & 1ull)) continue;
+            const int x0s = __builtin_amdgcn_readlane(x0, 16 * s), ipys = __builtin_amdgcn_readlane(ipy, 16 * s);
+            // 32-bit offsets from the slot's (wave-uniform) base: scalar part per slot, lane part per level
+            tile_loads(rI[s], slotI, slotI + pitch, (uint32_t)(g.origin[level] + (ipys - 1) * pitch + x0s), src, lane, kQPairs * 7);
+        }
+    };
+    request_I(g.nlevels - 1);
     for (int level = g.nlevels - 1; level >= 0; --level) {
         const int w = g.w[level], h = g.h[level], pitch = g.pitch[level];
-        const uint8_t *I = slotI + g.origin[level];
-        const uint8_t *J = slotJ + g.origin[level];
         // ---- control: window position and weights of every slot
         const float lscale = 1.f / (float)(1 << level);
         float px = prevPt.x * lscale, py = prevPt.y * lscale;
@@ -303,54 +338,67 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
         const int x0 = (ipx - 1) & ~3;
         const int offI = (ipx - 1) - x0;
 
-        // ---- I tiles (as row-pair column words) and patches + A sums, two slots at a time (two Q tiles
-        //      fill the wave's LDS region, which the four J tiles take over afterwards)
-        const unsigned long long m_on = __ballot(lvl_on);
-        int pA[kSlots][3];
-        uint32_t q_src[3];                       // lane part of the I tile source offsets at this level
+        // ---- position of the J window at the first iteration (nextPt is known): its tile is requested
+        //      together with the I tiles, so the patch arithmetic below covers the latency of both
+        float qx = nx - half, qy = ny - half;       // nextPt - halfWin
+        int tx0 = -(1 << 20), ty0 = 0;              // no J tile staged
+        {
+            const int inx = cv_floor(qx), iny = cv_floor(qy);
+            if (lvl_on && !window_oob(inx, iny, w, h)) { tx0 = inx - kJMargin; ty0 = iny - kJMargin; }
+        }
+        const unsigned long long m_on = __ballot(lvl_on), m_j = __ballot(tx0 != -(1 << 20));
+        uint32_t q_src[3];                       // lane part of the tile source offsets at this level
 #pragma unroll
         for (int t = 0; t < 3; t++) q_src[t] = (uint32_t)(q_pr[t] * pitch + q_dc4[t]);
+        uint32_t rJ[kSlots][3][2];
+        // ---- I tiles (as row-pair column words; all four fit the wave's LDS region, which the J tiles
+        //      take over afterwards), patches + A sums
+        int pA[kSlots][3];
 #pragma unroll
-        for (int grp = 0; grp < 2; grp++) {
+        for (int s = 0; s < kSlots; s++) {
+            if (!((m_on >> (16 * s)) & 1ull)) continue;
+            uint32_t *qt = lds + s * kQTileDw;
 #pragma unroll
-            for (int s = 2 * grp; s < 2 * grp + 2; s++) {
-                if (!((m_on >> (4 * s)) & 1ull)) continue;
-                const int x0s = __builtin_amdgcn_readlane(x0, 4 * s), ipys = __builtin_amdgcn_readlane(ipy, 4 * s);
-                uint32_t *qt = lds + (s & 1) * kQTileDw;
-                // 32-bit offsets from the slot's (wave-uniform) base: scalar part per slot, lane part per level
-                const uint32_t s_off = (uint32_t)(g.origin[level] + (ipys - 1) * pitch + x0s);
-                const uint8_t *rowA = slotI, *rowB = slotI + pitch;
-#pragma unroll
-                for (int t = 0; t < 3; t++) {
-                    if (lane + 64 * t < kQPairs * 7) {
-                        const uint32_t o = s_off + q_src[t];
-                        const uint32_t top = *(const uint32_t *)(rowA + o), bot = *(const uint32_t *)(rowB + o);
-                        uint4 q;
-                        q.x = perm_b32(bot, top, 0x0c040c00u); q.y = perm_b32(bot, top, 0x0c050c01u);
-                        q.z = perm_b32(bot, top, 0x0c060c02u); q.w = perm_b32(bot, top, 0x0c070c03u);
-                        *(uint4 *)(qt + q_dst[t]) = q;
-                    }
+            for (int t = 0; t < 3; t++) {
+                if (lane + 64 * t < kQPairs * 7) {
+                    const uint32_t top = rI[s][t][0], bot = rI[s][t][1];
+                    uint4 q;
+                    q.x = perm_b32(bot, top, 0x0c040c00u); q.y = perm_b32(bot, top, 0x0c050c01u);
+                    q.z = perm_b32(bot, top, 0x0c060c02u); q.w = perm_b32(bot, top, 0x0c070c03u);
+                    *(uint4 *)(qt + q_dst[t]) = q;
                 }
             }
-            wave_lds_fence();
+        }
+        // the J tiles are requested now (vmcnt counts in order: the waits above were for the I tiles only)
 #pragma unroll
-            for (int s = 2 * grp; s < 2 * grp + 2; s++) {
-                pA[s][0] = pA[s][1] = pA[s][2] = 0;
-                if (!((m_on >> (4 * s)) & 1ull)) continue;
-                const int offIs = __builtin_amdgcn_readlane(offI, 4 * s);
-                const uint32_t W01s = __builtin_amdgcn_readlane(WIa, 4 * s), W23s = __builtin_amdgcn_readlane(WIb, 4 * s);
-                const int ipxs = __builtin_amdgcn_readlane(ipx, 4 * s), ipys = __builtin_amdgcn_readlane(ipy, 4 * s);
-                const uint32_t *qt = lds + (s & 1) * kQTileDw;
-                if (__builtin_expect(ipxs < 0 || ipxs + kWin >= w || ipys < 0 || ipys + kWin >= h, 0))
-                    patch_slot<true>(qt, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
-                                     pA[s][0], pA[s][1], pA[s][2]);
-                else
-                    patch_slot<false>(qt, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
-                                      pA[s][0], pA[s][1], pA[s][2]);
-            }
-            if (grp == 0) wave_lds_fence();          // the second pair's tiles overwrite the first pair's
+        for (int s = 0; s < kSlots; s++) {
+            if (!((m_j >> (16 * s)) & 1ull)) continue;
+            const int tx0s = __builtin_amdgcn_readlane(tx0, 16 * s), ty0s = __builtin_amdgcn_readlane(ty0, 16 * s);
+            tile_loads(rJ[s], slotJ, slotJ + pitch, (uint32_t)(g.origin[level] + ty0s * pitch + tx0s), q_src, lane, kJPairs * 7);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int s = 0; s < kSlots; s++) {
+            pA[s][0] = pA[s][1] = pA[s][2] = 0;
+            if (!((m_on >> (16 * s)) & 1ull)) continue;
+            const int offIs = __builtin_amdgcn_readlane(offI, 16 * s);
+            const uint32_t W01s = __builtin_amdgcn_readlane(WIa, 16 * s), W23s = __builtin_amdgcn_readlane(WIb, 16 * s);
+            const int ipxs = __builtin_amdgcn_readlane(ipx, 16 * s), ipys = __builtin_amdgcn_readlane(ipy, 16 * s);
+            const uint32_t *qt = lds + s * kQTileDw;
+            if (__builtin_expect(ipxs < 0 || ipxs + kWin >= w || ipys < 0 || ipys + kWin >= h, 0))
+                patch_slot<true>(qt, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
+                                 pA[s][0], pA[s][1], pA[s][2]);
+            else
+                patch_slot<false>(qt, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
+                                  pA[s][0], pA[s][1], pA[s][2]);
         }
         wave_lds_fence();                        // the J tiles reuse the I tiles' LDS
+#pragma unroll
+        for (int s = 0; s < kSlots; s++) {
+            if (!((m_j >> (16 * s)) & 1ull)) continue;
+            tile_store_j(lds + s * kJTileDw, rJ[s], jq_dst, lane);
+        }
+        wave_lds_fence();
         float A11, A12, A22, D;
         {
             int v1[8], v2[8];
@@ -359,7 +407,7 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
                 v1[2 * s] = pA[s][0]; v1[2 * s + 1] = pA[s][1];
                 v2[2 * s] = pA[s][2]; v2[2 * s + 1] = 0;
             }
-            const int r1 = reduce_scatter8_wide(v1, lane), r2 = reduce_scatter8_wide(v2, lane);
+            const int r1 = reduce_scatter8_rows(v1, lane), r2 = reduce_scatter8_rows(v2, lane);
             A11 = wide_to_f32(quad_bcast<2>(r1), quad_bcast<0>(r1)) * FLT_SCALE;
             A12 = wide_to_f32(quad_bcast<3>(r1), quad_bcast<1>(r1)) * FLT_SCALE;
             A22 = wide_to_f32(quad_bcast<2>(r2), quad_bcast<0>(r2)) * FLT_SCALE;
@@ -373,9 +421,8 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
         D = 1.f / D;
 
         // ---- iterations (all slots in lockstep; a slot drops out when it converges or leaves)
-        float qx = nx - half, qy = ny - half;       // nextPt - halfWin
+        if (level > 0) request_I(level - 1);
         float pdx = 0.f, pdy = 0.f;
-        int tx0 = -(1 << 20), ty0 = 0;                // no J tile staged yet
         bool it_on = lvl_on;
         for (int j = 0; j < kLkMaxIter; j++) {
             if (!__any(it_on)) break;
@@ -387,37 +434,41 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
             const PackedWeights wj = bilinear_weights(qx - (float)inx, qy - (float)iny);
             const uint32_t Wa = wj.Wa, Wb = wj.Wb;
             int cx = inx - tx0, cy = iny - ty0;
-            const bool restage = it_on && ((unsigned)cx > 17u || (unsigned)cy > 10u);
-            if (restage) { tx0 = (inx - 8) & ~3; ty0 = iny - 5; cx = inx - tx0; cy = iny - ty0; }
-            // slot part of the J sample offset (bytes; 0 <= cy <= 10), tile position of the slot included
-            const int joff = (int)__umul24((unsigned)cy, kTileJDw * 4) + cx + (int)(((unsigned)lane >> 2) & 3u) * (kSlotDw * 4);
+            const bool restage = it_on && ((unsigned)cx > (unsigned)(2 * kJMargin) || (unsigned)cy > (unsigned)(2 * kJMargin));
+            if (restage) { tx0 = inx - kJMargin; ty0 = iny - kJMargin; cx = kJMargin; cy = kJMargin; }
+            // slot part of the J sample offset (bytes), tile position of the slot included
+            const int joff = ((int)__umul24((unsigned)cx, kJColDw) + cy + (lane >> 4) * kJTileDw) * 4;
             const unsigned long long m_it = __ballot(it_on), m_rs = __ballot(restage);
+            if (__builtin_expect(m_rs != 0, 0)) {     // a window drifted out of its tile
+#pragma unroll
+                for (int s = 0; s < kSlots; s++) {
+                    if (!((m_rs >> (16 * s)) & 1ull)) continue;
+                    const int tx0s = __builtin_amdgcn_readlane(tx0, 16 * s), ty0s = __builtin_amdgcn_readlane(ty0, 16 * s);
+                    uint32_t r[3][2];
+                    tile_loads(r, slotJ, slotJ + pitch, (uint32_t)(g.origin[level] + ty0s * pitch + tx0s), q_src, lane, kJPairs * 7);
+                    tile_store_j(lds + s * kJTileDw, r, jq_dst, lane);
+                }
+                wave_lds_fence();
+            }
             int pb[kSlots][2];
 #pragma unroll
             for (int s = 0; s < kSlots; s++) {
                 pb[s][0] = pb[s][1] = 0;
-                if (!((m_it >> (4 * s)) & 1ull)) continue;
-                uint32_t *tile = lds + s * kSlotDw;
-                if ((m_rs >> (4 * s)) & 1ull) {
-                    const int tx0s = __builtin_amdgcn_readlane(tx0, 4 * s), ty0s = __builtin_amdgcn_readlane(ty0, 4 * s);
-                    const uint8_t *base = J + (int64_t)ty0s * pitch + tx0s;
+                if (!((m_it >> (16 * s)) & 1ull)) continue;
+                const int joffs = __builtin_amdgcn_readlane(joff, 16 * s);
+                const uint32_t Was = __builtin_amdgcn_readlane(Wa, 16 * s), Wbs = __builtin_amdgcn_readlane(Wb, 16 * s);
+                const uint32_t *pj = lds_wg + ((joffs + lane_off) >> 2);
+                uint32_t C[8];
 #pragma unroll
-                    for (int t = 0; t < 5; t++) {
-                        const int i = lane + 64 * t, r = i / kTileJDw, c = i - r * kTileJDw;
-                        tile[i] = *(const uint32_t *)(base + (int64_t)r * pitch + 4 * c);
-                    }
-                    wave_lds_fence();
-                }
-                const int joffs = __builtin_amdgcn_readlane(joff, 4 * s);
-                const uint32_t Was = __builtin_amdgcn_readlane(Wa, 4 * s), Wbs = __builtin_amdgcn_readlane(Wb, 4 * s);
-                mismatch_slot(lds_wg, joffs + lane_off, Was, Wbs, IxP[s], IyP[s], nIIx[s], nIIy[s], vround, pb[s][0], pb[s][1]);
+                for (int k = 0; k < 8; k++) C[k] = pj[k * kJColDw];
+                mismatch_slot(C, Was, Wbs, IxP[s], IyP[s], nIIx[s], nIIy[s], vround, pb[s][0], pb[s][1]);
             }
             float b1f, b2f;
             {
                 int v[8];
 #pragma unroll
                 for (int s = 0; s < kSlots; s++) { v[2 * s] = pb[s][0]; v[2 * s + 1] = pb[s][1]; }
-                const int r = reduce_scatter8_wide(v, lane);       // quad s: {b1.lo, b2.lo, b1.hi, b2.hi} of slot s
+                const int r = reduce_scatter8_rows(v, lane);       // row s: {b1.lo, b2.lo, b1.hi, b2.hi} of slot s in every quad
                 b1f = wide_to_f32(quad_bcast<2>(r), quad_bcast<0>(r)) * FLT_SCALE;
                 b2f = wide_to_f32(quad_bcast<3>(r), quad_bcast<1>(r)) * FLT_SCALE;
             }
@@ -459,7 +510,7 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
 // every XCD on its own items -- an XCD then has about one item's four pyramids (3.3 MB) in flight
 // instead of slices of all items that are in flight anywhere on the chip (L2 hit rate 63 % -> see
 // DESIGN.md).  No workgroup barrier anywhere: each wave loops on its own.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void lk_kernel(LkArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void lk_kernel(LkArgs a)
 {
     __shared__ uint32_t lds[4 * kLdsDwPerWave];
     // items in whole groups of 8 are dealt one per XCD; the last (batch % 8) items -- the single pair of
@@ -474,14 +525,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         b = (a.batch & ~7) + r / a.gx; bx = r % a.gx;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slot = (lane >> 2) & 3;
+    const int slot = lane >> 4;
     int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
     n = min(n, a.cap);
     uint32_t *my = lds + wave * kLdsDwPerWave;
     for (int first = (bx * 4 + wave) * kSlots; first < n; first += a.gx * 4 * kSlots) {
         const int idx = first + slot;
         const bool valid = idx < n;
-        const bool writer = valid && lane == 4 * slot;         // one lane per slot stores results
+        const bool writer = valid && lane == 16 * slot;         // one lane per slot stores results
         const int64_t po = (int64_t)b * a.pts_stride + (valid ? idx : first);
         const float2 p0 = a.pts_in[po];
         float2 cur = p0, nxt;

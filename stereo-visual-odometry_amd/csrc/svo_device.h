@@ -95,38 +95,38 @@ __device__ inline int allsum_mod4(int v)
 }
 
 // Reduce-scatter of 8 per-lane values v[2*slot + t] (slot 0..3, t 0..1) whose 64-lane totals may
-// exceed 32 bits (each |v| < 2^29).  Two exchange steps first add groups of four lanes in full
-// 32-bit precision; the 4-lane sums are then split into 16-bit halves, which are reduced
-// separately (their 64-lane totals fit easily).  On return the lane with bits (b3 b2 b1 b0) holds
-// the total of:   slot = 2*b3 + b2,   half = b1 (0: low 16 bits, 1: arithmetic high part),   t = b0
-// i.e. quad `slot` holds that slot's {t0.lo, t1.lo, t0.hi, t1.hi}.  37 cross-lane/select ops.
-__device__ inline int reduce_scatter8_wide(const int (&v)[8], int lane)
+// exceed 32 bits (each |v| < 2^28).  The SLOT is scattered over the four rows of 16 lanes with the
+// CDNA4 row exchanges: v_permlane32_swap / v_permlane16_swap hand the partner's half of a value
+// pair over in place, so a scatter step is swap + add -- no selects.  t is scattered over lane bit 0
+// (two selects + one DPP add); the 8-lane sums, still exact in 32 bits, are then split into 16-bit
+// halves, the half is scattered over lane bit 1, and the remaining two lane bits (the four quads
+// of a row) are plain DPP adds.  On return EVERY quad of row `slot` holds that slot's
+//   {t0.lo, t1.lo, t0.hi, t1.hi}       (lo: low 16 bits, hi: arithmetic high part of the 8-lane sums)
+// 6 swaps + 16 other cross-lane/select ops (the bank-scattered version this replaces took 37).
+__device__ inline int reduce_scatter8_rows(const int (&v)[8], int lane)
 {
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-    int a[4], c[2], h[4], e[2];
+    const bool b0 = lane & 1, b1 = lane & 2;
+    int a[2][2], c[2];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {                          // split on t: a[slot]
-        int keep = b0 ? v[2 * i + 1] : v[2 * i], give = b0 ? v[2 * i] : v[2 * i + 1];
-        a[i] = keep + dpp_xor1(give);
+    for (int s0 = 0; s0 < 2; s0++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {                      // lanes 0-31 keep slots 0,1; lanes 32-63 slots 2,3
+            auto x = __builtin_amdgcn_permlane32_swap((unsigned)v[2 * s0 + t], (unsigned)v[2 * (s0 + 2) + t], false, false);
+            a[s0][t] = (int)(x[0] + x[1]);
+        }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {                          // even rows keep the even slot of their half
+        auto x = __builtin_amdgcn_permlane16_swap((unsigned)a[0][t], (unsigned)a[1][t], false, false);
+        c[t] = (int)(x[0] + x[1]);
     }
-#pragma unroll
-    for (int i = 0; i < 2; i++) {                          // split on slot & 1 (lane bit 2): c[slot >> 1]
-        int keep = b2 ? a[2 * i + 1] : a[2 * i], give = b2 ? a[2 * i] : a[2 * i + 1];
-        c[i] = keep + dpp_ror4(give);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++) { h[2 * i] = c[i] & 0xFFFF; h[2 * i + 1] = c[i] >> 16; }   // h[2*(slot>>1) + half]
-#pragma unroll
-    for (int i = 0; i < 2; i++) {                          // split on half (lane bit 1): e[slot >> 1]
-        int keep = b1 ? h[2 * i + 1] : h[2 * i], give = b1 ? h[2 * i] : h[2 * i + 1];
-        e[i] = keep + dpp_xor2(give);
-    }
-    int keep = b3 ? e[1] : e[0], give = b3 ? e[0] : e[1];   // split on slot >> 1 (lane bit 3)
-    int d = keep + dpp_ror8(give);
-    auto x = __builtin_amdgcn_permlane16_swap((unsigned)d, (unsigned)d, false, false);
-    d = (int)(x[0] + x[1]);
-    auto y = __builtin_amdgcn_permlane32_swap((unsigned)d, (unsigned)d, false, false);
-    return (int)(y[0] + y[1]);
+    const int keep = b0 ? c[1] : c[0], give = b0 ? c[0] : c[1];
+    const int d = keep + dpp_xor1(give);                   // t = lane bit 0; sums of 8 lanes
+    const int lo = d & 0xFFFF, hi = d >> 16;
+    const int keep2 = b1 ? hi : lo, give2 = b1 ? lo : hi;
+    int e = keep2 + dpp_xor2(give2);                       // half = lane bit 1
+    e += dpp_ror4(e);
+    e += dpp_ror8(e);
+    return e;
 }
 
 // broadcast lane q of every quad to the whole quad
