@@ -529,9 +529,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
     n = min(n, a.cap);
     uint32_t *my = lds + wave * kLdsDwPerWave;
-    for (int first = (bx * 4 + wave) * kSlots; first < n; first += a.gx * 4 * kSlots) {
+    // slots per wave: four when the launch fills the chip (the control work of an iteration is shared by
+    // four points); a launch of a few items only (the online path: one pair) is latency-bound -- there the
+    // points are spread over as many waves as the grid has, down to one point per wave
+    int spw = kSlots;
+    if (a.spread) spw = min(kSlots, max(1, (n + a.gx * 4 - 1) / (a.gx * 4)));
+    for (int first = (bx * 4 + wave) * spw; first < n; first += a.gx * 4 * spw) {
         const int idx = first + slot;
-        const bool valid = idx < n;
+        const bool valid = slot < spw && idx < n;
         const bool writer = valid && lane == 16 * slot;         // one lane per slot stores results
         const int64_t po = (int64_t)b * a.pts_stride + (valid ? idx : first);
         const float2 p0 = a.pts_in[po];
@@ -610,6 +615,12 @@ void launch_lk(const LkArgs &a0, int batch, int max_pts, hipStream_t st)
     const int chunks = (max_pts + 4 * kSlots - 1) / (4 * kSlots);
     LkArgs a = a0;
     a.gx = chunks < 192 ? chunks : 192;
+    a.spread = 0;
+    if (batch < 4) {                             // fewer than 768 workgroups: 3 per CU are resident at once
+        const int wide = (max_pts + 3) / 4, room = 768 / batch;
+        a.gx = wide < room ? wide : room;
+        a.spread = 1;
+    }
     a.batch = batch;
     dim3 grid(batch * a.gx, 1, 1), blk(256, 1, 1);
     hipLaunchKernelGGL(lk_kernel, grid, blk, 0, st, a);

@@ -46,7 +46,7 @@ struct LkArgs {
     uint8_t *status[kMaxChain];
     uint8_t *keep;                                // ncalls == 4: deleteBadmatchFeatures predicate
     float match_err_f; double match_err;          // feature_match_error
-    int gx, batch;                                // filled by launch_lk: workgroups per item, items
+    int gx, batch, spread;                                // filled by launch_lk: workgroups per item, items
 };
 void launch_lk(const LkArgs &a, int batch, int max_pts, hipStream_t st);
 
