@@ -22,75 +22,93 @@ namespace svo {
 #define SVO_DBL_EPS 2.220446049250313e-16
 #define SVO_DBL_MIN 2.2250738585072014e-308
 
+// The rotation of one Jacobi pair.  JacobiSVDImpl_ branches on the sign of beta:
+//   beta < 0:  s = sqrt(((gamma - beta) * 0.5) / gamma),  c = p / (gamma * s * 2)
+//   else:      c = sqrt((gamma + beta) / (gamma * 2)),    s = p / (gamma * c * 2)
+// Both arms are one division, one square root and one more division on different operands; selecting
+// the operands first runs ONE div-sqrt-div sequence for all lanes (64 lanes = 64 different matrices
+// practically always disagree on the sign, and then the branch form executes both arms: 2 sqrt + 4
+// div of ~15 instructions each).  Same operations on the same values per lane, so the same bits.
+__device__ __forceinline__ void jacobi_cs_d(double p, double beta, double gamma, double &c, double &s)
+{
+    const bool neg = beta < 0;
+    const double num = neg ? (gamma - beta) * 0.5 : gamma + beta;
+    const double den = neg ? gamma : gamma * 2;
+    const double r = sqrt(num / den);
+    const double q = p / (gamma * r * 2);
+    s = neg ? r : q;
+    c = neg ? q : r;
+}
+
 // JacobiSVDImpl_<double>: At is n rows of length m, element (i,k) at At[(i*m+k)*as].
 // Vt (n x n, element stride vs) may be null; `sort_rows` makes the rows of At follow the
 // descending sort and get normalised even without Vt (what cv::SVD does when U is requested).
 // M, N are compile-time so the k-loops unroll: their LDS / scratch loads are then issued together
 // instead of one dependent load per multiply (the run-time-bound version was latency-bound).
+// -- the three parts of JacobiSVDImpl_: column norms (+ V = I), the rotation of one pair, the epilogue
 template <int M, int N>
-__device__ inline void jacobi_svd_d(double *At, int as, double *W, double *Vt, int vs, bool sort_rows)
+__device__ inline void jacobi_init_d(double *At, int as, double *W, int ws, double *Vt, int vs)
 {
     constexpr int m = M, n = N;
-    const double eps = SVO_DBL_EPS * 10, minval = SVO_DBL_MIN;
-    const int max_iter = m > 30 ? m : 30;
     for (int i = 0; i < n; i++) {
         double sd = 0;
 #pragma unroll
         for (int k = 0; k < m; k++) { double t = At[(i * m + k) * as]; sd += t * t; }
-        W[i] = sd;
+        W[i * ws] = sd;
         if (Vt) {
             for (int k = 0; k < n; k++) Vt[(i * n + k) * vs] = 0;
             Vt[(i * n + i) * vs] = 1;
         }
     }
-    for (int iter = 0; iter < max_iter; iter++) {
-        bool changed = false;
-        for (int i = 0; i < n - 1; i++)
-            for (int j = i + 1; j < n; j++) {
-                double *Ai = At + (i * m) * as, *Aj = At + (j * m) * as;
-                double a = W[i], p = 0, b = W[j], c, s;
-                {
-                    double xi[M], xj[M];
+}
+
+// rows i, j of At (and of Vt); returns whether the pair was rotated
+template <int M, int N>
+__device__ __forceinline__ bool jacobi_pair_d(double *At, int as, double *W, int ws, double *Vt, int vs, int i, int j)
+{
+    constexpr int m = M, n = N;
+    const double eps = SVO_DBL_EPS * 10;
+    double *Ai = At + (i * m) * as, *Aj = At + (j * m) * as;
+    double a = W[i * ws], p = 0, b = W[j * ws], c, s;
+    {
+        double xi[M], xj[M];
 #pragma unroll
-                    for (int k = 0; k < m; k++) { xi[k] = Ai[k * as]; xj[k] = Aj[k * as]; }
+        for (int k = 0; k < m; k++) { xi[k] = Ai[k * as]; xj[k] = Aj[k * as]; }
 #pragma unroll
-                    for (int k = 0; k < m; k++) p += xi[k] * xj[k];
-                }
-                if (fabs(p) <= eps * sqrt(a * b)) continue;
-                p *= 2;
-                double beta = a - b, gamma = sqrt(p * p + beta * beta);
-                if (beta < 0) {
-                    double delta = (gamma - beta) * 0.5;
-                    s = sqrt(delta / gamma);
-                    c = p / (gamma * s * 2);
-                } else {
-                    c = sqrt((gamma + beta) / (gamma * 2));
-                    s = p / (gamma * c * 2);
-                }
-                a = b = 0;
-#pragma unroll
-                for (int k = 0; k < m; k++) {
-                    double x = Ai[k * as], y = Aj[k * as];
-                    double t0 = c * x + s * y;
-                    double t1 = -s * x + c * y;
-                    Ai[k * as] = t0; Aj[k * as] = t1;
-                    a += t0 * t0; b += t1 * t1;
-                }
-                W[i] = a; W[j] = b;
-                changed = true;
-                if (Vt) {
-                    double *Vi = Vt + (i * n) * vs, *Vj = Vt + (j * n) * vs;
-#pragma unroll
-                    for (int k = 0; k < n; k++) {
-                        double x = Vi[k * vs], y = Vj[k * vs];
-                        double t0 = c * x + s * y;
-                        double t1 = -s * x + c * y;
-                        Vi[k * vs] = t0; Vj[k * vs] = t1;
-                    }
-                }
-            }
-        if (!changed) break;
+        for (int k = 0; k < m; k++) p += xi[k] * xj[k];
     }
+    if (fabs(p) <= eps * sqrt(a * b)) return false;
+    p *= 2;
+    double beta = a - b, gamma = sqrt(p * p + beta * beta);
+    jacobi_cs_d(p, beta, gamma, c, s);
+    a = b = 0;
+#pragma unroll
+    for (int k = 0; k < m; k++) {
+        double x = Ai[k * as], y = Aj[k * as];
+        double t0 = c * x + s * y;
+        double t1 = -s * x + c * y;
+        Ai[k * as] = t0; Aj[k * as] = t1;
+        a += t0 * t0; b += t1 * t1;
+    }
+    W[i * ws] = a; W[j * ws] = b;
+    if (Vt) {
+        double *Vi = Vt + (i * n) * vs, *Vj = Vt + (j * n) * vs;
+#pragma unroll
+        for (int k = 0; k < n; k++) {
+            double x = Vi[k * vs], y = Vj[k * vs];
+            double t0 = c * x + s * y;
+            double t1 = -s * x + c * y;
+            Vi[k * vs] = t0; Vj[k * vs] = t1;
+        }
+    }
+    return true;
+}
+
+template <int M, int N>
+__device__ inline void jacobi_finish_d(double *At, int as, double *W, double *Vt, int vs, bool sort_rows)
+{
+    constexpr int m = M, n = N;
+    const double minval = SVO_DBL_MIN;
     for (int i = 0; i < n; i++) {
         double sd = 0;
 #pragma unroll
@@ -117,6 +135,48 @@ __device__ inline void jacobi_svd_d(double *At, int as, double *W, double *Vt, i
         double sd = W[i];
         double s = sd > minval ? 1 / sd : 0.;
         for (int k = 0; k < m; k++) At[(i * m + k) * as] *= s;
+    }
+}
+
+template <int M, int N>
+__device__ inline void jacobi_svd_d(double *At, int as, double *W, double *Vt, int vs, bool sort_rows)
+{
+    constexpr int m = M, n = N;
+    const int max_iter = m > 30 ? m : 30;
+    jacobi_init_d<M, N>(At, as, W, 1, Vt, vs);
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+        for (int i = 0; i < n - 1; i++)
+            for (int j = i + 1; j < n; j++)
+                if (jacobi_pair_d<M, N>(At, as, W, 1, Vt, vs, i, j)) changed = true;
+        if (!changed) break;
+    }
+    jacobi_finish_d<M, N>(At, as, W, Vt, vs, sort_rows);
+}
+
+// The sweeps of jacobi_svd_d<12, 12> (no V) by the NW waves of a workgroup: lane = matrix (the
+// lane-interleaved LDS image, W in LDS too), wave = one of the pairs that can be rotated at the same
+// time.  A rotation touches rows i, j and W[i], W[j] only, so rotations of disjoint pairs commute
+// exactly; the cyclic-by-rows order (0,1),(0,2),...,(10,11) is therefore equivalent -- bit for bit --
+// to any order that keeps the relative order of pairs SHARING a row.  Stage s = i + j does: two pairs
+// that share a row are ordered by their sum in the cyclic order (same i: by j; same j: by i; (a,b)
+// before (b,d): a < d; (c,a) before (a,b): c < b), and the pairs of one stage are disjoint.  21 stages
+// of up to 6 pairs replace 66 sequential pairs; one workgroup barrier per stage.  A matrix that has
+// converged keeps being swept while others have not (a sweep without rotation changes nothing).
+template <int NW>
+__device__ inline void jacobi12_sweeps_coop(double *At, int as, double *W, int ws, int wave)
+{
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+        for (int s = 1; s <= 21; s++) {
+            const int i_lo = s > 11 ? s - 11 : 0, cnt = (s - 1) / 2 - i_lo + 1;
+            for (int q = wave; q < cnt; q += NW) {
+                const int i = i_lo + q;
+                if (jacobi_pair_d<12, 12>(At, as, W, ws, nullptr, 0, i, s - i)) changed = true;
+            }
+            __syncthreads();
+        }
+        if (!__syncthreads_or(changed)) break;
     }
 }
 
@@ -152,14 +212,7 @@ __device__ inline void jacobi_null4_d(double (&At)[16], double (&X)[4])
                 if (fabs(p) <= eps * sqrt(a * b)) continue;
                 p *= 2;
                 double beta = a - b, gamma = sqrt(p * p + beta * beta);
-                if (beta < 0) {
-                    double delta = (gamma - beta) * 0.5;
-                    s = sqrt(delta / gamma);
-                    c = p / (gamma * s * 2);
-                } else {
-                    c = sqrt((gamma + beta) / (gamma * 2));
-                    s = p / (gamma * c * 2);
-                }
+                jacobi_cs_d(p, beta, gamma, c, s);
                 a = b = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -365,7 +418,8 @@ __device__ inline double epnp_R_and_t_d(Epnp5 &e, const double *v /* 4 x 12: ut 
 
 // epnp::compute_pose for the 5-point minimal sample.  `big` is this lane's 144-double matrix
 // region (element stride `bs`), used for the 12x12 eigenproblem of M^T M.
-__device__ inline void epnp5_d(Epnp5 &e, double *big, int bs, double Rout[9], double tout[3])
+// -- part 1: control points, barycentric coordinates, M^T M into `big`
+__device__ inline void epnp5_front_d(Epnp5 &e, double *big, int bs)
 {
     const int n = 5;
     // ---- choose_control_points
@@ -419,8 +473,11 @@ __device__ inline void epnp5_d(Epnp5 &e, double *big, int bs, double Rout[9], do
             for (int j = i; j < 12; j++) big[(i * 12 + j) * bs] += row[i] * row[j];
     }
     for (int i = 0; i < 12; i++) for (int j = 0; j < i; j++) big[(i * 12 + j) * bs] = big[(j * 12 + i) * bs];
-    double d12[12];
-    jacobi_svd_d<12, 12>(big, bs, d12, nullptr, 0, true);
+}
+
+// -- part 2 (after the SVD of `big`: rows = left singular vectors, sorted): betas, R, t
+__device__ inline void epnp5_back_d(Epnp5 &e, double *big, int bs, double Rout[9], double tout[3])
+{
     double v[48];                                   // ut rows 11, 10, 9, 8
     for (int i = 0; i < 4; i++) for (int k = 0; k < 12; k++) v[i * 12 + k] = big[((11 - i) * 12 + k) * bs];
 
@@ -518,6 +575,14 @@ __device__ inline void epnp5_d(Epnp5 &e, double *big, int bs, double Rout[9], do
             for (int i = 0; i < 3; i++) tout[i] = tn[i];
         }
     }
+}
+
+__device__ inline void epnp5_d(Epnp5 &e, double *big, int bs, double Rout[9], double tout[3])
+{
+    epnp5_front_d(e, big, bs);
+    double d12[12];
+    jacobi_svd_d<12, 12>(big, bs, d12, nullptr, 0, true);
+    epnp5_back_d(e, big, bs, Rout, tout);
 }
 
 // cv::Rodrigues vector -> matrix (+ 3x9 Jacobian)

@@ -228,16 +228,65 @@ __device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem)
     a.hyp[(int64_t)b * kPhaseHyps + h] = out;
 }
 
-// Two builds of the same body.  The 12x12 EPnP wants far more than 256 registers (Epnp5 alone is 88
-// doubles): with one wave per SIMD (512 registers, spills go to the accumulation half) a single
-// hypothesis block is ~20 % faster -- what the ONLINE path wants, where one pair's 64 hypotheses are
-// all there is.  A batch launches thousands of blocks beside the next batch's front end; there a
-// 512-register wave owns a whole SIMD's register file and starves the kernels it overlaps (ORB mode:
-// +1 ms per 256 pairs), so the batched path uses the 256-register build (two waves per SIMD).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void pnp_hyp_kernel_wide(PnpArgs a)
+// Two builds.  The batched path launches thousands of hypothesis blocks beside the next batch's front
+// end: one wave per block, 256 registers (two waves per SIMD) -- a 512-register wave owns a whole SIMD's
+// register file and starves the kernels it overlaps (ORB mode: +1 ms per 256 pairs).
+// The LATENCY build is for launches that leave the chip mostly empty (the online path: one pair's 64
+// hypotheses are all there is).  There the block is VALU-issue bound on ONE SIMD (f64 instructions
+// issue every ~4.5 cycles; two thirds of them are the 66-pairs-per-sweep Jacobi SVD of the 12x12
+// M^T M), so the block gets four waves -- one per SIMD, 512 registers each: wave 0 runs the
+// lane-private parts, and all four rotate DISJOINT pairs of the 12x12 problem at the same time
+// (jacobi12_sweeps_coop: 21 barrier-separated stages instead of 66 sequential pairs, same bits).
+constexpr size_t kPnpCoopLdsBytes = (size_t)((144 + 12) * 64) * sizeof(double);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void pnp_hyp_kernel_wide(PnpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double pnp_smem_w[];
-    pnp_hyp_body(a, pnp_smem_w);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    PnpState *st = a.state + b;
+    const int h = blockIdx.x * kHypBlock + lane;             // hypothesis index inside the phase
+    if (st->next_base != a.phase_base) return;               // phase not needed (uniform for the block)
+    if (blockIdx.x == gridDim.x - 1) {
+        if (wave) return;
+        // the drawer: subsets of the NEXT phase into the other buffer (see pnp_begin_kernel)
+        const int next = a.phase_base + a.phase_cap, niters = a.iterations > 1 ? a.iterations : 1;
+        const int n = st->n;
+        if (next < niters && n > 5 && st->phase_hyps > 0) {
+            const int more = niters - next < kPhaseHyps ? niters - next : kPhaseHyps;
+            const uint64_t rng = draw_subsets(st->rng, n, more, a.subsets + ((int64_t)b * 2 + (a.phase_index + 1) % 2) * kPhaseHyps * 5, lane);
+            if (lane == 0) st->rng = rng;
+        }
+        return;
+    }
+    if (blockIdx.x * kHypBlock >= st->phase_hyps) return;    // block beyond the phase
+    const bool active = h < st->phase_hyps;                  // idle lanes solve points 0..4 (they take part in the barriers)
+    double *big = pnp_smem_w + lane, *W = pnp_smem_w + 144 * 64 + lane;
+    Epnp5 e;
+    if (wave == 0) {
+        const float *X3 = a.X3 + (int64_t)b * a.stride * 3;
+        const float2 *img = a.img + (int64_t)b * a.stride;
+        const int *my = a.subsets + (((int64_t)b * 2 + a.phase_index % 2) * kPhaseHyps + h) * 5;
+        const double fx = a.fx, fy = a.fy, cx = a.cx, cy = a.cy;
+        e.fu = fx; e.fv = fy; e.uc = cx; e.vc = cy;
+        for (int i = 0; i < 5; i++) {
+            const int s = active ? my[i] : i;
+            e.pws[3 * i] = (double)X3[3 * s]; e.pws[3 * i + 1] = (double)X3[3 * s + 1]; e.pws[3 * i + 2] = (double)X3[3 * s + 2];
+            const float2 m = img[s];
+            const float xn = (float)(((double)m.x - cx) * (1. / fx));
+            const float yn = (float)(((double)m.y - cy) * (1. / fy));
+            e.us[2 * i] = (double)xn * fx + cx;
+            e.us[2 * i + 1] = (double)yn * fy + cy;
+        }
+        epnp5_front_d(e, big, 64);
+        jacobi_init_d<12, 12>(big, 64, W, 64, nullptr, 0);
+    }
+    __syncthreads();
+    jacobi12_sweeps_coop<4>(big, 64, W, 64, wave);
+    if (wave) return;
+    double d12[12];
+    jacobi_finish_d<12, 12>(big, 64, d12, nullptr, 0, true);
+    PnpHyp out;
+    epnp5_back_d(e, big, 64, out.R, out.t);
+    if (active) a.hyp[(int64_t)b * kPhaseHyps + h] = out;
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void pnp_hyp_kernel(PnpArgs a)
 {
@@ -683,7 +732,7 @@ int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
     if (hipFuncSetAttribute((const void *)pnp_hyp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPnpLdsBytes) != hipSuccess ||
         hipFuncSetAttribute((const void *)pnp_hyp_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kPnpLdsBytes) != hipSuccess)
+                            (int)kPnpCoopLdsBytes) != hipSuccess)
         return SVO_ERR_HIP;
     if (hipFuncSetAttribute((const void *)pnp_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kRefitLdsBytes) != hipSuccess)
@@ -714,7 +763,7 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
         const int blocks = (hyps + kHypBlock - 1) / kHypBlock;
         a.phase_base = base; a.phase_cap = cap; a.phase_index = phase;
         if ((blocks + 1) * n_items <= 256)     // the chip is not full: latency matters, registers are free
-            hipLaunchKernelGGL(pnp_hyp_kernel_wide, dim3(blocks + 1, n_items), dim3(64), kPnpLdsBytes, st, a);   // + the drawer
+            hipLaunchKernelGGL(pnp_hyp_kernel_wide, dim3(blocks + 1, n_items), dim3(256), kPnpCoopLdsBytes, st, a);   // + the drawer
         else
             hipLaunchKernelGGL(pnp_hyp_kernel, dim3(blocks + 1, n_items), dim3(64), kPnpLdsBytes, st, a);
         hipLaunchKernelGGL(pnp_score_kernel, dim3(blocks, n_items, zchunks), dim3(256), 0, st, a);
