@@ -475,11 +475,19 @@ __device__ inline void epnp5_front_d(Epnp5 &e, double *big, int bs)
     for (int i = 0; i < 12; i++) for (int j = 0; j < i; j++) big[(i * 12 + j) * bs] = big[(j * 12 + i) * bs];
 }
 
-// -- part 2 (after the SVD of `big`: rows = left singular vectors, sorted): betas, R, t
-__device__ inline void epnp5_back_d(Epnp5 &e, double *big, int bs, double Rout[9], double tout[3])
+// -- part 2 (after the SVD of `big`: rows = left singular vectors, sorted): the four null-space vectors
+__device__ inline void epnp5_load_v_d(const double *big, int bs, double (&v)[48])   // ut rows 11, 10, 9, 8
 {
-    double v[48];                                   // ut rows 11, 10, 9, 8
     for (int i = 0; i < 4; i++) for (int k = 0; k < 12; k++) v[i * 12 + k] = big[((11 - i) * 12 + k) * bs];
+}
+
+// -- part 3: betas, R, t.  NSEL = 0: all of epnp's three beta approximations, the best one wins
+// (compute_pose's rule); 1..3: only that approximation -- its pose and its reprojection error, for a
+// caller that runs the three side by side and applies the rule itself (pnp_hyp_kernel_wide).
+// `big` is workspace only here (64 doubles per lane).
+template <int NSEL = 0>
+__device__ inline double epnp5_back_d(Epnp5 &e, const double (&v)[48], double *big, int bs, double Rout[9], double tout[3])
+{
 
     // ---- compute_L_6x10, compute_rho
     double L[60], rho[6];
@@ -515,6 +523,7 @@ __device__ inline void epnp5_back_d(Epnp5 &e, double *big, int bs, double Rout[9
 
     double best_rep = 0;
     for (int N = 1; N <= 3; N++) {
+        if (NSEL && N != NSEL) continue;
         // ---- find_betas_approx_N
         double betas[4], Lr[30], bb[5];
         const int nc = N == 1 ? 4 : (N == 2 ? 3 : 5);
@@ -569,12 +578,13 @@ __device__ inline void epnp5_back_d(Epnp5 &e, double *big, int bs, double Rout[9
         double Rn[9], tn[3];
         double rep = epnp_R_and_t_d(e, v, betas, Rn, tn, big, bs);
         // "N = 1; if (rep[2] < rep[1]) N = 2; if (rep[3] < rep[N]) N = 3;"
-        if (N == 1 || rep < best_rep) {
+        if (N == 1 || NSEL || rep < best_rep) {
             best_rep = rep;
             for (int i = 0; i < 9; i++) Rout[i] = Rn[i];
             for (int i = 0; i < 3; i++) tout[i] = tn[i];
         }
     }
+    return best_rep;
 }
 
 __device__ inline void epnp5_d(Epnp5 &e, double *big, int bs, double Rout[9], double tout[3])
@@ -582,7 +592,9 @@ __device__ inline void epnp5_d(Epnp5 &e, double *big, int bs, double Rout[9], do
     epnp5_front_d(e, big, bs);
     double d12[12];
     jacobi_svd_d<12, 12>(big, bs, d12, nullptr, 0, true);
-    epnp5_back_d(e, big, bs, Rout, tout);
+    double v[48];
+    epnp5_load_v_d(big, bs, v);
+    epnp5_back_d<0>(e, v, big, bs, Rout, tout);
 }
 
 // cv::Rodrigues vector -> matrix (+ 3x9 Jacobian)

@@ -237,7 +237,7 @@ __device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem)
 // M^T M), so the block gets four waves -- one per SIMD, 512 registers each: wave 0 runs the
 // lane-private parts, and all four rotate DISJOINT pairs of the 12x12 problem at the same time
 // (jacobi12_sweeps_coop: 21 barrier-separated stages instead of 66 sequential pairs, same bits).
-constexpr size_t kPnpCoopLdsBytes = (size_t)((144 + 12) * 64) * sizeof(double);
+constexpr size_t kPnpCoopLdsBytes = (size_t)((144 + 12 + 57 + 64) * 64) * sizeof(double);   // image, W, hand-over, wave 2's workspace
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void pnp_hyp_kernel_wide(PnpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double pnp_smem_w[];
@@ -281,11 +281,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();
     jacobi12_sweeps_coop<4>(big, 64, W, 64, wave);
-    if (wave) return;
-    double d12[12];
-    jacobi_finish_d<12, 12>(big, 64, d12, nullptr, 0, true);
+    if (wave == 3) return;
+    // epnp's three beta approximations on waves 0..2: wave 0 hands its lane-private state over through LDS
+    double *xfer = pnp_smem_w + (144 + 12) * 64 + lane;      // 57 doubles per lane
+    if (wave == 0) {
+        double d12[12];
+        jacobi_finish_d<12, 12>(big, 64, d12, nullptr, 0, true);
+        for (int i = 0; i < 15; i++) xfer[i * 64] = e.pws[i];
+        for (int i = 0; i < 10; i++) xfer[(15 + i) * 64] = e.us[i];
+        for (int i = 0; i < 20; i++) xfer[(25 + i) * 64] = e.alphas[i];
+        for (int i = 0; i < 12; i++) xfer[(45 + i) * 64] = e.cws[i / 3][i % 3];
+    }
+    __syncthreads();
+    if (wave) {
+        e.fu = a.fx; e.fv = a.fy; e.uc = a.cx; e.vc = a.cy;
+        for (int i = 0; i < 15; i++) e.pws[i] = xfer[i * 64];
+        for (int i = 0; i < 10; i++) e.us[i] = xfer[(15 + i) * 64];
+        for (int i = 0; i < 20; i++) e.alphas[i] = xfer[(25 + i) * 64];
+        for (int i = 0; i < 12; i++) e.cws[i / 3][i % 3] = xfer[(45 + i) * 64];
+    }
+    double v[48];
+    epnp5_load_v_d(big, 64, v);
+    __syncthreads();                                         // the 12x12 image and the hand-over area are free now
     PnpHyp out;
-    epnp5_back_d(e, big, 64, out.R, out.t);
+    double rep;
+    double *ws = wave == 0 ? big : wave == 1 ? big + 64 * 64 : pnp_smem_w + (144 + 12 + 57) * 64 + lane;   // 64 doubles per lane each
+    if (wave == 0) rep = epnp5_back_d<1>(e, v, ws, 64, out.R, out.t);
+    else if (wave == 1) rep = epnp5_back_d<2>(e, v, ws, 64, out.R, out.t);
+    else rep = epnp5_back_d<3>(e, v, ws, 64, out.R, out.t);
+    if (wave) {
+        double *dst = xfer + (wave - 1) * 13 * 64;
+        for (int i = 0; i < 9; i++) dst[i * 64] = out.R[i];
+        for (int i = 0; i < 3; i++) dst[(9 + i) * 64] = out.t[i];
+        dst[12 * 64] = rep;
+    }
+    __syncthreads();
+    if (wave) return;
+    // epnp::compute_pose: "N = 1; if (rep[2] < rep[1]) N = 2; if (rep[3] < rep[N]) N = 3"
+#pragma unroll
+    for (int w = 1; w <= 2; w++) {
+        const double *src = xfer + (w - 1) * 13 * 64;
+        if (src[12 * 64] < rep) {
+            rep = src[12 * 64];
+            for (int i = 0; i < 9; i++) out.R[i] = src[i * 64];
+            for (int i = 0; i < 3; i++) out.t[i] = src[(9 + i) * 64];
+        }
+    }
     if (active) a.hyp[(int64_t)b * kPhaseHyps + h] = out;
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void pnp_hyp_kernel(PnpArgs a)
