@@ -154,25 +154,26 @@ __device__ inline void jacobi_svd_d(double *At, int as, double *W, double *Vt, i
     jacobi_finish_d<M, N>(At, as, W, Vt, vs, sort_rows);
 }
 
-// The sweeps of jacobi_svd_d<12, 12> (no V) by the NW waves of a workgroup: lane = matrix (the
-// lane-interleaved LDS image, W in LDS too), wave = one of the pairs that can be rotated at the same
-// time.  A rotation touches rows i, j and W[i], W[j] only, so rotations of disjoint pairs commute
+// The sweeps of jacobi_svd_d by the NW waves of a workgroup: lane = matrix (the lane-interleaved LDS
+// image; W in LDS too), wave = one of the pairs that can be rotated at the same time.  A rotation touches rows i, j and W[i], W[j] only, so rotations of disjoint pairs commute
 // exactly; the cyclic-by-rows order (0,1),(0,2),...,(10,11) is therefore equivalent -- bit for bit --
 // to any order that keeps the relative order of pairs SHARING a row.  Stage s = i + j does: two pairs
 // that share a row are ordered by their sum in the cyclic order (same i: by j; same j: by i; (a,b)
-// before (b,d): a < d; (c,a) before (a,b): c < b), and the pairs of one stage are disjoint.  21 stages
-// of up to 6 pairs replace 66 sequential pairs; one workgroup barrier per stage.  A matrix that has
+// before (b,d): a < d; (c,a) before (a,b): c < b), and the pairs of one stage are disjoint.  For 12
+// columns 21 stages of up to 6 pairs replace 66 sequential pairs (6 columns: 9 stages of up to 3
+// replace 15); one workgroup barrier per stage.  Every wave of the workgroup must call this.  A matrix that has
 // converged keeps being swept while others have not (a sweep without rotation changes nothing).
-template <int NW>
-__device__ inline void jacobi12_sweeps_coop(double *At, int as, double *W, int ws, int wave)
+template <int M, int N, int NW>
+__device__ inline void jacobi_sweeps_coop(double *At, int as, double *W, int ws, double *Vt, int vs, int wave)
 {
-    for (int iter = 0; iter < 30; iter++) {
+    constexpr int max_iter = M > 30 ? M : 30;
+    for (int iter = 0; iter < max_iter; iter++) {
         bool changed = false;
-        for (int s = 1; s <= 21; s++) {
-            const int i_lo = s > 11 ? s - 11 : 0, cnt = (s - 1) / 2 - i_lo + 1;
+        for (int s = 1; s <= 2 * N - 3; s++) {
+            const int i_lo = s > N - 1 ? s - (N - 1) : 0, cnt = (s - 1) / 2 - i_lo + 1;
             for (int q = wave; q < cnt; q += NW) {
                 const int i = i_lo + q;
-                if (jacobi_pair_d<12, 12>(At, as, W, ws, nullptr, 0, i, s - i)) changed = true;
+                if (jacobi_pair_d<M, N>(At, as, W, ws, Vt, vs, i, s - i)) changed = true;
             }
             __syncthreads();
         }
@@ -283,6 +284,78 @@ __device__ inline void svd_solve_d(const double *A, const double *b, double *x, 
         s *= wi;
         for (int j = 0; j < n; j++) x[j] = x[j] + s * Vt[(i * n + j) * st];
     }
+}
+
+// svd_solve_d by the NW waves of a workgroup (all of them call it, with identical arguments in the
+// lanes that share a matrix copy); Wl: n doubles of LDS per lane copy.  x is valid on wave 0.
+template <int M, int N, int NW>
+__device__ inline void svd_solve_coop_d(const double *A, const double *b, double *x, double *ws, int st, double *Wl, int wave)
+{
+    constexpr int m = M, n = N;
+    double *At = ws, *Vt = ws + 36 * st;
+    if (wave == 0) {
+        for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) At[(j * m + i) * st] = A[i * n + j];
+        jacobi_init_d<M, N>(At, st, Wl, st, Vt, st);
+    }
+    __syncthreads();
+    jacobi_sweeps_coop<M, N, NW>(At, st, Wl, st, Vt, st, wave);
+    if (wave) return;
+    double W[6];
+    jacobi_finish_d<M, N>(At, st, W, Vt, st, false);
+    double threshold = 0;
+    for (int i = 0; i < n; i++) x[i] = 0;
+    for (int i = 0; i < n; i++) threshold += W[i];
+    threshold *= SVO_DBL_EPS * 2;
+    for (int i = 0; i < n; i++) {
+        double wi = W[i];
+        if (fabs(wi) <= threshold) continue;
+        wi = 1 / wi;
+        double s = 0;
+        for (int j = 0; j < m; j++) s += At[(i * m + j) * st] * b[j];
+        s *= wi;
+        for (int j = 0; j < n; j++) x[j] = x[j] + s * Vt[(i * n + j) * st];
+    }
+}
+
+// A x = b for a symmetric positive definite 6x6 A by Cholesky, everything in registers.  Returns false
+// -- and leaves x undefined -- when a pivot is not safely positive (relative to its diagonal entry):
+// the caller then takes the SVD route, which is what cv::solve(DECOMP_SVD) would do for a
+// rank-deficient system.
+__device__ inline bool chol_solve6_d(const double (&A)[36], const double (&b)[6], double (&x)[6])
+{
+    double L[21];                                   // row-major lower triangle
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            double s = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+            if (i == j) {
+                ok = ok && s > 1e-10 * A[i * 6 + i];
+                L[i * (i + 1) / 2 + i] = sqrt(s);
+            } else {
+                L[i * (i + 1) / 2 + j] = s / L[j * (j + 1) / 2 + j];
+            }
+        }
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= L[i * (i + 1) / 2 + k] * y[k];
+        y[i] = s / L[i * (i + 1) / 2 + i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) s -= L[k * (k + 1) / 2 + i] * x[k];
+        x[i] = s / L[i * (i + 1) / 2 + i];
+    }
+    return ok;
 }
 
 // cv::invert(A, Ainv, DECOMP_SVD) for 3x3

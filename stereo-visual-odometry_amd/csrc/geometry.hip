@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         jacobi_init_d<12, 12>(big, 64, W, 64, nullptr, 0);
     }
     __syncthreads();
-    jacobi12_sweeps_coop<4>(big, 64, W, 64, wave);
+    jacobi_sweeps_coop<12, 12, 4>(big, 64, W, 64, nullptr, 0, wave);
     if (wave == 3) return;
     // epnp's three beta approximations on waves 0..2: wave 0 hands its lane-private state over through LDS
     double *xfer = pnp_smem_w + (144 + 12) * 64 + lane;      // 57 doubles per lane
@@ -478,13 +478,14 @@ __device__ inline double lm_eval(const double param[6], const float *X3, const f
     return acc[0];
 }
 
-constexpr size_t kRefitLdsBytes = (size_t)(72 * 64 + 4 * 28 + 8) * sizeof(double);
+constexpr size_t kRefitLdsBytes = (size_t)(72 * 64 + 4 * 28 + 8 + 6 * 64) * sizeof(double);
 __global__ __launch_bounds__(kRefitThreads) void pnp_refit_kernel(PnpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double pnp_smem[];
     double *ws = pnp_smem;                    // lane-interleaved 6x6 SVD workspace of wave 0 (36,864 B)
     double *red = pnp_smem + 72 * 64;         // 4 x 28 wave sums
     double *bcast = red + 4 * 28;             // 6 parameters + flags handed from wave 0 to the others
+    double *wl = bcast + 8;                   // lane-interleaved singular values of the cooperative SVD
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     const PnpState *st = a.state + b;
     const int n = st->n;
@@ -544,16 +545,27 @@ __global__ __launch_bounds__(kRefitThreads) void pnp_refit_kernel(PnpArgs a)
         bool done = false;
         for (;;) {
             const double lambda = POW10[lambdaLg10 + 16];
-            __syncthreads();                                 // bcast is free again
-            if (wave == 0) {
+            {
+                // The damped normal equations.  CvLevMarq solves them with cv::solve(DECOMP_SVD); J^T J (1 +
+                // lambda on the diagonal) is symmetric positive definite unless the inliers are degenerate,
+                // and then a register-only Cholesky solve (every thread the same values, no LDS, no
+                // barrier) gives the same step to within cond(A) * 2^-52 -- far inside what the LM
+                // iteration corrects anyway (the refit is compared with the oracle at 1e-9, DESIGN.md
+                // section 5).  The Jacobi SVD route (~80 k cycles per solve, two thirds of this kernel)
+                // remains for the degenerate case, where its singular-value threshold matters.
                 double A[36], x[6];
                 for (int i = 0; i < 36; i++) A[i] = JtJ[i];
                 for (int i = 0; i < 6; i++) A[i * 6 + i] *= 1. + lambda;
-                svd_solve_d<6, 6>(A, JtErr, x, ws + lane, 64);
-                if (lane == 0) for (int i = 0; i < 6; i++) bcast[i] = prevParam[i] - x[i];
+                if (chol_solve6_d(A, JtErr, x)) {
+                    for (int i = 0; i < 6; i++) param[i] = prevParam[i] - x[i];
+                } else {
+                    __syncthreads();                         // bcast is free again
+                    svd_solve_coop_d<6, 6, 4>(A, JtErr, x, ws + lane, 64, wl + lane, wave);
+                    if (tid == 0) for (int i = 0; i < 6; i++) bcast[i] = prevParam[i] - x[i];
+                    __syncthreads();
+                    for (int i = 0; i < 6; i++) param[i] = bcast[i];
+                }
             }
-            __syncthreads();
-            for (int i = 0; i < 6; i++) param[i] = bcast[i];
             errNorm = sqrt(lm_eval(param, X3, img, mask, n, fx, fy, cx, cy, red, nullptr, nullptr));
             if (errNorm > prevErrNorm) {
                 if (++lambdaLg10 <= 16) continue;
