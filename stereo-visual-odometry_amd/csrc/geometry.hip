@@ -16,6 +16,7 @@
 //   finalize_kernel    : per pair failure staging, Euler / translation gates, inv([R t;0 1]).
 //   chain_kernel       : frame_pose_ *= T^-1 over the batch, skipping failed steps.
 #include <cstring>
+#include <cstdlib>
 #include "svo_ctx.h"
 #include "geom_device.h"
 
@@ -102,6 +103,7 @@ struct PnpArgs {
     PnpRecord *out;
     PnpState *state; PnpHyp *hyp; int *counts; int *subsets;   // per item: 1, kPhaseHyps, kPhaseHyps, 2 x 5 * kPhaseHyps
     int phase_base, phase_cap, phase_index;                 // hypotheses [phase_base, phase_base + phase_cap) in this phase
+    int refit_svd;                                          // 1: always take the SVD route of the refit's solves (SVO_REFIT_SVD=1; tests)
 };
 
 __device__ inline double wave_allsum_f64(double v)
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(kRefitThreads) void pnp_refit_kernel(PnpArgs a)
                 double A[36], x[6];
                 for (int i = 0; i < 36; i++) A[i] = JtJ[i];
                 for (int i = 0; i < 6; i++) A[i * 6 + i] *= 1. + lambda;
-                if (chol_solve6_d(A, JtErr, x)) {
+                if (!a.refit_svd && chol_solve6_d(A, JtErr, x)) {
                     for (int i = 0; i < 6; i++) param[i] = prevParam[i] - x[i];
                 } else {
                     __syncthreads();                         // bcast is free again
@@ -823,6 +825,8 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
         hipLaunchKernelGGL(pnp_select_kernel, dim3(n_items), dim3(64), 0, st, a);
         base += cap;
     }
+    const char *force = getenv("SVO_REFIT_SVD");           // test hook: the rank-deficient route on ordinary data
+    a.refit_svd = force && force[0] == '1';
     hipLaunchKernelGGL(pnp_refit_kernel, dim3(n_items), dim3(kRefitThreads), kRefitLdsBytes, st, a);
 }
 

@@ -100,6 +100,15 @@ def test_pnp_ransac_parity(ctx, oracle, tc, n, seed, n_out):
         assert ref["ok"] == 1 and np.abs(ref["tvec"] - t).max() < 0.02
 
 
+def test_pnp_refit_svd_route_parity(ctx, oracle, monkeypatch):
+    """The refit solves its normal equations by Cholesky and keeps the reference's SVD solve (run by four
+    waves) for rank-deficient systems; SVO_REFIT_SVD=1 sends ordinary data down that route."""
+    monkeypatch.setenv("SVO_REFIT_SVD", "1")
+    for n, seed, n_out in [(400, 11, 100), (64, 13, 30), (9, 15, 0)]:
+        X, x, r, t = _planted(n, seed, n_out)
+        _check_pnp(ctx.pnp_ransac(X, x, K), oracle.pnp_ransac(X, x, K))
+
+
 def test_pnp_ransac_many_rounds_and_failure(ctx, oracle, tc):
     """Low inlier ratio -> the adaptive stop needs several 64-hypothesis rounds; garbage -> failure."""
     X, x, r, t = _planted(300, 21, 225, noise=0.02)          # 25 % inliers
