@@ -268,7 +268,7 @@ __device__ inline void svd_solve_d(const double *A, const double *b, double *x, 
 {
     constexpr int m = M, n = N;
     double W[6];
-    double *At = ws, *Vt = ws + 36 * st;
+    double *At = ws, *Vt = ws + (M * N) * st;           // workspace: M*N + N*N doubles
     for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) At[(j * m + i) * st] = A[i * n + j];
     jacobi_svd_d<M, N>(At, st, W, Vt, st, false);
     double threshold = 0;
@@ -292,7 +292,7 @@ template <int M, int N, int NW>
 __device__ inline void svd_solve_coop_d(const double *A, const double *b, double *x, double *ws, int st, double *Wl, int wave)
 {
     constexpr int m = M, n = N;
-    double *At = ws, *Vt = ws + 36 * st;
+    double *At = ws, *Vt = ws + (M * N) * st;           // workspace: M*N + N*N doubles
     if (wave == 0) {
         for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) At[(j * m + i) * st] = A[i * n + j];
         jacobi_init_d<M, N>(At, st, Wl, st, Vt, st);

@@ -184,65 +184,24 @@ __global__ __launch_bounds__(64) void pnp_begin_kernel(PnpArgs a)
     st->rng = rng;
 }
 
-constexpr size_t kPnpLdsBytes = (size_t)(144 * 64) * sizeof(double);
-// The LDS image is declared dynamic so that the compiler does not know it limits the kernel to two
-// workgroups per CU: it would otherwise hand the single wave all 512 registers of its SIMD, which
-// starves every kernel that overlaps the pose stage.  With two waves per EU
-// as the target it gets 256 (architectural + accumulation; spills go to the latter, not to memory).
-__device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem)
+// One workgroup = 64 hypotheses (lane = hypothesis) and FOUR waves.  A lane-private EPnP is VALU-issue
+// bound on its SIMD (f64 instructions issue every ~4.5 cycles; two thirds of them are the Jacobi SVD
+// of the 12x12 M^T M, 66 pairs per sweep), so the block is spread over the CU's four SIMDs:
+//   * wave 0 runs the lane-private front part (control points, barycentric coordinates, M^T M);
+//   * all four waves rotate DISJOINT pairs of the 12x12 problem at the same time
+//     (jacobi_sweeps_coop: 21 barrier-separated stages instead of 66 sequential pairs, same bits);
+//   * waves 0..2 run epnp's three beta approximations (N = 1, 2, 3) side by side; wave 0 applies
+//     compute_pose's selection rule.
+// LDS: the lane-interleaved 12x12 image + the singular values (156 doubles per lane, 78 KB -- two
+// workgroups per CU); after the SVD the same area is the hand-over buffer and the three waves'
+// workspaces.  Two builds of the same body: the batched path launches thousands of blocks beside the
+// next batch's front end and gets 256 registers per wave (two waves per SIMD: a 512-register wave owns
+// a SIMD's register file and starves the kernels it overlaps -- ORB mode: +1 ms per 256 pairs); the
+// LATENCY build, for launches that leave the chip mostly empty (the online path: one pair's 64
+// hypotheses are all there is), takes all 512.
+constexpr size_t kPnpLdsBytes = (size_t)((144 + 12) * 64) * sizeof(double);
+__device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem_w)
 {
-    const int lane = threadIdx.x, b = blockIdx.y;
-    PnpState *st = a.state + b;
-    const int h = blockIdx.x * kHypBlock + lane;             // hypothesis index inside the phase
-    if (st->next_base != a.phase_base) return;               // phase not needed
-    if (blockIdx.x == gridDim.x - 1) {
-        // the drawer: subsets of the NEXT phase into the other buffer (see pnp_begin_kernel)
-        const int next = a.phase_base + a.phase_cap, niters = a.iterations > 1 ? a.iterations : 1;
-        const int n = st->n;
-        if (next < niters && n > 5 && st->phase_hyps > 0) {
-            const int more = niters - next < kPhaseHyps ? niters - next : kPhaseHyps;
-            const uint64_t rng = draw_subsets(st->rng, n, more, a.subsets + ((int64_t)b * 2 + (a.phase_index + 1) % 2) * kPhaseHyps * 5, lane);
-            if (lane == 0) st->rng = rng;
-        }
-        return;
-    }
-    if (blockIdx.x * kHypBlock >= st->phase_hyps) return;    // block beyond the phase
-    if (h >= st->phase_hyps) return;                         // EPnP is lane-private: idle lanes just leave
-    const float *X3 = a.X3 + (int64_t)b * a.stride * 3;
-    const float2 *img = a.img + (int64_t)b * a.stride;
-    const int *my = a.subsets + (((int64_t)b * 2 + a.phase_index % 2) * kPhaseHyps + h) * 5;
-    const double fx = a.fx, fy = a.fy, cx = a.cx, cy = a.cy;
-    // PnPRansacCallback::runKernel: solvePnP(EPNP) on the 5 samples
-    Epnp5 e;
-    e.fu = fx; e.fv = fy; e.uc = cx; e.vc = cy;
-    for (int i = 0; i < 5; i++) {
-        const int s = my[i];
-        e.pws[3 * i] = (double)X3[3 * s]; e.pws[3 * i + 1] = (double)X3[3 * s + 1]; e.pws[3 * i + 2] = (double)X3[3 * s + 2];
-        const float2 m = img[s];
-        // undistortPoints (float output, zero distortion), then epnp::init_points' x*fu + uc
-        const float xn = (float)(((double)m.x - cx) * (1. / fx));
-        const float yn = (float)(((double)m.y - cy) * (1. / fy));
-        e.us[2 * i] = (double)xn * fx + cx;
-        e.us[2 * i + 1] = (double)yn * fy + cy;
-    }
-    PnpHyp out;
-    epnp5_d(e, pnp_smem + lane, 64, out.R, out.t);
-    a.hyp[(int64_t)b * kPhaseHyps + h] = out;
-}
-
-// Two builds.  The batched path launches thousands of hypothesis blocks beside the next batch's front
-// end: one wave per block, 256 registers (two waves per SIMD) -- a 512-register wave owns a whole SIMD's
-// register file and starves the kernels it overlaps (ORB mode: +1 ms per 256 pairs).
-// The LATENCY build is for launches that leave the chip mostly empty (the online path: one pair's 64
-// hypotheses are all there is).  There the block is VALU-issue bound on ONE SIMD (f64 instructions
-// issue every ~4.5 cycles; two thirds of them are the 66-pairs-per-sweep Jacobi SVD of the 12x12
-// M^T M), so the block gets four waves -- one per SIMD, 512 registers each: wave 0 runs the
-// lane-private parts, and all four rotate DISJOINT pairs of the 12x12 problem at the same time
-// (jacobi12_sweeps_coop: 21 barrier-separated stages instead of 66 sequential pairs, same bits).
-constexpr size_t kPnpCoopLdsBytes = (size_t)((144 + 12 + 57 + 64) * 64) * sizeof(double);   // image, W, hand-over, wave 2's workspace
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void pnp_hyp_kernel_wide(PnpArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) double pnp_smem_w[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
     PnpState *st = a.state + b;
     const int h = blockIdx.x * kHypBlock + lane;             // hypothesis index inside the phase
@@ -285,7 +244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     jacobi_sweeps_coop<12, 12, 4>(big, 64, W, 64, nullptr, 0, wave);
     if (wave == 3) return;
     // epnp's three beta approximations on waves 0..2: wave 0 hands its lane-private state over through LDS
-    double *xfer = pnp_smem_w + (144 + 12) * 64 + lane;      // 57 doubles per lane
+    double *xfer = pnp_smem_w + lane;                        // 57 doubles per lane: rows 0..4 of the image (rows 8..11 are still needed)
     if (wave == 0) {
         double d12[12];
         jacobi_finish_d<12, 12>(big, 64, d12, nullptr, 0, true);
@@ -304,15 +263,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     double v[48];
     epnp5_load_v_d(big, 64, v);
-    __syncthreads();                                         // the 12x12 image and the hand-over area are free now
+    __syncthreads();                                         // the whole area is free now
     PnpHyp out;
     double rep;
-    double *ws = wave == 0 ? big : wave == 1 ? big + 64 * 64 : pnp_smem_w + (144 + 12 + 57) * 64 + lane;   // 64 doubles per lane each
+    // workspaces: svd_solve of 6 x 4 / 6 x 3 / 6 x 5 (M*N + N*N doubles: 40, 27, 55), results from 122 on
+    double *ws = big + (wave == 0 ? 0 : wave == 1 ? 40 : 67) * 64;
     if (wave == 0) rep = epnp5_back_d<1>(e, v, ws, 64, out.R, out.t);
     else if (wave == 1) rep = epnp5_back_d<2>(e, v, ws, 64, out.R, out.t);
     else rep = epnp5_back_d<3>(e, v, ws, 64, out.R, out.t);
     if (wave) {
-        double *dst = xfer + (wave - 1) * 13 * 64;
+        double *dst = big + (122 + (wave - 1) * 13) * 64;
         for (int i = 0; i < 9; i++) dst[i * 64] = out.R[i];
         for (int i = 0; i < 3; i++) dst[(9 + i) * 64] = out.t[i];
         dst[12 * 64] = rep;
@@ -322,7 +282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // epnp::compute_pose: "N = 1; if (rep[2] < rep[1]) N = 2; if (rep[3] < rep[N]) N = 3"
 #pragma unroll
     for (int w = 1; w <= 2; w++) {
-        const double *src = xfer + (w - 1) * 13 * 64;
+        const double *src = big + (122 + (w - 1) * 13) * 64;
         if (src[12 * 64] < rep) {
             rep = src[12 * 64];
             for (int i = 0; i < 9; i++) out.R[i] = src[i * 64];
@@ -331,7 +291,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     if (active) a.hyp[(int64_t)b * kPhaseHyps + h] = out;
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void pnp_hyp_kernel(PnpArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void pnp_hyp_kernel_wide(PnpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double pnp_smem_w[];
+    pnp_hyp_body(a, pnp_smem_w);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pnp_hyp_kernel(PnpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double pnp_smem[];
     pnp_hyp_body(a, pnp_smem);
@@ -787,7 +752,7 @@ int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
     if (hipFuncSetAttribute((const void *)pnp_hyp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPnpLdsBytes) != hipSuccess ||
         hipFuncSetAttribute((const void *)pnp_hyp_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kPnpCoopLdsBytes) != hipSuccess)
+                            (int)kPnpLdsBytes) != hipSuccess)
         return SVO_ERR_HIP;
     if (hipFuncSetAttribute((const void *)pnp_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kRefitLdsBytes) != hipSuccess)
@@ -818,9 +783,9 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
         const int blocks = (hyps + kHypBlock - 1) / kHypBlock;
         a.phase_base = base; a.phase_cap = cap; a.phase_index = phase;
         if ((blocks + 1) * n_items <= 256)     // the chip is not full: latency matters, registers are free
-            hipLaunchKernelGGL(pnp_hyp_kernel_wide, dim3(blocks + 1, n_items), dim3(256), kPnpCoopLdsBytes, st, a);   // + the drawer
+            hipLaunchKernelGGL(pnp_hyp_kernel_wide, dim3(blocks + 1, n_items), dim3(256), kPnpLdsBytes, st, a);   // + the drawer
         else
-            hipLaunchKernelGGL(pnp_hyp_kernel, dim3(blocks + 1, n_items), dim3(64), kPnpLdsBytes, st, a);
+            hipLaunchKernelGGL(pnp_hyp_kernel, dim3(blocks + 1, n_items), dim3(256), kPnpLdsBytes, st, a);
         hipLaunchKernelGGL(pnp_score_kernel, dim3(blocks, n_items, zchunks), dim3(256), 0, st, a);
         hipLaunchKernelGGL(pnp_select_kernel, dim3(n_items), dim3(64), 0, st, a);
         base += cap;
