@@ -226,7 +226,7 @@ __device__ __forceinline__ int dot2_sv(uint32_t a, uint32_t b_uniform, int c)   
 }
 // `off` = byte offset of the lane's first J sample inside the slot's tile: (cy + row) * 40 + cx + seg * 7
 // (the slot part is one value broadcast from its control lane, the lane part a constant)
-// `vround` = 2^8 held in a VGPR: a VOP3P instruction can read ONE scalar operand, and that one is the
+// `vround` = 2^15 (the J rounding 2^8, scaled like the column words) held in a VGPR: a VOP3P instruction can read ONE scalar operand, and that one is the
 // slot's weight (an SGPR from v_readlane); a scalar rounding constant cost a v_mov per slot and iteration
 __device__ __forceinline__ void mismatch_slot(const uint32_t (&C)[8], uint32_t Wa, uint32_t Wb,
                                               const uint32_t (&IxP)[4], const uint32_t (&IyP)[4], int nIIx, int nIIy,
@@ -235,12 +235,12 @@ __device__ __forceinline__ void mismatch_slot(const uint32_t (&C)[8], uint32_t W
     int d[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) d[k] = dot2(C[k + 1], Wb, dot2_sv(C[k], Wa, vround));
-    // J samples d >> 9 (0 <= d < 2^22): bytes 1-2 of two sums side by side, then one packed shift
-    const u16x2 one = {1, 1};
+    // J samples = high halves of the sums (column words hold pixel << 7, vround = 2^15: (sum * 2^7) >> 16
+    // = sum >> 9, 0 <= sum < 2^22): two of them side by side with one v_perm
 #pragma unroll
     for (int m = 0; m < 4; m++) {
-        const uint32_t vp = m < 3 ? as_u32(as_u16x2(perm_b32((uint32_t)d[2 * m + 1], (uint32_t)d[2 * m], 0x06050201u)) >> one)
-                                  : (uint32_t)(d[6] >> (W_BITS - 5));
+        const uint32_t vp = m < 3 ? perm_b32((uint32_t)d[2 * m + 1], (uint32_t)d[2 * m], 0x07060302u)
+                                  : (uint32_t)d[6] >> 16;
         // the chains start from - sum(I * Ix), - sum(I * Iy) (see patch_slot); three-operand form for the
         // first link so that the constant is not copied into the accumulator first
         pb1 = m == 0 ? dot2_v(vp, IxP[m], nIIx) : dot2(vp, IxP[m], pb1);
@@ -269,8 +269,12 @@ __device__ __forceinline__ void tile_store_j(uint32_t *tile, const uint32_t (&r)
         if (lane + 64 * t < kJPairs * 7) {
             const uint32_t top = r[t][0], bot = r[t][1];
             uint32_t *d = tile + jq_dst[t];
-            d[0] = perm_b32(bot, top, 0x0c040c00u); d[kJColDw] = perm_b32(bot, top, 0x0c050c01u);
-            d[2 * kJColDw] = perm_b32(bot, top, 0x0c060c02u); d[3 * kJColDw] = perm_b32(bot, top, 0x0c070c03u);
+            // samples are stored as pixel << 7 (byte into the high byte of its half, one packed shift): the
+            // bilinear sums then come out scaled by 2^7 and "sum >> 9" is simply their high half
+            const u16x2 one = {1, 1};
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                d[c * kJColDw] = as_u32(as_u16x2(perm_b32(bot, top, 0x040c000cu + 0x01000100u * c)) >> one);
         }
     }
 }
@@ -296,7 +300,7 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
         const int i = lane + 64 * t;
         q_pr[t] = i / 7; q_dc4[t] = 4 * (i - q_pr[t] * 7); q_dst[t] = q_pr[t] * kQCols + q_dc4[t]; jq_dst[t] = q_dc4[t] * kJColDw + q_pr[t];
     }
-    int vround = 1 << (W_BITS - 5 - 1);
+    int vround = 1 << (W_BITS - 5 - 1 + 7);                   // rounding of the J samples, scaled like the column words
     asm volatile("" : "+v"(vround));                          // keep it in a VGPR (see mismatch_slot)
     status = 1;
     float nx = 0.f, ny = 0.f;                    // nextPts[i]
