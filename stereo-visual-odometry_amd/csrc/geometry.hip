@@ -23,10 +23,15 @@
 namespace svo {
 
 // ------------------------------------------------------------------------------------------
+struct PnpState;
+struct PnpBeginArgs { PnpState *state; int *counts; int *subsets; int iterations; };
+__device__ void pnp_begin_item(const PnpBeginArgs &a, int n, int b, int lane);
+
 struct TriArgs {
     double P1[12], P2[12];
     const float2 *x1, *x2; float *out3; int64_t stride;    // item b at + b*stride points
     const int *n_pts; int n_fixed;
+    int fuse_begin; PnpBeginArgs begin;                     // the batch pipeline: the last workgroup of an item starts its solvePnPRansac
 };
 
 // grid.x workgroups per item walk its points in strides (the launch is sized from the batch, not
@@ -35,7 +40,14 @@ __global__ __launch_bounds__(64) void triangulate_kernel(TriArgs a)
 {
     const int b = blockIdx.y;
     const int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
-    for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) {
+    const int gx = gridDim.x - a.fuse_begin;
+    if ((int)blockIdx.x == gx) {
+        // solvePnPRansac's per-item state and first point subsets depend on the point COUNT only: prepared
+        // here, beside the triangulation, instead of by a launch of their own (20 us of the online path)
+        pnp_begin_item(a.begin, n, b, threadIdx.x);
+        return;
+    }
+    for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gx * 64) {
         const int64_t o = (int64_t)b * a.stride + i;
         const float2 p1 = a.x1[o], p2 = a.x2[o];
         const double xs[2] = {(double)p1.x, (double)p2.x}, ys[2] = {(double)p1.y, (double)p2.y};
@@ -103,6 +115,7 @@ struct PnpArgs {
     PnpRecord *out;
     PnpState *state; PnpHyp *hyp; int *counts; int *subsets;   // per item: 1, kPhaseHyps, kPhaseHyps, 2 x 5 * kPhaseHyps
     int phase_base, phase_cap, phase_index;                 // hypotheses [phase_base, phase_base + phase_cap) in this phase
+    int score_chunk;                                        // points per scoring workgroup (grid.z chunks)
     int refit_svd;                                          // 1: always take the SVD route of the refit's solves (SVO_REFIT_SVD=1; tests)
 };
 
@@ -161,10 +174,8 @@ __device__ inline uint64_t draw_subsets(uint64_t rng_in, int n, int count, int *
 // Subsets are double-buffered by phase parity: while the EPnP blocks of phase p run, one extra
 // workgroup of the same launch draws the subsets phase p+1 would need (they depend on the RNG state
 // only, not on the selection), so the serial drawing never sits on the critical path.
-__global__ __launch_bounds__(64) void pnp_begin_kernel(PnpArgs a)
+__device__ void pnp_begin_item(const PnpBeginArgs &a, int n, int b, int lane)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
     PnpState *st = a.state + b;
     int *counts = a.counts + (int64_t)b * kPhaseHyps;
     for (int i = lane; i < kPhaseHyps; i += 64) counts[i] = 0;
@@ -182,6 +193,11 @@ __global__ __launch_bounds__(64) void pnp_begin_kernel(PnpArgs a)
     st->max_good = 0; st->best_iter = -1; st->iters_done = 0; st->next_base = 0;
     st->phase_hyps = hyps;
     st->rng = rng;
+}
+__global__ __launch_bounds__(64) void pnp_begin_kernel(PnpArgs a)
+{
+    const PnpBeginArgs ba{a.state, a.counts, a.subsets, a.iterations};
+    pnp_begin_item(ba, a.n_pts ? a.n_pts[blockIdx.x] : a.n_fixed, blockIdx.x, threadIdx.x);
 }
 
 // One workgroup = 64 hypotheses (lane = hypothesis) and FOUR waves.  A lane-private EPnP is VALU-issue
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(PnpArgs a)
     const int n = st->n;
     const int h = blockIdx.x * kHypBlock + lane;
     if (st->next_base != a.phase_base || blockIdx.x * kHypBlock >= st->phase_hyps || n <= 5) return;
-    const int i0 = blockIdx.z * kScoreChunk, i1 = min(n, i0 + kScoreChunk);
+    const int i0 = blockIdx.z * a.score_chunk, i1 = min(n, i0 + a.score_chunk);
     if (i0 >= n) return;
     const float *X3 = a.X3 + (int64_t)b * a.stride * 3;
     const float2 *img = a.img + (int64_t)b * a.stride;
@@ -763,7 +779,7 @@ int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
 
 // The launch sequence of one solvePnPRansac for n_items items (see the kernel comments above).
 // max_pts bounds the points of any item (grid.z of the scoring kernel).
-static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pts, hipStream_t st)
+static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pts, hipStream_t st, bool begun = false)
 {
     const svo_config &cfg = ctx->cfg;
     char *ws = (char *)ctx->pnp_ws;
@@ -773,9 +789,12 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
     a.hyp = (PnpHyp *)(ws + ws_off_hyp(cfg, B));
     a.counts = (int *)(ws + ws_off_counts(cfg, B));
     a.subsets = (int *)(ws + ws_off_subsets(cfg, B));
-    hipLaunchKernelGGL(pnp_begin_kernel, dim3(n_items), dim3(64), 0, st, a);
+    if (!begun) hipLaunchKernelGGL(pnp_begin_kernel, dim3(n_items), dim3(64), 0, st, a);
     const int niters = a.iterations > 1 ? a.iterations : 1;
-    const int zchunks = max_pts > 0 ? (max_pts + kScoreChunk - 1) / kScoreChunk : 1;
+    // 1024 points per scoring workgroup; a launch that leaves the chip mostly empty (the online path) takes
+    // 256 (one staging pass, four times the workgroups: 36 -> 12 us for a pair's 2.4 k points)
+    a.score_chunk = n_items <= 4 ? 256 : kScoreChunk;
+    const int zchunks = max_pts > 0 ? (max_pts + a.score_chunk - 1) / a.score_chunk : 1;
     int phase = 0;
     for (int base = 0; base < niters; phase++) {
         const int cap = base == 0 ? kHypBlock : kPhaseHyps;
@@ -803,11 +822,19 @@ void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const floa
     memcpy(a.P2, ctx->cfg.P2, sizeof(a.P2));
     a.x1 = x1; a.x2 = x2; a.out3 = ctx->X3; a.stride = ctx->cfg.max_keypoints;
     a.n_pts = n_pts; a.n_fixed = n_fixed;
-    if (max_pts <= 0) return;
     int gx = (8192 + n_items - 1) / n_items;                 // ~8 k workgroups per launch
     gx = gx < 2 ? 2 : gx;
     gx = gx > (max_pts + 63) / 64 ? (max_pts + 63) / 64 : gx;
-    hipLaunchKernelGGL(triangulate_kernel, dim3(gx, n_items), dim3(64), 0, ctx->stream, a);
+    gx = gx < 0 ? 0 : gx;
+    // + one workgroup per item that prepares the item's solvePnPRansac (launch_pnp_batch follows on every path)
+    char *ws = (char *)ctx->pnp_ws;
+    const int B = ctx->cfg.max_batch;
+    a.fuse_begin = 1;
+    a.begin.state = (PnpState *)(ws + ws_off_state(ctx->cfg, B));
+    a.begin.counts = (int *)(ws + ws_off_counts(ctx->cfg, B));
+    a.begin.subsets = (int *)(ws + ws_off_subsets(ctx->cfg, B));
+    a.begin.iterations = ctx->cfg.iterations;
+    hipLaunchKernelGGL(triangulate_kernel, dim3(gx + 1, n_items), dim3(64), 0, ctx->stream, a);
 }
 
 void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n_pts, int n_fixed, hipStream_t st)
@@ -820,7 +847,7 @@ void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n
     a.iterations = ctx->cfg.iterations; a.reproj_err = ctx->cfg.reproj_err;
     a.confidence = (double)ctx->cfg.confidence;
     a.mask = (uint8_t *)ctx->pnp_ws + ws_off_mask(ctx->cfg.max_batch);
-    launch_pnp_pipeline(ctx, a, n_items, ctx->cfg.max_keypoints, st);
+    launch_pnp_pipeline(ctx, a, n_items, ctx->cfg.max_keypoints, st, /*begun by launch_triangulate_batch*/ true);
 }
 
 void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur, const int *ovf,
