@@ -482,8 +482,10 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
             // the sum lands within 1e-4 relative of epsilon (float error here < 2e-7 relative)
             const float dd = dlx * dlx + dly * dly;
             bool conv = dd <= 0.9999e-4f;
-            if (__any(it_on && !conv && dd < 1.0001e-4f))
+            if (__builtin_expect(__any(it_on && !conv && dd < 1.0001e-4f), 0)) {
+                asm volatile("" ::: "memory");               // a real branch: if-converted, the f64 path ran every iteration
                 conv = (double)dlx * (double)dlx + (double)dly * (double)dly <= 0.01 * 0.01;
+            }
             if (it_on) {
                 qx += dlx; qy += dly;
                 nx = qx + half; ny = qy + half;
