@@ -5,29 +5,30 @@
 // (reference src/tracking.cpp:583-622), plus the deleteBadmatchFeatures predicate (:623-660).
 //
 // Mapping: ONE WAVEFRONT TRACKS FOUR POINTS ("slots"), four waves per workgroup, no workgroup
-// barrier.  The kernel is VALU-issue bound (rocprofv3: ~100 % VALU busy, tiles come from L2), and
-// more than half of a one-point-per-wave iteration is per-point SCALAR work (window position,
-// bilinear weights, 2x2 solve, convergence tests) that a wave executes as full vector
-// instructions.  Here that scalar work is done once for four points: lane l carries the control
-// state of slot l >> 4 (its row of 16 lanes), so one vector instruction advances all four points, while the pixel
-// work is done slot after slot by all 63 pixel lanes:
+// barrier.  The kernel is VALU-issue bound (tiles come from L2), and more than half of a
+// one-point-per-wave iteration is per-point SCALAR work (window position, bilinear weights, 2x2
+// solve, convergence tests) that a wave executes as full vector instructions.  Here that scalar work
+// is done once for four points: lane l carries the control state of slot l >> 4 (its row of 16
+// lanes), so one vector instruction advances all four points, while the pixel work is done slot
+// after slot by all 63 pixel lanes:
 //   * lane l owns window row l/3, columns (l%3)*7..+6 of EVERY slot (63 lanes x 7 px = 441 px);
-//   * per level, per slot: the 24x24 source tile of I is gathered into LDS with 4-byte aligned
-//     loads; the lane reads its 4 rows x 10 bytes as row-pair COLUMN WORDS, forms the Scharr
-//     derivatives of the 2x8 positions it interpolates from ON THE FLY with packed 16-bit math (the
-//     reference path materialises a full int16x2 derivative image per level per call), interpolates
-//     I, Ix, Iy with v_dot2_i32_i16 and keeps the patch as 12 packed VGPRs per slot;
-//   * per iteration, per active slot: two 8-byte J row segments from a 40x32 LDS tile (re-gathered
-//     only when the window drifts out of it) become eight column words, a four-tap bilinear sample
-//     is two v_dot2_i32_i16 (signed 16-bit weight pairs), then packed differences and v_dot2
-//     mismatch sums;
+//   * tiles live in LDS as ROW-PAIR COLUMN WORDS (pixel[r][c] | pixel[r+1][c] << 16), formed once while
+//     staging (4 v_perm per source dword pair): exactly the operand of the bilinear v_dot2_i32_i16, so
+//     neither the patch build nor an iteration spends an instruction on byte alignment or unpacking;
+//   * per level, per slot: the 24x28 I tile (requested one level ahead); the lane reads its 3 row pairs x
+//     10 columns, forms the Scharr derivatives of the 2x8 positions it interpolates from ON THE FLY with
+//     packed 16-bit math (the reference path materialises a full int16x2 derivative image per level
+//     per call), interpolates I, Ix, Iy with v_dot2_i32_i16 and keeps the patch as 12 packed VGPRs;
+//   * per iteration, per active slot: eight conflict-free dword reads from a column-major 27x28 J tile
+//     (re-staged only when the window drifts out of it; requested beside the patch arithmetic), a
+//     four-tap bilinear sample is two v_dot2_i32_i16 (signed 16-bit weight pairs; the words hold
+//     pixel << 7, so the sample is the high half of its sum), then v_dot2 mismatch sums;
 //   * the 16 partial sums of an iteration (4 slots x {b1,b2} x {low,high half}) are reduced with ONE
-//     reduce-scatter (DPP quad/row exchanges + v_permlane16/32_swap) that leaves slot s's four
-//     sums in quad s, exactly where that slot's control lanes need them.
+//     reduce-scatter over the rows (v_permlane32/16_swap + add, then DPP inside the row) that leaves
+//     slot s's four sums in every quad of row s, exactly where that slot's control lanes need them.
 // With ncalls == 4 the wave walks the whole circular chain L1 -> R1 -> R2 -> L2 -> L1' for its
-// four points and stops early once all of them are rejected.  The kernel is built for FOUR waves
-// per SIMD (128 VGPRs; the handful of spills sit outside the level and iteration loops): at three
-// waves it was 90 % VALU-busy, at four 97 %.
+// four points and stops early once all of them are rejected.  The column-word J tiles cost 4x the
+// LDS of byte tiles (52 KB per workgroup): three waves per SIMD, 168 VGPRs.
 //
 // Exactness: all pixel arithmetic is upstream's fixed point (14-bit weights, 5 fractional bits);
 // the five sums A11,A12,A22,b1,b2 are accumulated as exact integers (per-lane int32 partials,

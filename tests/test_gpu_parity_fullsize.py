@@ -130,6 +130,29 @@ def test_lk_whole_steps_low_inlier_ratio_many_ransac_rounds(pkg, oracle, tc, kit
     _check_online_lk(pkg, oracle, seq, frames[:3], ref, reproj_err=0.05)
 
 
+def test_lk_whole_steps_dense_corners_two_points_per_wave(pkg, oracle, tc, kitti):
+    """A low FAST threshold gives a pair several thousand corners: the online launch then packs two or three
+    points into a wave (lk_kernel spreads a single pair's points over the resident waves, one per wave up
+    to 3072 points), and a batch of four pairs takes the ordinary four-points-per-wave path."""
+    seq, frames = kitti
+    thr = 8
+    n0 = len(oracle.fast(frames[0][0], thr=thr))
+    assert 3500 <= n0 <= 16000
+    ref = _oracle_lk_steps(oracle, seq, frames[:3], fast_thr=thr)
+    _check_online_lk(pkg, oracle, seq, frames[:3], ref, fast_threshold=thr, max_keypoints=16384)
+    h, w = frames[0][0].shape
+    P1, P2 = seq.proj()
+    c = pkg.Context(w, h, device=0, P1=P1, P2=P2, max_batch=4, fast_threshold=thr, max_keypoints=16384)
+    fr5 = [frames[0], frames[1], frames[2], frames[1], frames[2]]     # pairs (0,1), (1,2), (2,1), (1,2): four items
+    L = tc.stack([tc.from_numpy(f[0]) for f in fr5]).cuda()
+    R = tc.stack([tc.from_numpy(f[1]) for f in fr5]).cuda()
+    res = c.track_batch(L, R)
+    for p in (0, 1):
+        _check_record(res[p], ref[p][0], ref[p][2])
+    assert res[3]["T_rel_inv"].tobytes() == res[1]["T_rel_inv"].tobytes()     # the same pair again: the same bits
+    c.close()
+
+
 def test_lk_whole_step_hd_stress_size(pkg, oracle, tc, synth):
     """BASELINE config #4: 1920x1080, FAST threshold raised so that a frame has about 2000 corners."""
     seq, frames = _render(synth, tc, 1920, 1080, 3, 1)
