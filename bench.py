@@ -307,7 +307,7 @@ def main():
             cf_ms = stage_ms["orb_cellfast"]
             alg_bytes = int(3.09 * W * H * 2 * (B + 1))
             achieved = alg_bytes / (cf_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "orb_cellfast_kernel (8 launches per step, one per pyramid level)",
+            out["roofline"] = {"bound": "hbm", "kernel": "orb_cellfast_kernel (one launch per step over all pyramid levels)",
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                                "launch_ms": round(cf_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}

@@ -41,12 +41,24 @@ __global__ __launch_bounds__(256) void orb_copy0_kernel(OrbGeom g, const uint8_t
     else for (int q = 0; q < 16 && x + q < w; q++) dst[q] = src[q];
 }
 
-__global__ __launch_bounds__(256) void orb_border_kernel(OrbGeom g, uint8_t *slots, int64_t slot_stride, int l)
+// One launch serves ALL pyramid levels where the per-level work is independent (borders, blur, cell FAST):
+// eight short launches per step each paid their own ramp-up and tail.  The level of a block is the last
+// one whose first block is not beyond it (wave-uniform: a scalar loop over <= 8 entries).
+constexpr int kBlurRowsPerThread = 28;
+__device__ __forceinline__ int level_of_block(const int *first, int nlevels, int blk)
+{
+    int l = 0;
+    for (int k = 1; k < nlevels; k++) l = blk >= first[k] ? k : l;
+    return l;
+}
+
+__global__ __launch_bounds__(256) void orb_border_kernel(OrbGeom g, uint8_t *slots, int64_t slot_stride)
 {
     const int b = blockIdx.y;
+    const int l = level_of_block(g.border_blk, g.nlevels, blockIdx.x);
     const int w = g.w[l], h = g.h[l], pitch = g.pitch[l];
     uint8_t *lvl = slots + (int64_t)b * slot_stride + g.origin[l];
-    const int gidx = blockIdx.x;
+    const int gidx = blockIdx.x - g.border_blk[l];
     if (gidx < 2 * kPad) {
         const int py = gidx < kPad ? gidx - kPad : h + (gidx - kPad);
         const uint8_t *src = lvl + (int64_t)refl101(py, h) * pitch;
@@ -164,10 +176,11 @@ __device__ __forceinline__ int fast_cornerness(const uint8_t *c, int P)
 }
 
 // One workgroup per cell (grid.x = cell, grid.y = level-local unused, grid.z = image).
-__global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint8_t *slots, int64_t slot_stride, int l,
+__global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint8_t *slots, int64_t slot_stride,
                                                            int iniTh, int minTh, float4 *cell_cand, int *cell_cnt,
                                                            int64_t cand_img_stride, int64_t cnt_img_stride)
 {
+    const int l = level_of_block(g.cell_off, g.nlevels, blockIdx.x);      // blockIdx.x = cell index over all levels
     // dynamic LDS: three byte planes + the position list, kCellMax columns x (hCell + 6) rows of THIS
     // level (a static 66 x 66 worst case would cost 21.8 KB and starve the kernel of workgroups
     // while the previous batch's pose solver holds 74 KB per CU)
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
     uint8_t *raw = cf_smem, *V = cf_smem + plane, *keep = cf_smem + 2 * plane;
     uint16_t *list = (uint16_t *)(cf_smem + 3 * plane);
     __shared__ int s_any, s_found, s_nlist, s_ncand, s_run, s_wtot[4];
-    const int b = blockIdx.z, cell = blockIdx.x;
+    const int b = blockIdx.z, cell = blockIdx.x - g.cell_off[l];
     const int W = g.w[l], H = g.h[l], pitch = g.pitch[l];
     const int minBX = 16, minBY = 16, maxBX = W - 16, maxBY = H - 16;
     const int nCols = g.nCols[l], wCell = g.wCell[l], hCell = g.hCell[l];
@@ -792,14 +805,15 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
 // v_dot4_u32_u8 each on byte windows cut from three aligned dwords (the level's stored reflect-101
 // frame IS the blur's border); the seven most recent row sums slide through registers for the
 // column pass (28-row band), so neither the int intermediate image nor a second launch exists.
-constexpr int kBlurRows = 28;     // 4 x 7: the row ring rotates with static indices
-__global__ __launch_bounds__(256) void orb_blur_kernel(OrbGeom g, const uint8_t *slots, int64_t slot_stride, int l,
+constexpr int kBlurRows = kBlurRowsPerThread;     // 4 x 7: the row ring rotates with static indices
+__global__ __launch_bounds__(256) void orb_blur_kernel(OrbGeom g, const uint8_t *slots, int64_t slot_stride,
                                                        uint8_t *blur, int64_t blur_img_stride)
 {
     const int b = blockIdx.z;
+    const int l = level_of_block(g.blur_blk, g.nlevels, blockIdx.y);      // blockIdx.y = row band over all levels
     const int w = g.w[l], h = g.h[l], pitch = g.pitch[l];
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y0 = (blockIdx.y * 4 + threadIdx.y) * kBlurRows;
+    const int y0 = ((blockIdx.y - g.blur_blk[l]) * 4 + threadIdx.y) * kBlurRows;
     if (x0 >= w || y0 >= h) return;
     const uint8_t *src = slots + (int64_t)b * slot_stride + g.origin[l] + x0 - 4;
     uint8_t *dst = blur + (int64_t)b * blur_img_stride + g.blur_off[l] + x0;
@@ -1180,6 +1194,15 @@ int orb_make_geom(const svo_config &cfg, OrbGeom *g)
     g->slot_bytes = off;
     g->blur_total = boff;
     g->cells_total = coff;
+    {
+        int bb = 0, yb = 0;
+        for (int l = 0; l < nlevels; l++) {
+            g->border_blk[l] = bb; g->blur_blk[l] = yb;
+            bb += 2 * kPad + (g->h[l] + 3) / 4;
+            yb += (g->h[l] + 4 * kBlurRowsPerThread - 1) / (4 * kBlurRowsPerThread);
+        }
+        for (int l = nlevels; l <= kOrbMaxLevels; l++) { g->border_blk[l] = bb; g->blur_blk[l] = yb; }
+    }
     int xo = 0, yo = 0;
     for (int l = 0; l < nlevels; l++) { g->xtab_off[l] = xo; g->ytab_off[l] = yo; if (l > 0) { xo += g->w[l]; yo += g->h[l]; } }
     g->xtab_total = xo; g->ytab_total = yo;
@@ -1321,24 +1344,26 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
                                (size_t)cap_rows * row_dw * 4, st, g, slots, g.slot_bytes, l,
                                (const int2 *)ctx->orb_xtab, (const int4 *)ctx->orb_ytab, cap_rows, row_dw);
         }
-        hipLaunchKernelGGL(orb_border_kernel, dim3(2 * kPad + (g.h[l] + 3) / 4, n_img), blk, 0, st, g, slots, g.slot_bytes, l);
     }
+    // borders of all levels in one launch (cv::resize clamps its taps to the image, so no level waits for a border)
+    hipLaunchKernelGGL(orb_border_kernel, dim3(g.border_blk[L], n_img), blk, 0, st, g, slots, g.slot_bytes);
     // the blurred levels only depend on the pyramid: computed here, before the LDS-hungry kernels,
     // so that in overlap mode the previous batch's pose solver (74 KB of LDS per workgroup) runs
     // beside kernels that need no LDS
     uint8_t *blur = ctx->orb_blur + (size_t)slot0 * g.blur_total;
-    for (int l = 0; l < L; l++)
-        hipLaunchKernelGGL(orb_blur_kernel, dim3((g.w[l] + 255) / 256, (g.h[l] + 4 * kBlurRows - 1) / (4 * kBlurRows), n_img),
-                           dim3(64, 4), 0, st, g, slots, g.slot_bytes, l, blur, g.blur_total);
+    hipLaunchKernelGGL(orb_blur_kernel, dim3((g.w[0] + 255) / 256, g.blur_blk[L], n_img), dim3(64, 4), 0, st, g, slots, g.slot_bytes,
+                       blur, g.blur_total);
     timing_mark(ctx, "orb_pyramid");
     float4 *cell_cand = ctx->orb_cell_cand + (size_t)slot0 * g.cells_total * kCellCap;
     int *cell_cnt = ctx->orb_cell_cnt + (size_t)slot0 * g.cells_total;
-    for (int l = 0; l < L; l++)
-        if (g.ncell[l] > 0)
-            hipLaunchKernelGGL(orb_cellfast_kernel, dim3(g.ncell[l], 1, n_img), blk,
-                               (size_t)5 * ((kCellPitch * (g.hCell[l] + 6) + 15) & ~15), st, g, slots, g.slot_bytes, l,
-                               ctx->cfg.orb_ini_th, ctx->cfg.orb_min_th, cell_cand, cell_cnt,
+    {
+        int hmax = 0;
+        for (int l = 0; l < L; l++) if (g.ncell[l] > 0 && g.hCell[l] > hmax) hmax = g.hCell[l];
+        if (g.cells_total > 0)
+            hipLaunchKernelGGL(orb_cellfast_kernel, dim3(g.cells_total, 1, n_img), blk, (size_t)5 * ((kCellPitch * (hmax + 6) + 15) & ~15), st,
+                               g, slots, g.slot_bytes, ctx->cfg.orb_ini_th, ctx->cfg.orb_min_th, cell_cand, cell_cnt,
                                (int64_t)g.cells_total * kCellCap, (int64_t)g.cells_total);
+    }
     float4 *lvl_cand = ctx->orb_lvl_cand + (size_t)slot0 * L * kCandCap;
     int *lvl_cnt = ctx->orb_lvl_cnt + (size_t)slot0 * L;
     hipLaunchKernelGGL(orb_gather_kernel, dim3(L, n_img), blk, 0, st, g, cell_cand, cell_cnt, (int64_t)g.cells_total * kCellCap,
