@@ -674,7 +674,10 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
     extern __shared__ __attribute__((aligned(16))) uint8_t qt_smem[];
     QLds L = qlds_carve(qt_smem, a.node_cap);
     const int lane = threadIdx.x;
-    const int l = blockIdx.x, b = blockIdx.y, inst = b * a.g.nlevels + l;
+    // workgroups are dispatched in index order: all level-0 instances (the longest: the largest quota) first,
+    // the short top levels last, so the tail of the launch is made of short instances (longest-first packing;
+    // with the level as the fast index the last round waited for level-0 trees: 2.4 ms instead of 1.3)
+    const int b = blockIdx.x, l = blockIdx.y, inst = b * a.g.nlevels + l;
     const int nkeys = a.lvl_cnt[inst];
     const float4 *cand = a.lvl_cand + (int64_t)inst * a.cand_cap;
     int *sel = a.sel + (int64_t)inst * a.sel_cap;
@@ -1375,7 +1378,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     d.sel = ctx->orb_sel + (size_t)slot0 * L * ctx->orb_node_cap; d.sel_cnt = ctx->orb_sel_cnt + (size_t)slot0 * L; d.sel_cap = ctx->orb_node_cap;
     d.overflow = ovf;
     d.node_cap = ctx->orb_node_cap;
-    hipLaunchKernelGGL(orb_distribute_kernel, dim3(L, n_img), dim3(64), qlds_bytes(ctx->orb_node_cap), st, d);
+    hipLaunchKernelGGL(orb_distribute_kernel, dim3(n_img, L), dim3(64), qlds_bytes(ctx->orb_node_cap), st, d);
     timing_mark(ctx, "orb_quadtree");
     OrbDescArgs e{};
     e.g = g; e.slots = slots; e.slot_stride = g.slot_bytes; e.blur = blur; e.blur_img_stride = g.blur_total;
