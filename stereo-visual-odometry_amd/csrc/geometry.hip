@@ -216,6 +216,7 @@ __global__ __launch_bounds__(64) void pnp_begin_kernel(PnpArgs a)
 // LATENCY build, for launches that leave the chip mostly empty (the online path: one pair's 64
 // hypotheses are all there is), takes all 512.
 constexpr size_t kPnpLdsBytes = (size_t)((144 + 12) * 64) * sizeof(double);
+constexpr size_t kPnpLdsBytesBeside = 84 * 1000;           // > 80 KB: one workgroup per CU (see launch_pnp_pipeline)
 __device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem_w)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
@@ -766,7 +767,7 @@ int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
 {
     // called once per context at creation: the EPnP and refit kernels need more dynamic LDS than the default limit
     if (hipFuncSetAttribute((const void *)pnp_hyp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kPnpLdsBytes) != hipSuccess ||
+                            (int)kPnpLdsBytesBeside) != hipSuccess ||
         hipFuncSetAttribute((const void *)pnp_hyp_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPnpLdsBytes) != hipSuccess)
         return SVO_ERR_HIP;
@@ -804,7 +805,14 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
         if ((blocks + 1) * n_items <= 256)     // the chip is not full: latency matters, registers are free
             hipLaunchKernelGGL(pnp_hyp_kernel_wide, dim3(blocks + 1, n_items), dim3(256), kPnpLdsBytes, st, a);   // + the drawer
         else
-            hipLaunchKernelGGL(pnp_hyp_kernel, dim3(blocks + 1, n_items), dim3(256), kPnpLdsBytes, st, a);
+        {
+            // On the side stream (overlap mode) the blocks run beside the next batch's front end: two of them
+            // per CU would hold 156 of its 160 KB of LDS and lock out every front-end kernel that stages
+            // through LDS (ORB mode: the resize chain stalled for the whole hypothesis kernel, 1.7 ms per 256
+            // pairs).  Asking for a little over half of the LDS keeps it to ONE block per CU there.
+            const size_t lds = st != ctx->stream ? kPnpLdsBytesBeside : kPnpLdsBytes;
+            hipLaunchKernelGGL(pnp_hyp_kernel, dim3(blocks + 1, n_items), dim3(256), lds, st, a);
+        }
         hipLaunchKernelGGL(pnp_score_kernel, dim3(blocks, n_items, zchunks), dim3(256), 0, st, a);
         hipLaunchKernelGGL(pnp_select_kernel, dim3(n_items), dim3(64), 0, st, a);
         base += cap;
