@@ -28,11 +28,14 @@ __device__ __forceinline__ const uint8_t *src_image(const PyrArgs &a, int b)
 
 __global__ __launch_bounds__(256) void pyr_copy0_kernel(PyrArgs a)
 {
-    const int b = blockIdx.z, y = blockIdx.y;
+    // block = (lanes per row, rows): a KITTI row is 78 sixteen-byte chunks, so one row per 256-thread
+    // workgroup left two thirds of it idle and the launch bound by workgroup turnaround
+    const int b = blockIdx.z, y = blockIdx.y * blockDim.y + threadIdx.y;
     const int w = a.g.w[0];
+    if (y >= a.g.h[0]) return;
     const uint8_t *src = src_image(a, b) + (int64_t)y * a.pitch;
     uint8_t *dst = a.slots + (int64_t)b * a.slot_stride + a.g.origin[0] + (int64_t)y * a.g.pitch[0];
-    const int x = (blockIdx.x * 256 + threadIdx.x) * 16;
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
     if (x >= w) return;
     if (x + 16 <= w && ((uintptr_t)(src + x) & 15) == 0) {
         *(uint4 *)(dst + x) = *(const uint4 *)(src + x);          // dst rows are 32-byte aligned
@@ -44,6 +47,7 @@ __global__ __launch_bounds__(256) void pyr_copy0_kernel(PyrArgs a)
 // frame of level l: every padded position outside the interior copies its reflect-101 source.
 // Workgroup g < 2*kPad handles one full top/bottom frame row; the others handle four interior
 // rows each (64 lanes = the 2 x 32 side bytes of a row), so no workgroup is launched for nothing.
+constexpr int kBorderRows = 16;              // interior rows whose side bytes one workgroup writes
 __global__ __launch_bounds__(256) void pyr_border_kernel(PyrArgs a, int l)
 {
     const int b = blockIdx.y;
@@ -51,30 +55,41 @@ __global__ __launch_bounds__(256) void pyr_border_kernel(PyrArgs a, int l)
     uint8_t *lvl = a.slots + (int64_t)b * a.slot_stride + a.g.origin[l];
     const int gidx = blockIdx.x;
     if (gidx < 2 * kPad) {
+        // a full frame row, four bytes per thread (the padded row starts 4-byte aligned)
         const int py = gidx < kPad ? gidx - kPad : h + (gidx - kPad);
         const uint8_t *src = lvl + (int64_t)refl101(py, h) * pitch;
         uint8_t *dst = lvl + (int64_t)py * pitch;
-        for (int px = (int)threadIdx.x - kPad; px < w + kPad; px += 256) dst[px] = src[refl101(px, w)];
+        for (int px = ((int)threadIdx.x << 2) - kPad; px < w + kPad; px += 1024) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v |= (uint32_t)src[refl101(min(px + q, w + kPad - 1), w)] << (8 * q);
+            if (px + 4 <= w + kPad) *(uint32_t *)(dst + px) = v;
+            else for (int q = 0; px + q < w + kPad; q++) dst[px + q] = (uint8_t)(v >> (8 * q));
+        }
     } else {
-        const int py = (gidx - 2 * kPad) * 4 + (threadIdx.x >> 6);
-        if (py >= h) return;
         const int t = threadIdx.x & 63;
         const int px = t < kPad ? t - kPad : w + (t - kPad);
-        uint8_t *row = lvl + (int64_t)py * pitch;
-        row[px] = row[refl101(px, w)];
+        const int sx = refl101(px, w);
+        for (int r = threadIdx.x >> 6; r < kBorderRows; r += 4) {
+            const int py = (gidx - 2 * kPad) * kBorderRows + r;
+            if (py >= h) return;
+            uint8_t *row = lvl + (int64_t)py * pitch;
+            row[px] = row[sx];
+        }
     }
 }
 
 // level l (>= 1) interior from level l-1: thread -> 4 consecutive output pixels
 __global__ __launch_bounds__(256) void pyr_down_kernel(PyrArgs a, int l)
 {
-    const int b = blockIdx.z, y = blockIdx.y;
+    const int b = blockIdx.z, y = blockIdx.y * blockDim.y + threadIdx.y;     // block = (lanes per row, rows)
     const int w = a.g.w[l];
+    if (y >= a.g.h[l]) return;
     const int sp = a.g.pitch[l - 1];
     uint8_t *slot = a.slots + (int64_t)b * a.slot_stride;
     const uint8_t *src = slot + a.g.origin[l - 1];
     uint8_t *dst = slot + a.g.origin[l] + (int64_t)y * a.g.pitch[l];
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (x0 >= w) return;
     // source columns 2*x0-2 .. 2*x0+8, fetched as the 4 aligned dwords starting at 2*x0-4
     // (x0 % 4 == 0 and the level origin is 32-byte aligned, so 2*x0-4 is 4-byte aligned; the
@@ -117,16 +132,24 @@ __global__ __launch_bounds__(256) void pyr_read_level_kernel(PyrGeom g, const ui
 void launch_pyramid(const PyrArgs &a, int batch, hipStream_t st)
 {
     dim3 blk(256, 1, 1);
+    // a block of up to 256 threads = (lanes a row needs, as many rows as fit)
+    auto shape = [](int lanes_per_row, int rows, dim3 &grid, dim3 &block, int batch) {
+        const int bx = lanes_per_row < 256 ? lanes_per_row : 256, by = 256 / bx;
+        block = dim3(bx, by, 1);
+        grid = dim3((lanes_per_row + bx - 1) / bx, (rows + by - 1) / by, batch);
+    };
     {
-        dim3 g((a.g.w[0] + 4095) / 4096, a.g.h[0], batch);
-        hipLaunchKernelGGL(pyr_copy0_kernel, g, blk, 0, st, a);
+        dim3 g, bk;
+        shape((a.g.w[0] + 15) / 16, a.g.h[0], g, bk, batch);
+        hipLaunchKernelGGL(pyr_copy0_kernel, g, bk, 0, st, a);
     }
     for (int l = 0; l < a.g.nlevels; l++) {
         if (l > 0) {
-            dim3 g((a.g.w[l] + 1023) / 1024, a.g.h[l], batch);
-            hipLaunchKernelGGL(pyr_down_kernel, g, blk, 0, st, a, l);
+            dim3 g, bk;
+            shape((a.g.w[l] + 3) / 4, a.g.h[l], g, bk, batch);
+            hipLaunchKernelGGL(pyr_down_kernel, g, bk, 0, st, a, l);
         }
-        dim3 gb(2 * kPad + (a.g.h[l] + 3) / 4, batch, 1);
+        dim3 gb(2 * kPad + (a.g.h[l] + kBorderRows - 1) / kBorderRows, batch, 1);
         hipLaunchKernelGGL(pyr_border_kernel, gb, blk, 0, st, a, l);
     }
 }
