@@ -32,9 +32,10 @@ __constant__ signed char c_pattern[1024];
 __global__ __launch_bounds__(256) void orb_copy0_kernel(OrbGeom g, const uint8_t *img, int pitch, int64_t img_stride,
                                                         uint8_t *slots, int64_t slot_stride)
 {
-    const int b = blockIdx.z, y = blockIdx.y, x = (blockIdx.x * 256 + threadIdx.x) * 16;
+    // block = (16-byte lanes a row needs, rows that fit 256 threads): one row per workgroup left most of it idle
+    const int b = blockIdx.z, y = blockIdx.y * blockDim.y + threadIdx.y, x = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
     const int w = g.w[0];
-    if (x >= w) return;
+    if (x >= w || y >= g.h[0]) return;
     const uint8_t *src = img + (int64_t)b * img_stride + (int64_t)y * pitch + x;
     uint8_t *dst = slots + (int64_t)b * slot_stride + g.origin[0] + (int64_t)y * g.pitch[0] + x;   // 16-byte aligned
     if (x + 16 <= w && ((uintptr_t)src & 15) == 0) *(uint4 *)dst = *(const uint4 *)src;
@@ -1326,15 +1327,16 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     dim3 blk(256);
     int *ovf = ctx->orb_overflow + slot0;
     SVO_HIP(hipMemsetAsync(ovf, 0, sizeof(int) * (size_t)n_img, st));
-    if (img2) {
-        // left images -> even slots, right images -> odd slots
-        hipLaunchKernelGGL(orb_copy0_kernel, dim3((g.w[0] + 4095) / 4096, g.h[0], n_img / 2), blk, 0, st, g, img, pitch, img_stride,
-                           slots, 2 * g.slot_bytes);
-        hipLaunchKernelGGL(orb_copy0_kernel, dim3((g.w[0] + 4095) / 4096, g.h[0], n_img / 2), blk, 0, st, g, img2, pitch, img_stride,
-                           slots + g.slot_bytes, 2 * g.slot_bytes);
-    } else {
-        hipLaunchKernelGGL(orb_copy0_kernel, dim3((g.w[0] + 4095) / 4096, g.h[0], n_img), blk, 0, st, g, img, pitch, img_stride,
-                           slots, g.slot_bytes);
+    {
+        const int lanes = (g.w[0] + 15) / 16, bx = lanes < 256 ? lanes : 256, by = 256 / bx;
+        const dim3 cblk(bx, by), cgrid((lanes + bx - 1) / bx, (g.h[0] + by - 1) / by, img2 ? n_img / 2 : n_img);
+        if (img2) {
+            // left images -> even slots, right images -> odd slots
+            hipLaunchKernelGGL(orb_copy0_kernel, cgrid, cblk, 0, st, g, img, pitch, img_stride, slots, 2 * g.slot_bytes);
+            hipLaunchKernelGGL(orb_copy0_kernel, cgrid, cblk, 0, st, g, img2, pitch, img_stride, slots + g.slot_bytes, 2 * g.slot_bytes);
+        } else {
+            hipLaunchKernelGGL(orb_copy0_kernel, cgrid, cblk, 0, st, g, img, pitch, img_stride, slots, g.slot_bytes);
+        }
     }
     for (int l = 0; l < L; l++) {
         if (l > 0) {
