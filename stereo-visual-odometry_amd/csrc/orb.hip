@@ -226,94 +226,117 @@ __global__ __launch_bounds__(256) void orb_cellfast_kernel(OrbGeom g, const uint
     const uint32_t *rawd = (const uint32_t *)raw;           // aligned dword view, kCellPitch / 4 dwords per row
     raw += ox;
     __syncthreads();
-    // Cornerness only matters where it can reach minTh: a corner at threshold t needs one pixel
-    // of each opposite pair (0,8), (4,12) beyond t, so positions failing that 4-pixel test at minTh
-    // keep V = 0, and the full arc min/max runs over a compacted list of the survivors.
+    // Cornerness only matters where it can reach the threshold in force: a corner at threshold t needs one
+    // pixel of each opposite pair (0,8), (4,12) beyond t, so positions failing that 4-pixel test at t keep
+    // V = 0, and the full arc min/max runs over a compacted list of the survivors.
+    // The reference runs FAST at iniTh and, only if the cell stays empty, again at minTh.  Cornerness is
+    // therefore computed in TWO PHASES: first for the survivors of the test at iniTh (on textured images
+    // nearly every pixel survives the test at minTh = 7, and the arc min/max of every pixel was three
+    // quarters of this kernel); the pixels with iniTh > V >= minTh only matter when the cell has no
+    // keypoint at iniTh (no corner, or strict NMS emptied it), and only then are they computed.
     // The test runs on FOUR pixels per thread (one aligned LDS dword of row y and its neighbours
     // three rows up / down and three columns left / right: five dword reads instead of twenty byte
     // reads), in packed 16-bit arithmetic on the even and the odd bytes:
     //   alive <=> max( min(v - min(p0,p8), v - min(p4,p12)),  min(max(p0,p8) - v, max(p4,p12) - v) ) > t
-    {
-        typedef short s16x2 __attribute__((ext_vector_type(2)));
-        const int rows = ch - 6, ngroups = nd * rows;
-        const s16x2 T1 = {(short)(lowTh + 1), (short)(lowTh + 1)};
-        constexpr int RD = kCellPitch / 4;
-        for (int i0 = 0; i0 < ngroups; i0 += 256) {
-            const int i = i0 + tid;
-            uint32_t m4 = 0;
-            int y = 0, xb = 0;
-            if (i < ngroups) {
-                const int yy = (int)(((float)i + 0.5f) * inv_nd), gq = i - yy * nd;
-                y = yy + 3; xb = 4 * gq - ox;                            // cell x of the dword's first byte
-                const uint32_t *r = rawd + y * RD + gq;
-                const uint32_t C = r[0], U = r[-3 * RD], D = r[3 * RD], Lf = gq > 0 ? r[-1] : 0u, Rt = r[1];
-                const uint32_t Lv = __builtin_amdgcn_alignbyte(C, Lf, 1);    // x - 3 neighbours of the four pixels
-                const uint32_t Rv = __builtin_amdgcn_alignbyte(Rt, C, 3);    // x + 3 neighbours
-                uint32_t sgn[2];
-#pragma unroll
-                for (int hb = 0; hb < 2; hb++) {                          // even bytes (pixels 0, 2), odd bytes (1, 3)
-                    auto half = [&](uint32_t w) { return __builtin_bit_cast(s16x2, (hb ? w >> 8 : w) & 0x00FF00FFu); };
-                    const s16x2 v = half(C), u = half(U), d = half(D), l = half(Lv), rr = half(Rv);
-                    const s16x2 mnA = __builtin_elementwise_min(u, d), mxA = __builtin_elementwise_max(u, d);
-                    const s16x2 mnB = __builtin_elementwise_min(l, rr), mxB = __builtin_elementwise_max(l, rr);
-                    const s16x2 dark = __builtin_elementwise_min(v - mnA, v - mnB);
-                    const s16x2 bright = __builtin_elementwise_min(mxA - v, mxB - v);
-                    sgn[hb] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(dark, bright) - T1);   // sign set <=> not alive
+    auto survivors_and_cornerness = [&](const int th) -> int {
+        {
+            typedef short s16x2 __attribute__((ext_vector_type(2)));
+            const int rows = ch - 6, ngroups = nd * rows;
+            const s16x2 T1 = {(short)(th + 1), (short)(th + 1)};
+            constexpr int RD = kCellPitch / 4;
+            for (int i0 = 0; i0 < ngroups; i0 += 256) {
+                const int i = i0 + tid;
+                uint32_t m4 = 0;
+                int y = 0, xb = 0;
+                if (i < ngroups) {
+                    const int yy = (int)(((float)i + 0.5f) * inv_nd), gq = i - yy * nd;
+                    y = yy + 3; xb = 4 * gq - ox;                            // cell x of the dword's first byte
+                    const uint32_t *r = rawd + y * RD + gq;
+                    const uint32_t C = r[0], U = r[-3 * RD], D = r[3 * RD], Lf = gq > 0 ? r[-1] : 0u, Rt = r[1];
+                    const uint32_t Lv = __builtin_amdgcn_alignbyte(C, Lf, 1);    // x - 3 neighbours of the four pixels
+                    const uint32_t Rv = __builtin_amdgcn_alignbyte(Rt, C, 3);    // x + 3 neighbours
+                    uint32_t sgn[2];
+    #pragma unroll
+                    for (int hb = 0; hb < 2; hb++) {                          // even bytes (pixels 0, 2), odd bytes (1, 3)
+                        auto half = [&](uint32_t w) { return __builtin_bit_cast(s16x2, (hb ? w >> 8 : w) & 0x00FF00FFu); };
+                        const s16x2 v = half(C), u = half(U), d = half(D), l = half(Lv), rr = half(Rv);
+                        const s16x2 mnA = __builtin_elementwise_min(u, d), mxA = __builtin_elementwise_max(u, d);
+                        const s16x2 mnB = __builtin_elementwise_min(l, rr), mxB = __builtin_elementwise_max(l, rr);
+                        const s16x2 dark = __builtin_elementwise_min(v - mnA, v - mnB);
+                        const s16x2 bright = __builtin_elementwise_min(mxA - v, mxB - v);
+                        sgn[hb] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(dark, bright) - T1);   // sign set <=> not alive
+                    }
+                    const uint32_t dead = ((sgn[0] >> 15) & 1u) | ((sgn[1] >> 14) & 2u) | ((sgn[0] >> 29) & 4u) | ((sgn[1] >> 28) & 8u);
+                    // pixels inside [3, cw - 3)
+                    const int lo = max(0, 3 - xb), hi = min(4, cw - 3 - xb);
+                    const uint32_t inside = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+                    m4 = ~dead & inside;
                 }
-                const uint32_t dead = ((sgn[0] >> 15) & 1u) | ((sgn[1] >> 14) & 2u) | ((sgn[0] >> 29) & 4u) | ((sgn[1] >> 28) & 8u);
-                // pixels inside [3, cw - 3)
-                const int lo = max(0, 3 - xb), hi = min(4, cw - 3 - xb);
-                const uint32_t inside = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
-                m4 = ~dead & inside;
+                // survivors -> list (any order): one LDS atomic per wave and step
+                const int lane = tid & 63;
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const unsigned long long b0 = __ballot(m4 & 1u), b1 = __ballot(m4 & 2u), b2 = __ballot(m4 & 4u), b3 = __ballot(m4 & 8u);
+                const int c0 = __popcll(b0), c1 = __popcll(b1), c2 = __popcll(b2), c3 = __popcll(b3);
+                if (c0 + c1 + c2 + c3) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_nlist, c0 + c1 + c2 + c3);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const int pos = y * kCellPitch + xb;
+                    if (m4 & 1u) list[base + __popcll(b0 & lt)] = (uint16_t)pos;
+                    if (m4 & 2u) list[base + c0 + __popcll(b1 & lt)] = (uint16_t)(pos + 1);
+                    if (m4 & 4u) list[base + c0 + c1 + __popcll(b2 & lt)] = (uint16_t)(pos + 2);
+                    if (m4 & 8u) list[base + c0 + c1 + c2 + __popcll(b3 & lt)] = (uint16_t)(pos + 3);
+                }
             }
-            // survivors -> list (any order): one LDS atomic per wave and step
-            const int lane = tid & 63;
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const unsigned long long b0 = __ballot(m4 & 1u), b1 = __ballot(m4 & 2u), b2 = __ballot(m4 & 4u), b3 = __ballot(m4 & 8u);
-            const int c0 = __popcll(b0), c1 = __popcll(b1), c2 = __popcll(b2), c3 = __popcll(b3);
-            if (c0 + c1 + c2 + c3) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_nlist, c0 + c1 + c2 + c3);
-                base = __builtin_amdgcn_readfirstlane(base);
-                const int pos = y * kCellPitch + xb;
-                if (m4 & 1u) list[base + __popcll(b0 & lt)] = (uint16_t)pos;
-                if (m4 & 2u) list[base + c0 + __popcll(b1 & lt)] = (uint16_t)(pos + 1);
-                if (m4 & 4u) list[base + c0 + c1 + __popcll(b2 & lt)] = (uint16_t)(pos + 2);
-                if (m4 & 8u) list[base + c0 + c1 + c2 + __popcll(b3 & lt)] = (uint16_t)(pos + 3);
-            }
-        }
-    }
-    __syncthreads();
-    // cornerness of the survivors; the positions that reach minTh are compacted again IN PLACE (a
-    // write index never passes the block of 256 entries being read), so the NMS passes below only
-    // visit possible keypoints instead of every pixel of the cell
-    int any = 0;
-    const int nlist = s_nlist;
-    for (int i0 = 0; i0 < nlist; i0 += 256) {
-        const int i = i0 + tid;
-        int pos = 0, v = 0;
-        if (i < nlist) {
-            pos = list[i];
-            v = fast_cornerness(&raw[pos], kCellPitch);
-            V[pos] = (uint8_t)v;
-            any |= v >= iniTh;
         }
         __syncthreads();
-        const bool cand = v >= lowTh && v > 0;
-        const unsigned long long m = __ballot(cand);
-        if (m) {
-            const int lane = tid & 63;
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&s_ncand, __popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (cand) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+        // cornerness of the survivors; the positions that reach minTh are compacted again IN PLACE (a
+        // write index never passes the block of 256 entries being read), so the NMS passes below only
+        // visit possible keypoints instead of every pixel of the cell
+        int any = 0;
+        const int nlist = s_nlist;
+        for (int i0 = 0; i0 < nlist; i0 += 256) {
+            const int i = i0 + tid;
+            int pos = 0, v = 0;
+            if (i < nlist) {
+                pos = list[i];
+                v = fast_cornerness(&raw[pos], kCellPitch);
+                V[pos] = (uint8_t)v;
+                any |= v >= iniTh;
+            }
+            __syncthreads();
+            const bool cand = v >= th && v > 0;
+            const unsigned long long m = __ballot(cand);
+            if (m) {
+                const int lane = tid & 63;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_ncand, __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (cand) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+            }
         }
-    }
-    if (any) s_any = 1;
+        return any;
+    };
+    // phase 1 at the higher of the two thresholds the cell can end up with, phase 2 (all pixels that can
+    // reach the lower one) only when the first NMS pass leaves the cell empty
+    const int th1 = iniTh > minTh ? iniTh : lowTh;
+    int th_done = th1;
+    if (survivors_and_cornerness(th1)) s_any = 1;
     __syncthreads();
-    const int ncand = s_ncand;
+    int ncand = s_ncand;
     int thr = s_any ? iniTh : minTh;
     for (int pass = 0; pass < 2; pass++) {
+        if (thr < th_done) {
+            // the pixels with th_done > V >= thr are needed now: V of every survivor of the weaker test
+            // (those of phase 1 come out the same again), candidate list rebuilt
+            __syncthreads();
+            if (tid == 0) { s_nlist = 0; s_ncand = 0; }
+            __syncthreads();
+            survivors_and_cornerness(lowTh);
+            th_done = lowTh;
+            __syncthreads();
+            ncand = s_ncand;
+        }
         int found = 0;
         for (int i = tid; i < ncand; i += 256) {
             const int pos = list[i];
