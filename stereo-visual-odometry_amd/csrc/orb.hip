@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void orb_copy0_kernel(OrbGeom g, const uint8_t
 // eight short launches per step each paid their own ramp-up and tail.  The level of a block is the last
 // one whose first block is not beyond it (wave-uniform: a scalar loop over <= 8 entries).
 constexpr int kBlurRowsPerThread = 28;
+constexpr int kOrbBorderRowsPerBlock = 16;
 __device__ __forceinline__ int level_of_block(const int *first, int nlevels, int blk)
 {
     int l = 0;
@@ -53,6 +54,7 @@ __device__ __forceinline__ int level_of_block(const int *first, int nlevels, int
     return l;
 }
 
+constexpr int kOrbBorderRows = kOrbBorderRowsPerBlock;   // interior rows whose side bytes one workgroup writes
 __global__ __launch_bounds__(256) void orb_border_kernel(OrbGeom g, uint8_t *slots, int64_t slot_stride)
 {
     const int b = blockIdx.y;
@@ -61,17 +63,30 @@ __global__ __launch_bounds__(256) void orb_border_kernel(OrbGeom g, uint8_t *slo
     uint8_t *lvl = slots + (int64_t)b * slot_stride + g.origin[l];
     const int gidx = blockIdx.x - g.border_blk[l];
     if (gidx < 2 * kPad) {
+        // a full frame row, four bytes per thread (the padded row starts 64-byte aligned: pitch and slot
+        // offsets are multiples of 64 and pixel (0,0) sits kPad bytes into its row)
         const int py = gidx < kPad ? gidx - kPad : h + (gidx - kPad);
         const uint8_t *src = lvl + (int64_t)refl101(py, h) * pitch;
         uint8_t *dst = lvl + (int64_t)py * pitch;
-        for (int px = (int)threadIdx.x - kPad; px < w + kPad; px += 256) dst[px] = src[refl101(px, w)];
+        for (int px = ((int)threadIdx.x << 2) - kPad; px < w + kPad; px += 1024) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v |= (uint32_t)src[refl101(min(px + q, w + kPad - 1), w)] << (8 * q);
+            if (px + 4 <= w + kPad) *(uint32_t *)(dst + px) = v;
+            else for (int q = 0; px + q < w + kPad; q++) dst[px + q] = (uint8_t)(v >> (8 * q));
+        }
     } else {
-        const int py = (gidx - 2 * kPad) * 4 + (threadIdx.x >> 6);
-        if (py >= h) return;
-        const int t = threadIdx.x & 63;
-        const int px = t < kPad ? t - kPad : w + (t - kPad);
-        uint8_t *row = lvl + (int64_t)py * pitch;
-        row[px] = row[refl101(px, w)];
+        // 2 x kPad side bytes of kOrbBorderRows interior rows, four rows at a time
+        static_assert(2 * kPad == 64, "one wave per row's side bytes");
+        const int rr = threadIdx.x >> 6, c = threadIdx.x & 63;
+        const int px = c < kPad ? c - kPad : w + (c - kPad);
+        const int sx = refl101(px, w);
+        for (int r = rr; r < kOrbBorderRows; r += 4) {
+            const int py = (gidx - 2 * kPad) * kOrbBorderRows + r;
+            if (py >= h) return;
+            uint8_t *row = lvl + (int64_t)py * pitch;
+            row[px] = row[sx];
+        }
     }
 }
 
@@ -454,9 +469,10 @@ __global__ __launch_bounds__(256) void orb_gather_kernel(OrbGeom g, const float4
     if (threadIdx.x == 0 && total > cand_cap) atomicOr(overflow + b, 2);
     const float4 *src = cell_cand + (int64_t)b * cand_img_stride + (int64_t)g.cell_off[l] * kCellCap;
     float4 *dst = lvl_cand + ((int64_t)b * g.nlevels + l) * cand_cap;
-    for (int c = threadIdx.x >> 6; c < ncell; c += 4) {
+    // a cell holds a few dozen candidates at most: 16 lanes per cell (a whole wave per cell copied 20 of 64 lanes)
+    for (int c = threadIdx.x >> 4; c < ncell; c += 16) {
         const int n = min(cnt[c], kCellCap), o = offs[c];
-        for (int k = threadIdx.x & 63; k < n; k += 64)
+        for (int k = threadIdx.x & 15; k < n; k += 16)
             if (o + k < cand_cap) dst[o + k] = src[(int64_t)c * kCellCap + k];
     }
     if (threadIdx.x == 0) lvl_cnt[b * g.nlevels + l] = min(total, cand_cap);
@@ -836,8 +852,8 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
 // frame IS the blur's border); the seven most recent row sums slide through registers for the
 // column pass (28-row band), so neither the int intermediate image nor a second launch exists.
 constexpr int kBlurRows = kBlurRowsPerThread;     // 4 x 7: the row ring rotates with static indices
-__global__ __launch_bounds__(256) void orb_blur_kernel(OrbGeom g, const uint8_t *slots, int64_t slot_stride,
-                                                       uint8_t *blur, int64_t blur_img_stride)
+__global__ __launch_bounds__(256) void orb_blur_kernel(OrbGeom g, const uint8_t *__restrict__ slots, int64_t slot_stride,
+                                                       uint8_t *__restrict__ blur, int64_t blur_img_stride)
 {
     const int b = blockIdx.z;
     const int l = level_of_block(g.blur_blk, g.nlevels, blockIdx.y);      // blockIdx.y = row band over all levels
@@ -849,36 +865,55 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(OrbGeom g, const uint8_t 
     uint8_t *dst = blur + (int64_t)b * blur_img_stride + g.blur_off[l] + x0;
     const uint32_t k0123 = (uint32_t)g.gk[0] | ((uint32_t)g.gk[1] << 8) | ((uint32_t)g.gk[2] << 16) | ((uint32_t)g.gk[3] << 24);
     const uint32_t k456 = (uint32_t)g.gk[4] | ((uint32_t)g.gk[5] << 8) | ((uint32_t)g.gk[6] << 16);
-    auto rowsum = [&](int yy, uint32_t (&out)[4]) {
-        const uint32_t *p = (const uint32_t *)(src + (int64_t)yy * pitch);
-        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];             // columns x0-4 .. x0+7
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+    auto rowsum = [&](const uint32_t (&d)[3], uint32_t (&out)[4]) {      // d: columns x0-4 .. x0+7 of one row
 #pragma unroll
         for (int o = 0; o < 4; o++) {                               // taps of column x0+o: bytes o+1 .. o+7
-            const uint32_t lo = o == 3 ? d1 : __builtin_amdgcn_alignbyte(d1, d0, o + 1);
-            const uint32_t hi = o == 3 ? d2 : __builtin_amdgcn_alignbyte(d2, d1, o + 1);
+            const uint32_t lo = o == 3 ? d[1] : __builtin_amdgcn_alignbyte(d[1], d[0], o + 1);
+            const uint32_t hi = o == 3 ? d[2] : __builtin_amdgcn_alignbyte(d[2], d[1], o + 1);
             out[o] = __builtin_amdgcn_udot4(lo, k0123, __builtin_amdgcn_udot4(hi, k456, 0u, false), false);
         }
     };
+    auto load_row = [&](int yy, uint32_t (&d)[3]) {
+        const uint32_t *p = (const uint32_t *)(src + (int64_t)yy * pitch);
+        d[0] = p[0]; d[1] = p[1]; d[2] = p[2];
+    };
     // ring of the seven most recent row sums: row y0-3+i lives in win[i % 7] (static indices: the
-    // band is walked in fully unrolled groups of seven rows)
+    // band is walked in fully unrolled groups of seven rows).  The seven source rows of a group are
+    // requested together, before the first of them is used (one row per step made every thread a chain of
+    // 34 dependent memory round trips: 0.85 ms per 256 pairs, four times either of the kernel's roofs);
+    // rows past the band's last one still lie inside the stored frame (kPad >= 28 + 3).
     uint32_t win[7][4];
+    {
+        uint32_t d[6][3];
 #pragma unroll
-    for (int r = 0; r < 6; r++) rowsum(y0 - 3 + r, win[r]);
+        for (int r = 0; r < 6; r++) load_row(y0 - 3 + r, d[r]);
+#pragma unroll
+        for (int r = 0; r < 6; r++) rowsum(d[r], win[r]);
+    }
     const int rows = min(kBlurRows, h - y0);
     for (int k = 0; k < kBlurRows / 7; k++) {
+        if (7 * k >= rows) return;
+        uint32_t d[7][3];
+#pragma unroll
+        for (int j = 0; j < 7; j++) load_row(y0 + 7 * k + j + 3, d[j]);
 #pragma unroll
         for (int j = 0; j < 7; j++) {
             const int yy = 7 * k + j;
-            if (yy >= rows) return;
-            rowsum(y0 + yy + 3, win[(j + 6) % 7]);              // row index yy + 6 in the ring
-            uint8_t *q = dst + (int64_t)(y0 + yy) * w;
+            rowsum(d[j], win[(j + 6) % 7]);                     // row index yy + 6 in the ring
+            uint32_t v4 = 0;
 #pragma unroll
             for (int o = 0; o < 4; o++) {
                 uint32_t v = 1u << 15;
 #pragma unroll
                 for (int r = 0; r < 7; r++) v += win[(j + r) % 7][o] * (uint32_t)g.gk[r];
                 v >>= 16;
-                if (x0 + o < w) q[o] = (uint8_t)(v > 255u ? 255u : v);
+                v4 |= (v > 255u ? 255u : v) << (8 * o);
+            }
+            if (yy < rows) {
+                uint8_t *q = dst + (int64_t)(y0 + yy) * w;
+                if (x0 + 4 <= w) *(u32_unaligned *)q = v4;          // the tight blurred rows are w bytes apart: any alignment
+                else for (int o = 0; x0 + o < w; o++) q[o] = (uint8_t)(v4 >> (8 * o));
             }
         }
     }
@@ -1228,7 +1263,7 @@ int orb_make_geom(const svo_config &cfg, OrbGeom *g)
         int bb = 0, yb = 0;
         for (int l = 0; l < nlevels; l++) {
             g->border_blk[l] = bb; g->blur_blk[l] = yb;
-            bb += 2 * kPad + (g->h[l] + 3) / 4;
+            bb += 2 * kPad + (g->h[l] + kOrbBorderRowsPerBlock - 1) / kOrbBorderRowsPerBlock;
             yb += (g->h[l] + 4 * kBlurRowsPerThread - 1) / (4 * kBlurRowsPerThread);
         }
         for (int l = nlevels; l <= kOrbMaxLevels; l++) { g->border_blk[l] = bb; g->blur_blk[l] = yb; }
