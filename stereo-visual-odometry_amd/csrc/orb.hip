@@ -8,8 +8,9 @@
 // off), so keypoints, angles, descriptors and matches are bit-identical to oracle/orb.c.
 //
 // Launch sequence for a batch of images (every kernel covers all images of the batch):
-//   copy0/border -> [resize(l), border(l)] x7 -> cellfast(l) x8 -> gather -> distribute -> blur rows/cols
-//   -> orient+describe -> assemble.
+//   copy0 -> resize(l) x7 -> blur (all levels) -> cellfast (all levels) -> gather -> distribute
+//   -> orient+describe -> assemble.  (No frame is written around the ORB levels: the blur, its only
+//   reader, reflects at the edges itself.)
 // The quadtree (std::list / sort / pointer code in the reference) is restated as an array-based
 // doubly linked list in LDS walked by ONE WAVE per (image, level): the walk is serial by nature (each
 // split decision depends on the node count so far), so its control flow is wave-uniform, while every
@@ -42,52 +43,15 @@ __global__ __launch_bounds__(256) void orb_copy0_kernel(OrbGeom g, const uint8_t
     else for (int q = 0; q < 16 && x + q < w; q++) dst[q] = src[q];
 }
 
-// One launch serves ALL pyramid levels where the per-level work is independent (borders, blur, cell FAST):
+// One launch serves ALL pyramid levels where the per-level work is independent (blur, cell FAST):
 // eight short launches per step each paid their own ramp-up and tail.  The level of a block is the last
 // one whose first block is not beyond it (wave-uniform: a scalar loop over <= 8 entries).
 constexpr int kBlurRowsPerThread = 28;
-constexpr int kOrbBorderRowsPerBlock = 16;
 __device__ __forceinline__ int level_of_block(const int *first, int nlevels, int blk)
 {
     int l = 0;
     for (int k = 1; k < nlevels; k++) l = blk >= first[k] ? k : l;
     return l;
-}
-
-constexpr int kOrbBorderRows = kOrbBorderRowsPerBlock;   // interior rows whose side bytes one workgroup writes
-__global__ __launch_bounds__(256) void orb_border_kernel(OrbGeom g, uint8_t *slots, int64_t slot_stride)
-{
-    const int b = blockIdx.y;
-    const int l = level_of_block(g.border_blk, g.nlevels, blockIdx.x);
-    const int w = g.w[l], h = g.h[l], pitch = g.pitch[l];
-    uint8_t *lvl = slots + (int64_t)b * slot_stride + g.origin[l];
-    const int gidx = blockIdx.x - g.border_blk[l];
-    if (gidx < 2 * kPad) {
-        // a full frame row, four bytes per thread (the padded row starts 64-byte aligned: pitch and slot
-        // offsets are multiples of 64 and pixel (0,0) sits kPad bytes into its row)
-        const int py = gidx < kPad ? gidx - kPad : h + (gidx - kPad);
-        const uint8_t *src = lvl + (int64_t)refl101(py, h) * pitch;
-        uint8_t *dst = lvl + (int64_t)py * pitch;
-        for (int px = ((int)threadIdx.x << 2) - kPad; px < w + kPad; px += 1024) {
-            uint32_t v = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) v |= (uint32_t)src[refl101(min(px + q, w + kPad - 1), w)] << (8 * q);
-            if (px + 4 <= w + kPad) *(uint32_t *)(dst + px) = v;
-            else for (int q = 0; px + q < w + kPad; q++) dst[px + q] = (uint8_t)(v >> (8 * q));
-        }
-    } else {
-        // 2 x kPad side bytes of kOrbBorderRows interior rows, four rows at a time
-        static_assert(2 * kPad == 64, "one wave per row's side bytes");
-        const int rr = threadIdx.x >> 6, c = threadIdx.x & 63;
-        const int px = c < kPad ? c - kPad : w + (c - kPad);
-        const int sx = refl101(px, w);
-        for (int r = rr; r < kOrbBorderRows; r += 4) {
-            const int py = (gidx - 2 * kPad) * kOrbBorderRows + r;
-            if (py >= h) return;
-            uint8_t *row = lvl + (int64_t)py * pitch;
-            row[px] = row[sx];
-        }
-    }
 }
 
 // cv::resize(level l-1 -> level l, INTER_LINEAR), 8-bit fixed point (11-bit coefficients)
@@ -848,8 +812,8 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
 
 // ---- blur (7x7, sigma 2, reflect-101; integer kernel, (sum + 2^15) >> 16, saturated) -------------
 // One pass: a thread owns 4 adjacent columns of a 28-row band.  A row's four 7-tap sums are two
-// v_dot4_u32_u8 each on byte windows cut from three aligned dwords (the level's stored reflect-101
-// frame IS the blur's border); the seven most recent row sums slide through registers for the
+// v_dot4_u32_u8 each on byte windows cut from three aligned dwords (reflect-101 at the image edges by
+// index arithmetic in the few threads that touch them); the seven most recent row sums slide through registers for the
 // column pass (28-row band), so neither the int intermediate image nor a second launch exists.
 constexpr int kBlurRows = kBlurRowsPerThread;     // 4 x 7: the row ring rotates with static indices
 __global__ __launch_bounds__(256) void orb_blur_kernel(OrbGeom g, const uint8_t *__restrict__ slots, int64_t slot_stride,
@@ -861,10 +825,39 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(OrbGeom g, const uint8_t 
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y0 = ((blockIdx.y - g.blur_blk[l]) * 4 + threadIdx.y) * kBlurRows;
     if (x0 >= w || y0 >= h) return;
-    const uint8_t *src = slots + (int64_t)b * slot_stride + g.origin[l] + x0 - 4;
+    const uint8_t *lvl = slots + (int64_t)b * slot_stride + g.origin[l];
     uint8_t *dst = blur + (int64_t)b * blur_img_stride + g.blur_off[l] + x0;
+    // BORDER_REFLECT_101 is applied HERE (ORBextractor.cpp:1034-1035 blurs the un-bordered clone of the level):
+    // rows by reflecting the row index, columns only in the threads whose 12-byte window leaves the row -- the
+    // first thread of a row and the last one or two.  No kernel writes a frame around the ORB levels any more
+    // (the border launch was 0.3-0.5 ms per 256 pairs for bytes only this kernel ever read).
+    const bool edge = x0 == 0 || x0 + 8 > w;
     const uint32_t k0123 = (uint32_t)g.gk[0] | ((uint32_t)g.gk[1] << 8) | ((uint32_t)g.gk[2] << 16) | ((uint32_t)g.gk[3] << 24);
     const uint32_t k456 = (uint32_t)g.gk[4] | ((uint32_t)g.gk[5] << 8) | ((uint32_t)g.gk[6] << 16);
+    // byte shuffles that put the reflected columns into an edge thread's 12-byte window (columns x0-4 .. x0+7 =
+    // window bytes 0..11): every column a valid output needs (<= w+2, >= -3) reflects to a column inside the same
+    // window.  Window byte i takes byte sidx(i); two v_perm per dword (one over d0|d1, one bringing in d2).
+    uint32_t selA[3], selB[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        uint32_t sa = 0, sb = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = 4 * k + q, col = x0 - 4 + i;
+            int s = i;
+            if (col < 0 || col >= w) {
+                const int r = col < 0 ? -col : 2 * w - 2 - col;
+                const int j = r - (x0 - 4);
+                if (r >= 0 && r < w && j >= 0 && j < 12) s = j;
+            }
+            // stage 1: t = perm(d1, d0, selA): bytes of d0 (0-3) / d1 (4-7); a d2 source leaves a placeholder
+            sa |= (uint32_t)(s < 8 ? s : 0) << (8 * q);
+            // stage 2: out = perm(d2, t, selB): t's byte q (index q) or d2's byte (4 + s - 8)
+            sb |= (uint32_t)(s < 8 ? q : 4 + (s - 8)) << (8 * q);
+        }
+        selA[k] = sa; selB[k] = sb;
+    }
+    const bool wave_edge = __builtin_amdgcn_ballot_w64(edge) != 0;       // (uniform: decides the code path of the whole wave)
     typedef uint32_t u32_unaligned __attribute__((aligned(1)));
     auto rowsum = [&](const uint32_t (&d)[3], uint32_t (&out)[4]) {      // d: columns x0-4 .. x0+7 of one row
 #pragma unroll
@@ -875,14 +868,21 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(OrbGeom g, const uint8_t 
         }
     };
     auto load_row = [&](int yy, uint32_t (&d)[3]) {
-        const uint32_t *p = (const uint32_t *)(src + (int64_t)yy * pitch);
-        d[0] = p[0]; d[1] = p[1]; d[2] = p[2];
+        yy = yy < 0 ? -yy : (yy >= h ? 2 * h - 2 - yy : yy);        // reflect-101 (one reflection: |offset| < 32 <= h)
+        yy = min(max(yy, 0), h - 1);
+        const uint32_t *p = (const uint32_t *)(lvl + (int64_t)yy * pitch + x0 - 4);   // (a thread at a row end reads a few
+        d[0] = p[0]; d[1] = p[1]; d[2] = p[2];                                        //  bytes of the slot's unused frame area)
+        if (wave_edge) {
+            const uint32_t d0 = d[0], d1 = d[1], d2 = d[2];
+#pragma unroll
+            for (int k = 0; k < 3; k++) d[k] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, selA[k]), selB[k]);
+        }
     };
     // ring of the seven most recent row sums: row y0-3+i lives in win[i % 7] (static indices: the
     // band is walked in fully unrolled groups of seven rows).  The seven source rows of a group are
     // requested together, before the first of them is used (one row per step made every thread a chain of
     // 34 dependent memory round trips: 0.85 ms per 256 pairs, four times either of the kernel's roofs);
-    // rows past the band's last one still lie inside the stored frame (kPad >= 28 + 3).
+    // (rows past the band's last one reflect back into the image: loaded, never used for an output row)
     uint32_t win[7][4];
     {
         uint32_t d[6][3];
@@ -1260,13 +1260,12 @@ int orb_make_geom(const svo_config &cfg, OrbGeom *g)
     g->blur_total = boff;
     g->cells_total = coff;
     {
-        int bb = 0, yb = 0;
+        int yb = 0;
         for (int l = 0; l < nlevels; l++) {
-            g->border_blk[l] = bb; g->blur_blk[l] = yb;
-            bb += 2 * kPad + (g->h[l] + kOrbBorderRowsPerBlock - 1) / kOrbBorderRowsPerBlock;
+            g->blur_blk[l] = yb;
             yb += (g->h[l] + 4 * kBlurRowsPerThread - 1) / (4 * kBlurRowsPerThread);
         }
-        for (int l = nlevels; l <= kOrbMaxLevels; l++) { g->border_blk[l] = bb; g->blur_blk[l] = yb; }
+        for (int l = nlevels; l <= kOrbMaxLevels; l++) g->blur_blk[l] = yb;
     }
     int xo = 0, yo = 0;
     for (int l = 0; l < nlevels; l++) { g->xtab_off[l] = xo; g->ytab_off[l] = yo; if (l > 0) { xo += g->w[l]; yo += g->h[l]; } }
@@ -1411,8 +1410,6 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
                                (const int2 *)ctx->orb_xtab, (const int4 *)ctx->orb_ytab, cap_rows, row_dw);
         }
     }
-    // borders of all levels in one launch (cv::resize clamps its taps to the image, so no level waits for a border)
-    hipLaunchKernelGGL(orb_border_kernel, dim3(g.border_blk[L], n_img), blk, 0, st, g, slots, g.slot_bytes);
     // the blurred levels only depend on the pyramid: computed here, before the LDS-hungry kernels,
     // so that in overlap mode the previous batch's pose solver (74 KB of LDS per workgroup) runs
     // beside kernels that need no LDS

@@ -35,8 +35,8 @@ struct OrbGeom {
     int nCols[kOrbMaxLevels], nRows[kOrbMaxLevels], wCell[kOrbMaxLevels], hCell[kOrbMaxLevels];
     int ncell[kOrbMaxLevels], cell_off[kOrbMaxLevels], cells_total;
     int xtab_off[kOrbMaxLevels], ytab_off[kOrbMaxLevels], xtab_total, ytab_total;   // resize tables (levels >= 1)
-    // launches that cover ALL levels: first block (x for the border kernel, y for the blur kernel) of level l
-    int border_blk[kOrbMaxLevels + 1], blur_blk[kOrbMaxLevels + 1];
+    // the blur launch covers ALL levels: first block (y) of level l
+    int blur_blk[kOrbMaxLevels + 1];
 };
 
 __host__ __device__ inline int refl101(int i, int n)
