@@ -82,14 +82,18 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(OrbGeom g, uint8_t *slo
     // source rows [sy_first, sy_last] (the table's rows are monotone), columns [s0, s0 + 4 ndw)
     const int sy_first = yt[dy0].x, sy_last = yt[dy1 - 1].y;
     const int nsrc = sy_last - sy_first + 1;
-    const int s0 = (xt[dx_first].x & 0xFFFF) & ~3;
-    const int ndw = (((xt[dx_last].x >> 16) - s0) >> 2) + 1;
+    // staged as 16-byte chunks (pixel (0,0) of a level and its pitch are 16-byte aligned; kResizeDw is a multiple of 4):
+    // four times the bytes in flight per load of the dword version, which left level 1 (whose source comes from HBM)
+    // at 1.5 TB/s
+    const int s0 = (xt[dx_first].x & 0xFFFF) & ~15;
+    const int ndw = ((((xt[dx_last].x >> 16) - s0) >> 4) + 1) << 2;
     const bool staged = ndw <= kResizeDw && nsrc <= src_rows_cap;
     if (staged) {
-        const float inv_ndw = 1.0f / (float)ndw;
-        for (int i = tid; i < nsrc * ndw; i += 256) {
-            const int r = (int)(((float)i + 0.5f) * inv_ndw), c = i - r * ndw;
-            rs_rows[r * kResizeDw + c] = *(const uint32_t *)(src + (int64_t)(sy_first + r) * sp + s0 + 4 * c);
+        const int n16 = ndw >> 2;
+        const float inv_n16 = 1.0f / (float)n16;
+        for (int i = tid; i < nsrc * n16; i += 256) {
+            const int r = (int)(((float)i + 0.5f) * inv_n16), c = i - r * n16;
+            *(uint4 *)(rs_rows + r * kResizeDw + 4 * c) = *(const uint4 *)(src + (int64_t)(sy_first + r) * sp + s0 + 16 * c);
         }
         __syncthreads();
     }
@@ -1403,7 +1407,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
             // source rows a strip of kResizeRows output rows can touch (+3: second tap, rounding), and the
             // dwords 1024 output columns can span (+3: second tap, alignment slack)
             int cap_rows = (int)((double)kResizeRows * g.h[l - 1] / g.h[l]) + 3;
-            int row_dw = (int)(1024.0 * g.w[l - 1] / g.w[l] / 4.0) + 3;
+            int row_dw = (((int)(1024.0 * g.w[l - 1] / g.w[l] / 4.0) + 3 + 4) + 3) & ~3;     // + the 16-byte alignment slack, multiple of 4
             if ((size_t)cap_rows * row_dw * 4 > 60 * 1024) cap_rows = 60 * 1024 / (row_dw * 4);     // beyond it: the unstaged path
             hipLaunchKernelGGL(orb_resize_kernel, dim3((g.w[l] + 1023) / 1024, (g.h[l] + kResizeRows - 1) / kResizeRows, n_img), blk,
                                (size_t)cap_rows * row_dw * 4, st, g, slots, g.slot_bytes, l,
