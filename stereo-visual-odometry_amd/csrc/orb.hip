@@ -796,15 +796,30 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
     int *order = (int *)L.ea;
     int m = 0;
     for (int i = t.head; i >= 0 && m < a.sel_cap; i = rfl(L.next[i])) { if (lane == 0) order[m] = i; m++; }
+    // responses (FAST scores, integers <= 255) as a byte table in the expansion list's second half, which is free now:
+    // a leaf's keys are then compared from LDS (one dependent global load per key made this phase a tenth of the
+    // kernel); candidate lists too long for the table keep reading the list in global memory
+    uint8_t *resp8 = (uint8_t *)L.eb;
+    const bool resp_lds = nkeys <= L.node_cap * 8;
+    if (resp_lds)
+        for (int i = lane; i < nkeys; i += 64) resp8[i] = (uint8_t)(int)cand[i].z;
     for (int j = lane; j < m; j += 64) {
         const int id = order[j], beg = L.begin[id], n = L.count[id];
         // keys of a node are in candidate order: the first maximum is the smallest index among the maxima
         int best = keys.id[beg];
-        float maxR = cand[best].z;
-        for (int k = 1; k < n; k++) {
-            const int c = keys.id[beg + k];
-            const float r = cand[c].z;
-            if (r > maxR) { best = c; maxR = r; }
+        if (resp_lds) {
+            int maxR = resp8[best];
+            for (int k = 1; k < n; k++) {
+                const int c = keys.id[beg + k], r = resp8[c];
+                if (r > maxR) { best = c; maxR = r; }
+            }
+        } else {
+            float maxR = cand[best].z;
+            for (int k = 1; k < n; k++) {
+                const int c = keys.id[beg + k];
+                const float r = cand[c].z;
+                if (r > maxR) { best = c; maxR = r; }
+            }
         }
         sel[j] = best;
     }
