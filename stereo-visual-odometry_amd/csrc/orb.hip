@@ -603,6 +603,8 @@ __device__ inline void qt_divide(QLds &L, QState &t, const KeyArr keys, const Ke
         int q[8], r[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) {
+            k[c] = make_uint2(0, 0); q[c] = 0; r[c] = 0;
+            if (64 * c >= n) continue;                        // (uniform: chunks past the node's last key cost nothing)
             const bool valid = lane + 64 * c < n;
             k[c] = valid ? keys.get(beg + lane + 64 * c) : make_uint2(0, 0);
             q[c] = key_quadrant(k[c], midx, midy);
@@ -610,6 +612,7 @@ __device__ inline void qt_divide(QLds &L, QState &t, const KeyArr keys, const Ke
         }
 #pragma unroll
         for (int c = 0; c < 8; c++) {
+            if (64 * c >= n) continue;
             const int off = q[c] == 0 ? 0 : (q[c] == 1 ? cnt[0] : (q[c] == 2 ? cnt[0] + cnt[1] : cnt[0] + cnt[1] + cnt[2]));
             if (lane + 64 * c < n) keys.set(beg + off + r[c], k[c]);
         }
