@@ -580,16 +580,10 @@ __device__ __forceinline__ int chunk_rank(bool valid, int q, int lane, int c[4])
 
 // ExtractorNode::DivideNode (ORBextractor.cpp:430-485): stable 4-way partition of the node's keys,
 // children created for the non-empty quadrants (ch[q] = node id or -1, cnt[q] = its key count)
-__device__ inline void qt_divide(QLds &L, QState &t, const KeyArr keys, const KeyArr gtmp, bool keys_global, const NodeView &nv,
-                                 int ch[4], int cnt[4], int cseq[4], int lane)
+__device__ inline void qt_partition(const KeyArr keys, const KeyArr gtmp, bool keys_global, const NodeView &nv, int midx, int midy,
+                                    int cnt[4], int lane)
 {
-    const int ulx = nv.ulx, uly = nv.uly, brx = nv.brx, bry = nv.bry, beg = nv.beg, n = nv.cnt;
-    // the (up to four) ids the children may take from the free list, fetched together up front;
-    // nothing is pushed onto the list before the parent is erased, after the children exist
-    const int nf0 = t.n_free;
-    const int f0 = L.free_list[max(nf0 - 1, 0)], f1 = L.free_list[max(nf0 - 2, 0)], f2 = L.free_list[max(nf0 - 3, 0)],
-              f3 = L.free_list[max(nf0 - 4, 0)];
-    const int midx = ulx + ((brx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);   // ceil(d / 2)
+    const int beg = nv.beg, n = nv.cnt;
     cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
     if (n <= 64) {
         const bool valid = lane < n;
@@ -636,33 +630,85 @@ __device__ inline void qt_divide(QLds &L, QState &t, const KeyArr keys, const Ke
         for (int i = lane; i < n; i += 64) keys.set(beg + i, gtmp.get(i));
     }
     if (keys_global) __threadfence();
-    const int pre[4] = {rfl(f0), rfl(f1), rfl(f2), rfl(f3)};
-    const int cbeg[4] = {beg, beg + cnt[0], beg + cnt[0] + cnt[1], beg + cnt[0] + cnt[1] + cnt[2]};
-    const int cul[4][2] = {{ulx, uly}, {midx, uly}, {ulx, midy}, {midx, midy}};
-    const int cbr[4][2] = {{midx, midy}, {brx, midy}, {midx, bry}, {brx, bry}};
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        ch[q] = -1; cseq[q] = 0;
-        if (cnt[q] == 0) continue;
-        cseq[q] = t.seq;
-        int nid;
-        if (t.n_free > 0) { nid = pre[nf0 - t.n_free]; t.n_free--; }
-        else if (t.n_alloc < L.node_cap) nid = t.n_alloc++;
-        else { t.overflow = true; nid = L.node_cap - 1; }
-        if (lane == 0) L.seq[nid] = (unsigned short)t.seq;
-        t.seq++;
-        if (lane == 0) {
-            QBox c; c.ulx = (short)cul[q][0]; c.uly = (short)cul[q][1]; c.brx = (short)cbr[q][0]; c.bry = (short)cbr[q][1];
-            L.box[nid] = c; L.begin[nid] = (unsigned short)cbeg[q]; L.count[nid] = (unsigned short)cnt[q];
-        }
-        ch[q] = nid;
-    }
 }
 
 __device__ __forceinline__ unsigned long long exp_key(int count, int seq, int id)
 {
     return ((unsigned long long)count << 40) | ((unsigned long long)seq << 12) | (unsigned long long)id;
 }
+
+// DivideNode + the list surgery around it (ORBextractor.cpp:430-485 and :573-618 / :640-681): the node's keys are
+// partitioned, its non-empty children are created and pushed to the FRONT of the list in quadrant order, the
+// children with more than one key are appended to the expansion list, the node itself is erased.
+// Children are handled by lanes 0..3 AT ONCE (lane = quadrant): ids, creation numbers, boxes, key ranges and the
+// list links of all four are written by one vector store each, where the scalar version walked the four quadrants
+// one after the other with ~25 single-lane LDS stores and the bookkeeping between them (the tree walk is a
+// chain of dependent instructions on a lone wave: their number is what the kernel costs).
+// The resulting state is exactly the sequential one: child of rank r (among the non-empty quadrants) takes the
+// r-th id off the free list (then fresh ids), creation number seq + r; the list reads
+//   last child, ..., first child, <what followed: the old head, or the erased node's successor if it WAS the head>
+__device__ inline void qt_split(QLds &L, QState &t, const KeyArr keys, const KeyArr gtmp, bool keys_global, const NodeView &nv,
+                                int node, int lane, int &n_exp, int &n_to_expand)
+{
+    const int ulx = nv.ulx, uly = nv.uly, brx = nv.brx, bry = nv.bry, beg = nv.beg;
+    const int midx = ulx + ((brx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);   // ceil(d / 2)
+    int cnt[4];
+    qt_partition(keys, gtmp, keys_global, nv, midx, midy, cnt, lane);
+    // ---- uniform bookkeeping
+    const uint32_t ne_mask = (cnt[0] > 0 ? 1u : 0u) | (cnt[1] > 0 ? 2u : 0u) | (cnt[2] > 0 ? 4u : 0u) | (cnt[3] > 0 ? 8u : 0u);
+    const uint32_t ex_mask = (cnt[0] > 1 ? 1u : 0u) | (cnt[1] > 1 ? 2u : 0u) | (cnt[2] > 1 ? 4u : 0u) | (cnt[3] > 1 ? 8u : 0u);
+    const int k = __popc(ne_mask), g = __popc(ex_mask);
+    const int nf0 = t.n_free, take = k < nf0 ? k : nf0, fresh = k - take;
+    const int head0 = t.head, seq0 = t.seq, alloc0 = t.n_alloc;
+    if (alloc0 + fresh > L.node_cap) t.overflow = true;
+    // ---- per quadrant (lanes 0..3)
+    const int q = lane & 3;
+    const bool mine = lane < 4 && ((ne_mask >> q) & 1u);
+    const int r = __popc(ne_mask & ((1u << q) - 1u));                    // rank among the non-empty children
+    const int c_q = q == 0 ? cnt[0] : q == 1 ? cnt[1] : q == 2 ? cnt[2] : cnt[3];
+    int id = 0;
+    if (mine) id = r < nf0 ? (int)L.free_list[nf0 - 1 - r] : min(alloc0 + (r - nf0), L.node_cap - 1);
+    const int cid0 = __builtin_amdgcn_readlane(id, 0), cid1 = __builtin_amdgcn_readlane(id, 1),
+              cid2 = __builtin_amdgcn_readlane(id, 2), cid3 = __builtin_amdgcn_readlane(id, 3);
+    auto cid = [&](int qq) { return qq == 0 ? cid0 : qq == 1 ? cid1 : qq == 2 ? cid2 : cid3; };
+    const int q_first = __ffs((int)ne_mask) - 1, q_last = 31 - __clz((int)ne_mask);
+    const int first = cid(q_first), last = cid(q_last);
+    const int after = head0 == node ? nv.next : head0;                  // what follows the children in the list
+    if (mine) {
+        const uint32_t lo = ne_mask & ((1u << q) - 1u), hi = ne_mask >> (q + 1);
+        const int nxt = lo ? cid(31 - __clz((int)lo)) : after;          // towards the back: the previous non-empty quadrant
+        const int prv = hi ? cid(q + 1 + (__ffs((int)hi) - 1)) : -1;    // towards the front: the next one
+        QBox bx;
+        bx.ulx = (short)((q & 1) ? midx : ulx); bx.uly = (short)((q & 2) ? midy : uly);
+        bx.brx = (short)((q & 1) ? brx : midx); bx.bry = (short)((q & 2) ? bry : midy);
+        const int cb = beg + (q > 0 ? cnt[0] : 0) + (q > 1 ? cnt[1] : 0) + (q > 2 ? cnt[2] : 0);
+        L.seq[id] = (unsigned short)(seq0 + r);
+        L.box[id] = bx; L.begin[id] = (unsigned short)cb; L.count[id] = (unsigned short)c_q;
+        L.next[id] = (short)nxt; L.prev[id] = (short)prv;
+        if (c_q > 1) {
+            const int slot = n_exp + __popc(ex_mask & ((1u << q) - 1u));
+            if (slot < L.node_cap) L.ea[slot] = exp_key(c_q, seq0 + r, id);
+        }
+    }
+    // ---- the neighbours and the erased node (lane 0)
+    if (lane == 0) {
+        if (head0 != node) {
+            L.prev[head0] = (short)first;
+            L.next[nv.prev] = (short)nv.next;
+            if (nv.next >= 0) L.prev[nv.next] = (short)nv.prev;
+        } else if (nv.next >= 0) L.prev[nv.next] = (short)first;
+        L.free_list[nf0 - take] = (short)node;
+    }
+    if (nv.next < 0) t.tail = head0 != node ? nv.prev : first;
+    t.head = last;
+    t.size += k - 1;
+    t.seq = seq0 + k;
+    t.n_free = nf0 - take + 1;
+    t.n_alloc = min(alloc0 + fresh, L.node_cap);
+    n_to_expand += g;
+    n_exp = min(n_exp + g, max(n_exp, L.node_cap));                   // (the list stops growing at the capacity)
+}
+
 // ascending (size, creation order) -- CANONICAL (O1); keys are unique, so rank == final position
 __device__ inline void exp_sort(const unsigned long long *in, unsigned long long *out, int n, int lane)
 {
@@ -747,24 +793,12 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
     bool finish = false;
     int n_exp = 0;
     while (!finish) {
-        int prevSize = t.size, nToExpand = 0, lit = t.head, ch[4], cn[4], cs[4];
+        int prevSize = t.size, nToExpand = 0, lit = t.head;
         n_exp = 0;
         while (lit >= 0) {
             const NodeView nv = qt_view(L, lit);
             if (nv.cnt == 1) { lit = nv.next; continue; }
-            qt_divide(L, t, keys, gtmp, keys_global, nv, ch, cn, cs, lane);
-            int lit_prev = nv.prev;                        // pushing in front of the head changes the head's prev
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (ch[q] >= 0) {
-                    if (t.head == lit) lit_prev = ch[q];
-                    qt_push_front(L, t, ch[q], lane);
-                    if (cn[q] > 1) {
-                        nToExpand++;
-                        if (n_exp < L.node_cap) { if (lane == 0) L.ea[n_exp] = exp_key(cn[q], cs[q], ch[q]); n_exp++; }
-                    }
-                }
-            qt_erase_known(L, t, lit, lit_prev, nv.next, lane);
+            qt_split(L, t, keys, gtmp, keys_global, nv, lit, lane, n_exp, nToExpand);
             lit = nv.next;
             if (t.overflow) break;
         }
@@ -779,16 +813,7 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
                 for (int j = n_prev - 1; j >= 0; j--) {
                     const int nid = rfl((int)((uint32_t)L.eb[j] & 0xFFFu));
                     const NodeView nv = qt_view(L, nid);
-                    qt_divide(L, t, keys, gtmp, keys_global, nv, ch, cn, cs, lane);
-                    int nid_prev = nv.prev;
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        if (ch[q] >= 0) {
-                            if (t.head == nid) nid_prev = ch[q];
-                            qt_push_front(L, t, ch[q], lane);
-                            if (cn[q] > 1 && n_exp < L.node_cap) { if (lane == 0) L.ea[n_exp] = exp_key(cn[q], cs[q], ch[q]); n_exp++; }
-                        }
-                    qt_erase_known(L, t, nid, nid_prev, nv.next, lane);
+                    qt_split(L, t, keys, gtmp, keys_global, nv, nid, lane, n_exp, nToExpand);
                     if (t.size >= N || t.overflow) break;
                 }
                 if (t.size >= N || t.size == prevSize || t.overflow) finish = true;
