@@ -1012,8 +1012,17 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     const int b = blockIdx.y, lane = threadIdx.x & 63, half = lane >> 5, sl = lane & 31;
     const int gidx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;   // keypoint index in the image's output
     // locate level: prefix over the per-level selected counts
+    // (the per-level counts are fetched by eight lanes at once and handed round as scalars: read one after the
+    //  other -- once for the total, again for the level search -- they were a chain of ~15 dependent global loads
+    //  at the head of every wave)
     int l = 0, base = 0, total = 0;
-    for (int q = 0; q < a.g.nlevels; q++) total += a.sel_cnt[b * a.g.nlevels + q];
+    int cl[kOrbMaxLevels];
+    {
+        const int mine = (lane & 7) < a.g.nlevels ? a.sel_cnt[b * a.g.nlevels + (lane & 7)] : 0;
+        static_assert(kOrbMaxLevels <= 8, "one lane per level");
+#pragma unroll
+        for (int q = 0; q < kOrbMaxLevels; q++) { cl[q] = __builtin_amdgcn_readlane(mine, q); total += q < a.g.nlevels ? cl[q] : 0; }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.n_out[b] = min(total, a.out_cap);
         if (total > a.out_cap) atomicOr(a.overflow + b, 4);          // more keypoints than max_keypoints
@@ -1021,10 +1030,15 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     const bool valid = gidx < total && gidx < a.out_cap;
     if (__ballot(valid) == 0ull) return;
     const int gq = valid ? gidx : 0;                                  // an idle half shadows keypoint 0, stores nothing
-    for (l = 0; l < a.g.nlevels - 1; l++) {
-        const int c = a.sel_cnt[b * a.g.nlevels + l];
-        if (gq < base + c) break;
-        base += c;
+    {
+        // (branch-free search over the register copies: per-lane level, no memory in the loop)
+        int run = 0;
+#pragma unroll
+        for (int q = 0; q < kOrbMaxLevels - 1; q++) {
+            const bool beyond = q < a.g.nlevels - 1 && gq >= run + cl[q];        // the keypoint lies past level q
+            if (beyond) { l = q + 1; base = run + cl[q]; }
+            run += cl[q];
+        }
     }
     const int inst = b * a.g.nlevels + l;
     const float4 cand = a.lvl_cand[(int64_t)inst * a.cand_cap + a.sel[(int64_t)inst * a.sel_cap + (gq - base)]];
