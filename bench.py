@@ -71,7 +71,53 @@ def parse():
                          "multi-rank control flow with several ranks sharing one GPU: collectives on CPU copies)")
     ap.add_argument("--frames-cache", default="", help="torch file to load/save the rendered S0 frames "
                     "(keeps profiler traces free of the renderer's torch kernels)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.config5 and args.shard == "pairs":
+        # the ranks of --config5 run DIFFERENT step counts; --shard pairs has a collective in every step
+        ap.error("--config5 deals whole sequences to the ranks: it cannot be combined with --shard pairs")
+    return args
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves, one child
+    process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the child's environment, exactly what
+    `python -m torch.distributed.run --nproc-per-node N` would have set).  This parent never touches
+    the GPU (no torch import, no HIP call) and never execs: it waits, stops the other ranks as soon as
+    one of them fails (by exact PID) and returns the first non-zero exit code.  Rank 0's one JSON line
+    goes straight to the inherited stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n = args.gpus
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SVO_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, live, t_fail = 0, set(range(n)), None
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc, t_fail = code, time.monotonic()
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in live:
+                    procs[q].terminate()
+        if live:
+            time.sleep(0.05)
+            if t_fail is not None and time.monotonic() - t_fail > 20:      # a rank that ignored SIGTERM
+                for q in live:
+                    procs[q].kill()
+    return rc
 
 
 def kernel_source_hash():
@@ -93,17 +139,27 @@ def usable_cores():
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))                # before anything in this process touches the GPU
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    gloo = args.dist_backend == "gloo"
+    # --gpus is the contract: never report a run as N GPUs that was not N ranks on N cards
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: start it as `python bench.py --gpus N` "
+                         f"(it launches the ranks itself) or under torch.distributed.run with --nproc-per-node N")
+    n_dev = torch.cuda.device_count()               # counting devices does not initialise the GPU
+    if n_dev < 1 or (not gloo and n_dev < world):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} over {args.dist_backend} needs {world if not gloo else 1} GPU(s), this node "
+                         f"has {n_dev} (one rank per GPU; --dist-backend gloo rehearses the control flow with ranks sharing a card)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    gloo = args.dist_backend == "gloo"
     if gloo:                                       # rehearsal: every rank on the same card
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        local_rank = local_rank % max(n_dev, 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -122,13 +178,19 @@ def main():
     dev = torch.device("cuda", local_rank)
     coll_dev = torch.device("cpu") if gloo else dev
     by_pairs = args.shard == "pairs"
-    # ---- how many steps this rank runs, and on which chunks --------------------------------------
+    # ---- how many steps this rank runs, on which chunks, with how many pairs each ---------------------
     steps = args.steps
     my_seqs = None
+    plan = [(None, B, 0)] * steps                  # (sequence, pairs in this step, first pair's index in the sequence)
     if args.config5:
         deal = mg.deal_sequences(mg.KITTI_LENGTHS, world)
         my_seqs = deal[rank]
-        steps = mg.steps_for(mg.KITTI_LENGTHS, my_seqs, B)
+        plan = []
+        for s_ in my_seqs:                         # a sequence = full batches + one ragged last batch
+            n_pairs = mg.KITTI_LENGTHS[s_] - 1
+            plan += [(s_, min(B, n_pairs - o), o) for o in range(0, n_pairs, B)]
+        steps = len(plan)
+        assert steps == mg.steps_for(mg.KITTI_LENGTHS, my_seqs, B)
     NC = max(1, min(args.chunks, max(steps, 1)))
     F = NC * B + 1
     # ---- synthetic S0 frames: NC chunks of B pairs (+ the halo frame), resident in HBM ----------
@@ -163,41 +225,69 @@ def main():
     pose_off = pkg.STEP_DTYPE.fields["pose"][1]
     trel_off, ok_off = pkg.STEP_DTYPE.fields["T_rel_inv"][1], pkg.STEP_DTYPE.fields["ok"][1]
     state = {"k": 0}
+    # config #5: every sequence's relative motions + ok flags stay on the device until the sequence is
+    # chained (svo_chain_relative) and its FULL pose list goes to rank 0 in the one ragged gather
+    acc = ({s_: torch.zeros((mg.KITTI_LENGTHS[s_] - 1, 17), dtype=torch.float64, device=dev) for s_ in my_seqs}
+           if args.config5 else {})
+    gathered = {}
 
-    def chunk(k):
+    def chunk(k, n_pairs):
         c = k % NC
-        return L[c * B:c * B + B + 1, :, :W], R[c * B:c * B + B + 1, :, :W]
+        return L[c * B:c * B + n_pairs + 1, :, :W], R[c * B:c * B + n_pairs + 1, :, :W]
 
-    def collect(res):
+    def collect(res, item):
         """The only inter-GPU traffic: per pair 16 doubles (poses) or 17 (relative motion + ok) to rank 0."""
         host = (lambda t: t.cpu()) if gloo else (lambda t: t)
+        s_, n, off = item
         if by_pairs:       # chunks of ONE sequence: gather, then chain on rank 0
             g = mg.gather_relative(host(mg.field_view(res, trel_off, B, 16)), host(mg.int_field(res, ok_off, B)), rank, world, dst=0)
             if rank == 0:
                 ctx.chain_relative(g[0].to(dev), g[1].to(dev))
-        elif world > 1 and not args.config5:
+        elif args.config5:  # no collective per step (the ranks run different step counts): keep the records
+            acc[s_][off:off + n, :16] = mg.field_view(res, trel_off, n, 16)
+            acc[s_][off:off + n, 16] = mg.int_field(res, ok_off, n).to(torch.float64)
+        elif world > 1:
             mg.gather_poses(host(mg.poses_view(res, pose_off, B)), rank, world, dst=0)
 
-    def step():
+    def step(items):
         k = state["k"]
-        Lk, Rk = chunk(k)
+        Lk, Rk = chunk(k, items[k % len(items)][1])
         ctx.track_batch(Lk, Rk, results=res_buf[k & 1])
         # svo_track_batch(k) has already ordered the context's stream after the pose stage of batch
         # k-1 (it reuses that stage's buffers), so batch k-1's records are complete here
-        if k > 0 and (world > 1 or by_pairs):
-            collect(res_buf[(k - 1) & 1])
+        if k > 0 and (world > 1 or by_pairs or args.config5):
+            collect(res_buf[(k - 1) & 1], items[(k - 1) % len(items)])
         state["k"] = k + 1
 
-    def drain():
-        """Records of the last step: wait for its pose stage, then collect them."""
-        if state["k"] > 0 and (world > 1 or by_pairs):
+    def drain(items):
+        """Records of the last step: wait for its pose stage, then collect them; config #5: chain every
+        sequence on the device and send the full pose lists to rank 0 (one ragged gather)."""
+        k = state["k"]
+        if k > 0 and (world > 1 or by_pairs or args.config5):
             ctx.wait_results()
-            collect(res_buf[(state["k"] - 1) & 1])
+            collect(res_buf[(k - 1) & 1], items[(k - 1) % len(items)])
+        if args.config5:
+            lists = [ctx.chain_relative(acc[s_][:, :16].contiguous(), acc[s_][:, 16].to(torch.int32)) for s_ in my_seqs]
+            mine = torch.cat(lists, 0) if lists else torch.zeros((0, 16), dtype=torch.float64, device=dev)
+            if gloo:
+                ctx.sync()
+                mine = mine.cpu()
+            got = mg.gather_ragged(mine, rank, world, dst=0)
+            if rank == 0:
+                gathered.clear()
+                for r_, d in enumerate(mg.deal_sequences(mg.KITTI_LENGTHS, world)):
+                    o = 0
+                    for s_ in d:
+                        gathered[s_] = got[r_][o:o + mg.KITTI_LENGTHS[s_] - 1]
+                        o += mg.KITTI_LENGTHS[s_] - 1
+                    assert o == got[r_].shape[0], "ragged pose gather: a rank's message has the wrong length"
         state["k"] = 0
 
-    for _ in range(args.warmup):
-        step()
-    drain()
+    wplan = plan[:max(1, min(args.warmup, len(plan)))] if plan else plan
+    for _ in range(args.warmup if plan else 0):
+        step(wplan)
+    if plan or args.config5:
+        drain(plan if args.config5 else wplan)     # config #5: every rank takes part in the warm-up gather too
     torch.cuda.synchronize()
     if not args.no_timing_marks:
         ctx.enable_timing(True)
@@ -207,8 +297,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
-    drain()                                       # every step's records are collected inside the timed region
+        step(plan)
+    if plan or args.config5:
+        drain(plan)                               # every step's records are collected inside the timed region
     torch.cuda.synchronize()
     busy = time.perf_counter() - t0               # this rank's own busy time (config #5: ranks differ)
     if world > 1:
@@ -221,31 +312,29 @@ def main():
     ctx.enable_timing(False)
     last = res_buf[(steps - 1) & 1] if steps > 0 else res_buf[0]
     res = np.frombuffer(last.cpu().numpy().tobytes(), dtype=pkg.STEP_DTYPE)
+    n_last = plan[-1][1] if plan else 0            # pairs of the last step (config #5: ragged)
+    res = res[:n_last]
     n_ok = int(res["ok"].sum())
-    pts_total = int(res["n_prev_kps"].sum())
+    mean_kps = float(res["n_prev_kps"].sum()) / max(n_last, 1)
+    pts_total = int(round(mean_kps * (sum(it[1] for it in plan) / max(steps, 1))))   # points of a MEAN step: the stage times are means too
 
-    # ---- config #5: per-rank busy time and the ragged pose gather --------------------------------
+    # ---- config #5: per-rank busy time (the full pose lists were gathered inside the timed region) ----
     per_rank = None
     if args.config5:
-        mine = torch.tensor([[float(rank), float(steps), busy, float(sum(mg.KITTI_LENGTHS[s] for s in my_seqs))]],
+        mine = torch.tensor([[float(rank), float(steps), busy, float(sum(mg.KITTI_LENGTHS[s_] for s_ in my_seqs))]],
                             dtype=torch.float64, device=coll_dev)
         rows = mg.gather_ragged(mine, rank, world, dst=0)
-        # the poses of a rank's LAST step stand in for its sequences' pose files: ragged lengths
-        n_keep = min(B, max(1, (mg.KITTI_LENGTHS[my_seqs[-1]] - 1) % B or B)) if my_seqs else 0
-        poses = mg.poses_view(last, pose_off, B)[:n_keep]
-        got = mg.gather_ragged(poses.cpu() if gloo else poses, rank, world, dst=0)
         if rank == 0:
             tab = torch.cat(rows, 0).cpu().numpy()
             per_rank = [{"rank": int(r[0]), "sequences": mg.deal_sequences(mg.KITTI_LENGTHS, world)[int(r[0])],
                          "frames": int(r[3]), "steps": int(r[1]), "busy_s": round(float(r[2]), 4)} for r in tab]
-            assert [g.shape[0] for g in got] == [min(B, max(1, (mg.KITTI_LENGTHS[d[-1]] - 1) % B or B)) if d else 0
-                                                 for d in mg.deal_sequences(mg.KITTI_LENGTHS, world)]
+            assert sorted(gathered) == list(range(len(mg.KITTI_LENGTHS)))
+            assert all(gathered[s_].shape == (mg.KITTI_LENGTHS[s_] - 1, 16) for s_ in gathered)
 
     out = None
     if rank == 0:
         if args.config5:
-            all_steps = sum(mg.steps_for(mg.KITTI_LENGTHS, d, B) for d in mg.deal_sequences(mg.KITTI_LENGTHS, world))
-            pairs = all_steps * B
+            pairs = sum(n - 1 for n in mg.KITTI_LENGTHS)       # the last batch of a sequence is ragged: exact pair count
         else:
             pairs = world * B * steps
         value = pairs / elapsed
@@ -255,13 +344,15 @@ def main():
               "track_mode ORB_stereof2f_pnp")
         out = {
             "metric": "stereo frames/sec on KITTI-00 1241x376; LK-kernel achieved HBM GB/s vs peak",
-            "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": steps,
+            "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "ranks": world,
+            "dist_backend": (args.dist_backend + (" (RCCL)" if not gloo else " (rehearsal: ranks share a card)")) if world > 1 else None,
+            "steps": steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(steps, 1), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": wl + f", batched frame pairs ({B} per step, {NC} distinct chunks cycled), frames resident in HBM "
                                       "for `value`; `m1` = host-resident frames, H2D included",
-                       "pairs_per_step_per_gpu": B, "mean_keypoints_per_pair": round(pts_total / B, 1),
+                       "pairs_per_step_per_gpu": B, "mean_keypoints_per_pair": round(mean_kps, 1),
                        "pairs_ok_last_step": n_ok, "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
                        "parallelism": ((f"one sequence in {world} chunks of frame pairs (1-frame halo), RCCL gather of "
                                         f"relative motions, prefix product on rank 0") if by_pairs else
@@ -271,8 +362,12 @@ def main():
             busys = [p["busy_s"] for p in per_rank]
             out["config"]["config5"] = {"kitti_lengths": list(mg.KITTI_LENGTHS), "per_rank": per_rank,
                                         "imbalance_max_over_mean": round(max(busys) / (sum(busys) / len(busys)), 3),
-                                        "note": "--steps ignored: every rank runs ceil((len-1)/B) steps per sequence; frames are the "
-                                                "rank's rendered chunks cycled (sequence LENGTHS are modelled, not their content)"}
+                                        "poses_gathered": {"sequences": len(gathered), "pairs": int(sum(g.shape[0] for g in gathered.values())),
+                                                           "bytes": int(sum(g.numel() * 8 for g in gathered.values()))},
+                                        "note": "--steps ignored: every rank runs ceil((len-1)/B) steps per sequence, the last one ragged; "
+                                                "each sequence's relative motions are chained on its GPU and its FULL pose list goes to rank 0 "
+                                                "in one ragged gather inside the timed region; frames are the rank's rendered chunks cycled "
+                                                "(sequence LENGTHS are modelled, not their content)"}
         src_hash = kernel_source_hash()
         lk_ms = stage_ms.get("lk")
         if lk_ms:

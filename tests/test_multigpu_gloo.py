@@ -157,6 +157,9 @@ def test_bench_config5_two_ranks_rehearsal_on_one_gpu():
     assert [p["steps"] for p in c5["per_rank"]] == [(4660 + 23) // 24 + 3 * ((1100 + 23) // 24) + (270 + 23) // 24,
                                                      (4540 + 23) // 24 + (2760 + 23) // 24 + (800 + 23) // 24]
     assert out["value"] > 0 and c5["imbalance_max_over_mean"] >= 1.0 and all(p["busy_s"] > 0 for p in c5["per_rank"])
+    # every sequence's FULL pose list reached rank 0 (16 doubles per pair), not a stand-in
+    n_pairs = sum(n - 1 for n in (4541, 1101, 4661, 801, 271, 2761, 1101, 1101))
+    assert c5["poses_gathered"] == {"sequences": 8, "pairs": n_pairs, "bytes": n_pairs * 128}
 
 
 @pytest.mark.gpu
@@ -178,6 +181,59 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(shard):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["pairs_ok_last_step"] == 6 and out["roofline"]["frac"] > 0
+
+
+def _bench(*flags, env=None, timeout=600):
+    cmd = [sys.executable, os.path.join(conftest.ROOT, "bench.py")] + list(flags)
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run(cmd, capture_output=True, timeout=timeout, env=e)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """Plain `python bench.py --gpus 2` (no torch.distributed.run around it, the way the driver calls
+    `--gpus 1`): bench.py starts the two ranks itself and rank 0 reports n_gpus == 2.  gloo backend,
+    the ranks share the test box's one GPU."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "6", "--cpu-pairs", "0", "--dist-backend", "gloo")
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["steps"] == 2 and out["value"] > 0
+    assert out["dist_backend"].startswith("gloo")
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_nccl_ranks_than_gpus():
+    """`--gpus N` over nccl (RCCL) on a node with fewer than N cards exits non-zero with a message: a run is
+    never reported as N GPUs unless N ranks ran on N cards."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    n = torch.cuda.device_count() + 1
+    r = _bench("--gpus", str(n), "--steps", "1", "--warmup", "0", "--batch", "6", "--cpu-pairs", "0", timeout=300)
+    assert r.returncode != 0
+    assert f"needs {n} GPU(s)" in r.stderr.decode() and not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+def test_bench_gpus_flag_is_checked_without_a_gpu():
+    """CPU box: the launcher still starts N ranks, every rank finds no card and exits non-zero, the parent
+    returns that code (and prints no JSON line); a WORLD_SIZE that contradicts --gpus is refused too;
+    --config5 with --shard pairs (unequal step counts around a per-step collective) is an argument error."""
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-pairs", "0", "--dist-backend", "gloo", timeout=300)
+    if r.returncode == 0:
+        pytest.skip("this box has a GPU: covered by the gpu tests")
+    err = r.stderr.decode()
+    assert "this node has 0" in err and "stopping the other ranks" in err or "exited with" in err
+    assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    r = _bench("--gpus", "2", "--steps", "1", env={"RANK": "0", "WORLD_SIZE": "1"}, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE is 1" in r.stderr.decode()
+    r = _bench("--gpus", "2", "--config5", "--shard", "pairs", timeout=60)
+    assert r.returncode == 2 and "cannot be combined" in r.stderr.decode()
 
 
 def test_shard_pairs_partitions_every_pair_exactly_once():
