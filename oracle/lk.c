@@ -10,6 +10,15 @@
  * float once before the 2^-20 scale (upstream's own acctype=int64 variant) -- order independent,
  * so a 64-lane GPU reduction is bit-identical.  Everything else is upstream's single-precision
  * recipe with FP contraction off.
+ *
+ * SENSITIVITY SWITCH (orc_lk_set_accum, tests only; never the parity target): the same function with
+ * upstream's x86 accumulation instead -- acctype = itemtype = float (every OpenCV 3 build that is not
+ * the Tegra one), either in plain raster order (the scalar loop of lkpyramid.cpp) or in the lane order
+ * of its CV_SSE2 block as recalled from OpenCV 3.4 (A: four lanes over x = 0..19 plus a scalar tail
+ * for x = 20; b: two 4-lane accumulators fed by _mm_madd_epi16 pairs (d_k, d_k+4) over x = 0..15 plus
+ * a scalar tail for x = 16..20).  tests/test_lk_accum_sensitivity.py measures how far tracks and
+ * poses move between the three orders: the evidence that the pose bar holds whichever one the
+ * reference author's OpenCV used.
  */
 #include "svo_oracle.h"
 #include <math.h>
@@ -134,6 +143,10 @@ static int16_t *scharr_deriv(const uint8_t *lvl, int w, int h, int pad, int pitc
     return d;
 }
 
+static int g_lk_accum = 0;      /* 0 exact int64 (CANONICAL), 1 float raster order, 2 float SSE2 lane order */
+void orc_lk_set_accum(int mode) { g_lk_accum = (mode == 1 || mode == 2) ? mode : 0; }
+int orc_lk_get_accum(void) { return g_lk_accum; }
+
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 #define W_BITS 14
 
@@ -169,7 +182,11 @@ static void lk_point_level(const uint8_t *I, int pitchI, const int16_t *dI, int 
     int iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
     int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
+    const int accum = g_lk_accum;
     int64_t iA11 = 0, iA12 = 0, iA22 = 0;
+    float fA11 = 0.f, fA12 = 0.f, fA22 = 0.f;              /* upstream's float accumulators (sensitivity modes) */
+    float qA11[4] = {0.f, 0.f, 0.f, 0.f}, qA12[4] = {0.f, 0.f, 0.f, 0.f}, qA22[4] = {0.f, 0.f, 0.f, 0.f};
+    const int simdA = accum == 2 ? (win / 4) * 4 : 0;      /* x < simdA rides the four SSE lanes */
     int x, y;
     for (y = 0; y < win; y++) {
         const uint8_t *src = I + (ptrdiff_t)(y + ipy) * pitchI + ipx;
@@ -187,9 +204,31 @@ static void lk_point_level(const uint8_t *I, int pitchI, const int16_t *dI, int 
             iA11 += (int64_t)ixval * ixval;
             iA12 += (int64_t)ixval * iyval;
             iA22 += (int64_t)iyval * iyval;
+            if (accum) {
+                if (x < simdA) {                           /* _mm_cvtepi32_ps, _mm_mul_ps, _mm_add_ps per lane */
+                    float fx = (float)ixval, fy = (float)iyval;
+                    qA22[x & 3] += fy * fy;
+                    qA12[x & 3] += fx * fy;
+                    qA11[x & 3] += fx * fx;
+                } else {                                   /* iA11 += (itemtype)(ixval*ixval) */
+                    fA11 += (float)(ixval * ixval);
+                    fA12 += (float)(ixval * iyval);
+                    fA22 += (float)(iyval * iyval);
+                }
+            }
         }
     }
-    float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
+    float A11, A12, A22;
+    if (accum) {
+        if (accum == 2) {                                  /* iA11 += A11buf[0] + A11buf[1] + A11buf[2] + A11buf[3] */
+            fA11 += qA11[0] + qA11[1] + qA11[2] + qA11[3];
+            fA12 += qA12[0] + qA12[1] + qA12[2] + qA12[3];
+            fA22 += qA22[0] + qA22[1] + qA22[2] + qA22[3];
+        }
+        A11 = fA11 * FLT_SCALE; A12 = fA12 * FLT_SCALE; A22 = fA22 * FLT_SCALE;
+    } else {
+        A11 = (float)iA11 * FLT_SCALE; A12 = (float)iA12 * FLT_SCALE; A22 = (float)iA22 * FLT_SCALE;
+    }
     float D = A11 * A22 - A12 * A12;
     float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
                    (float)(2 * win * win);
@@ -214,17 +253,50 @@ static void lk_point_level(const uint8_t *I, int pitchI, const int16_t *dI, int 
         iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
         iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         int64_t ib1 = 0, ib2 = 0;
+        float fb1 = 0.f, fb2 = 0.f;
+        float qb0[4] = {0.f, 0.f, 0.f, 0.f}, qb1[4] = {0.f, 0.f, 0.f, 0.f};
+        const int simdB = accum == 2 ? (win / 8) * 8 : 0;
         for (y = 0; y < win; y++) {
             const uint8_t *Jp = J + (ptrdiff_t)(y + iny) * pitchJ + inx;
             const int16_t *Ip = Ibuf + y * win, *dIp = dIbuf + y * win * 2;
+            int dgrp[8];
             for (x = 0; x < win; x++) {
                 int diff = DESCALE(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + pitchJ] * iw10 +
                                    Jp[x + pitchJ + 1] * iw11, W_BITS - 5) - Ip[x];
                 ib1 += (int64_t)(diff * dIp[2 * x]);
                 ib2 += (int64_t)(diff * dIp[2 * x + 1]);
+                if (accum && x >= simdB) {                 /* ib1 += (itemtype)(diff*dIptr[0]) */
+                    fb1 += (float)(diff * dIp[2 * x]);
+                    fb2 += (float)(diff * dIp[2 * x + 1]);
+                } else if (accum) {
+                    dgrp[x & 7] = diff;
+                    if ((x & 7) == 7) {
+                        /* _mm_madd_epi16 pairs pixel k with k+4 of the group of eight, exactly in int32;
+                         * qb0 = [bx(0,4) by(0,4) bx(1,5) by(1,5)], qb1 = [bx(2,6) by(2,6) bx(3,7) by(3,7)] */
+                        const int16_t *g = dIp + 2 * (x - 7);
+                        int k;
+                        for (k = 0; k < 4; k++) {
+                            int sx = dgrp[k] * g[2 * k] + dgrp[k + 4] * g[2 * (k + 4)];
+                            int sy = dgrp[k] * g[2 * k + 1] + dgrp[k + 4] * g[2 * (k + 4) + 1];
+                            float *q = (k < 2) ? qb0 : qb1;
+                            q[(k & 1) * 2] += (float)sx;
+                            q[(k & 1) * 2 + 1] += (float)sy;
+                        }
+                    }
+                }
             }
         }
-        float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
+        float b1, b2;
+        if (accum) {
+            if (accum == 2) {                              /* bbuf = qb0 + qb1; ib1 += bbuf[0] + bbuf[2]; ib2 += bbuf[1] + bbuf[3] */
+                float bb0 = qb0[0] + qb1[0], bb1 = qb0[1] + qb1[1], bb2 = qb0[2] + qb1[2], bb3 = qb0[3] + qb1[3];
+                fb1 += bb0 + bb2;
+                fb2 += bb1 + bb3;
+            }
+            b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE;
+        } else {
+            b1 = (float)ib1 * FLT_SCALE; b2 = (float)ib2 * FLT_SCALE;
+        }
         float dlx = (A12 * b2 - A22 * b1) * D;
         float dly = (A12 * b1 - A11 * b2) * D;
         nextx += dlx; nexty += dly;

@@ -123,6 +123,18 @@ def lk_track(prev, nxt, pts, win=21, max_level=3, max_iter=30, eps=0.01, min_eig
     return out, st
 
 
+LK_ACCUM_EXACT, LK_ACCUM_FLOAT_RASTER, LK_ACCUM_FLOAT_SSE = 0, 1, 2
+
+
+def set_lk_accum(mode):
+    """Sensitivity switch of the LK sums A11, A12, A22, b1, b2 (process-wide; tests only): 0 = exact int64
+    (canonical choice C0, the parity target), 1 = upstream's float accumulation in raster order, 2 = in the
+    lane order of upstream's SSE2 block.  Returns the previous mode."""
+    old = lib().orc_lk_get_accum()
+    lib().orc_lk_set_accum(int(mode))
+    return old
+
+
 def circular_keep(p0, p1, p2, p3, p0r, s0, s1, s2, s3, match_err=3.0):
     arrs = [np.ascontiguousarray(a, np.float32) for a in (p0, p1, p2, p3, p0r)]
     sts = [np.ascontiguousarray(a, np.uint8) for a in (s0, s1, s2, s3)]

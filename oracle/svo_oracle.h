@@ -61,6 +61,10 @@ void orc_pyr_down(const uint8_t *src, int w, int h, int spitch, uint8_t *dst, in
 /* calcOpticalFlowPyrLK(prev, next, prev_pts, next_pts, status, err, Size(win,win), max_level,
  *                      TermCriteria(COUNT+EPS, max_iter, eps), flags = 0, min_eig)
  * threads > 1 splits the point range over OpenMP threads (results do not depend on it). */
+/* sensitivity switch (tests only): 0 = exact int64 sums (canonical, the parity target), 1 = upstream's
+ * float accumulation in raster order, 2 = in the lane order of upstream's SSE2 block.  Process-wide. */
+void orc_lk_set_accum(int mode);
+int orc_lk_get_accum(void);
 int orc_lk_track(const orc_pyramid *prev, const orc_pyramid *next,
                  const orc_pt2f *prev_pts, int n, orc_pt2f *next_pts, uint8_t *status,
                  int win, int max_iter, double eps, float min_eig, int threads);

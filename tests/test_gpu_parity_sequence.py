@@ -1,0 +1,273 @@
+"""Sequence-scale whole-step parity, HIP vs the CPU oracle (-m gpu): BASELINE config #1's "first 100 pairs"
+at 1241x376 instead of three pairs of one seed.
+
+  * 100 consecutive S0 pairs (seed 20200710), track_mode LK_stereof2f_pnp, through svo_track_batch, through
+    the online path (svo_add_frame) and through the run_kitti_stereo drop-in (per-frame loop and batched
+    runner) -- fail_stage, counts, ransac_iters, best_iter, lm_iters equal; tracks and RANSAC inlier masks
+    byte-equal; the chained pose within 1e-4 relative Frobenius (north_star) at EVERY frame, with the bound
+    actually observed asserted as well;
+  * a second seed (24 pairs); 24 ORB-mode pairs (config #3);
+  * config #4: one 1920x1080 whole step on exactly the 2000 strongest FAST corners, composed from the stage
+    API (svo_circular_match -> svo_triangulate -> svo_pnp_ransac).
+The oracle runs one 1-thread step per frame pair on a thread pool (pairs are independent: SURVEY.md 0.3).
+Reference call sites: src/tracking.cpp:258-344 (LK step), :168-249 (ORB step), :593-660, :464-501."""
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import conftest
+from test_gpu_parity_fullsize import POSE_TOL, TIGHT, _K, _check_record, relfro
+
+pytestmark = pytest.mark.gpu
+CHAIN_TIGHT = 1e-7          # observed bound of the CHAINED pose over 100 frames (each step is within 1e-9)
+HOST = os.path.join(conftest.ROOT, "stereo-visual-odometry_amd", "host")
+
+
+def _workers():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 32))
+
+
+@pytest.fixture(scope="module")
+def tc():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _render(synth, tc, w, h, n, seed):
+    seq = synth.StereoSequence(width=w, height=h, n_frames=n, seed=seed, device=tc.device("cuda", 0))
+    return seq, [tuple(x.cpu().numpy() for x in seq.render(t)) for t in range(n)]
+
+
+def _oracle_lk_sequence(oracle, seq, frames, **prm_kw):
+    """[(step record incl. tracks, 3-D points, RANSAC record incl. mask, chained pose)] for every pair."""
+    P1, P2 = seq.proj()
+    prm = oracle.make_params(P1, P2, **prm_kw)
+
+    def one(t):
+        kps = oracle.fast(frames[t - 1][0], thr=prm.fast_thr)
+        res, _, _ = oracle.lk_track_step(prm, *frames[t - 1], *frames[t], kps, np.eye(4), want_tracks=True, threads=1)
+        X = oracle.triangulate(P1, P2, res["tracks"][0], res["tracks"][1])
+        pnp = oracle.pnp_ransac(X, res["tracks"][3], _K(P1), iterations=prm.iterations, reproj_err=prm.reproj_err,
+                                confidence=prm.confidence)
+        assert pnp["n_inliers"] == res["n_inliers"]
+        return res, X, pnp
+
+    with ThreadPoolExecutor(max_workers=_workers()) as ex:
+        recs = list(ex.map(one, range(1, len(frames))))
+    pose, out = np.eye(4), []
+    for res, X, pnp in recs:
+        if res["ok"]:
+            pose = pose @ res["T_rel_inv"]          # frame_pose_ = frame_pose_ * T.inv()  (src/tracking.cpp:318)
+        out.append((res, X, pnp, pose.copy()))
+    return out
+
+
+def _check_batch(pkg, tc, seq, frames, ref, **ctx_kw):
+    h, w = frames[0][0].shape
+    P1, P2 = seq.proj()
+    c = pkg.Context(w, h, device=0, P1=P1, P2=P2, max_batch=len(frames) - 1, **ctx_kw)
+    L = tc.stack([tc.from_numpy(f[0]) for f in frames]).cuda()
+    R = tc.stack([tc.from_numpy(f[1]) for f in frames]).cuda()
+    res = c.track_batch(L, R)
+    worst = 0.0
+    for p, (r, X, pnp, pose) in enumerate(ref):
+        _check_record(res[p], r, pnp)
+        e = relfro(res[p]["pose"].reshape(4, 4), pose)
+        worst = max(worst, e)
+        assert e <= POSE_TOL, (p, e)
+    assert worst <= CHAIN_TIGHT, worst
+    c.close()
+    return res, worst
+
+
+def _check_online(pkg, seq, frames, ref, **ctx_kw):
+    h, w = frames[0][0].shape
+    P1, P2 = seq.proj()
+    c = pkg.Context(w, h, device=0, P1=P1, P2=P2, **ctx_kw)
+    rc, _ = c.add_frame(*frames[0])
+    assert rc == 0
+    worst = 0.0
+    for t in range(1, len(frames)):
+        r, X, pnp, pose = ref[t - 1]
+        rc, g = c.add_frame(*frames[t])
+        assert rc == (0 if r["ok"] else r["fail_stage"])
+        _check_record(g, r, pnp)
+        t1l, t1r, t2r, t2l, inl = c.last_tracks()
+        for got, want in zip((t1l, t1r, t2r, t2l), r["tracks"]):
+            assert got.tobytes() == want.tobytes(), t                       # matched tracks: byte-equal
+        assert inl.tobytes() == pnp["mask"].tobytes(), t                    # RANSAC inlier mask: byte-equal
+        if t % 10 == 1:       # the stage API on the same tracks: 3-D points and the winning hypothesis index
+            Xg = c.triangulate(P1, P2, t1l, t1r)
+            assert Xg.tobytes() == X.tobytes()
+            sg = c.pnp_ransac(Xg, t2l, _K(P1), iterations=c.cfg.iterations, reproj_err=c.cfg.reproj_err, confidence=c.cfg.confidence)
+            assert sg["best_iter"] == pnp["best_iter"] and sg["ransac_iters"] == pnp["ransac_iters"]
+        e = relfro(c.get_pose(), pose)
+        worst = max(worst, e)
+        assert e <= POSE_TOL, (t, e)
+    assert worst <= CHAIN_TIGHT, worst
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def s0_100(synth, tc):
+    return _render(synth, tc, 1241, 376, 101, 20200710)
+
+
+@pytest.fixture(scope="module")
+def s0_100_ref(oracle, s0_100):
+    seq, frames = s0_100
+    return _oracle_lk_sequence(oracle, seq, frames)
+
+
+def test_lk_100_pairs_batched_and_online(pkg, oracle, tc, s0_100, s0_100_ref):
+    seq, frames = s0_100
+    ref = s0_100_ref
+    assert len(ref) == 100 and all(r["ok"] for r, _, _, _ in ref)
+    assert min(r["n_tracked"] for r, _, _, _ in ref) > 1000
+    _, worst = _check_batch(pkg, tc, seq, frames, ref)
+    print(f"100-pair chained pose, HIP vs oracle: max rel. Frobenius {worst:.2e}")
+    _check_online(pkg, seq, frames, ref)
+
+
+def _write_pgm(path, img):
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(np.ascontiguousarray(img).tobytes())
+
+
+def test_lk_100_pairs_through_run_kitti_stereo(pkg, s0_100, s0_100_ref, tmp_path):
+    """The drop-in binary on the same 101 frames from disk: per-frame loop (the reference's System::Run) and
+    the batched runner; every row of the pose file against the oracle's chained pose."""
+    from test_host_api import _write_yaml
+    pkg.build_library()
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    seq, frames = s0_100
+    for cam in (0, 1):
+        os.makedirs(tmp_path / f"image_{cam}")
+    for t, (L, R) in enumerate(frames):
+        _write_pgm(tmp_path / "image_0" / f"{t:06d}.pgm", L)
+        _write_pgm(tmp_path / "image_1" / f"{t:06d}.pgm", R)
+    _write_yaml(tmp_path / "cfg.yaml", str(tmp_path), fx=seq.fx, fy=seq.fy, cx=seq.cx, cy=seq.cy)
+    with open(tmp_path / "cfg.yaml", encoding="utf-8") as f:
+        txt = f.read()
+    with open(tmp_path / "batched.yaml", "w", encoding="utf-8") as f:
+        f.write(txt + "batch_size: 32\ndecode_threads: 8\n")
+    want = np.stack([np.eye(4)] + [pose for _, _, _, pose in s0_100_ref])[:, :3]
+    for cfg in ("cfg.yaml", "batched.yaml"):
+        out = tmp_path / (cfg + ".poses")
+        r = subprocess.run([os.path.join(HOST, "run_kitti_stereo"), str(tmp_path / cfg), str(out)], capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        poses = np.loadtxt(out).reshape(-1, 3, 4)
+        assert poses.shape == want.shape
+        errs = [relfro(poses[t], want[t]) for t in range(len(want))]
+        assert max(errs) <= POSE_TOL and max(errs) <= 1e-6, (cfg, max(errs))     # the file holds 10 significant digits
+
+
+def test_lk_second_seed_24_pairs(pkg, oracle, tc, synth):
+    seq, frames = _render(synth, tc, 1241, 376, 25, 7)
+    ref = _oracle_lk_sequence(oracle, seq, frames)
+    assert sum(r["ok"] for r, _, _, _ in ref) >= 23
+    _check_batch(pkg, tc, seq, frames, ref)
+    _check_online(pkg, seq, frames, ref)
+
+
+def test_orb_24_pairs_batched_and_online(pkg, oracle, tc, s0_100):
+    """BASELINE config #3 over 24 consecutive pairs: both sides' ORB keypoints and descriptors byte-equal,
+    matches, RANSAC record, pose chain; online and batched."""
+    seq, frames = s0_100
+    frames = frames[:25]
+    h, w = frames[0][0].shape
+    P1, P2 = seq.proj()
+    prm = oracle.make_params(P1, P2, min_t2=0.05 ** 2, max_t2=10.0 ** 2)
+    with ThreadPoolExecutor(max_workers=_workers()) as ex:
+        flat = list(ex.map(lambda im: oracle.orb_extract(im)[:2], [im for fr in frames for im in fr]))
+    feats = [(flat[2 * t], flat[2 * t + 1]) for t in range(len(frames))]
+
+    def one(t):
+        (kL, dL), (kR, dR) = feats[t - 1]
+        (k2, d2), _ = feats[t]
+        r, _ = oracle.orb_track_step(prm, kL, dL, kR, dR, k2, d2, np.eye(4))
+        t2l, t1l, t1r = oracle.orb_robust_match(kL, dL, kR, dR, k2, d2)
+        X = oracle.triangulate(P1, P2, t1l, t1r)
+        return r, (t1l, t1r, t2l), oracle.pnp_ransac(X, t2l, _K(P1))
+
+    with ThreadPoolExecutor(max_workers=_workers()) as ex:
+        steps = list(ex.map(one, range(1, len(frames))))
+    pose, ref = np.eye(4), []
+    for r, tr, pnp in steps:
+        if r["ok"]:
+            pose = pose @ r["T_rel_inv"]
+        ref.append((r, tr, pnp, pose.copy()))
+    assert sum(r["ok"] for r, _, _, _ in ref) >= 23 and min(r["n_tracked"] for r, _, _, _ in ref) > 50
+    kw = dict(P1=P1, P2=P2, track_mode=pkg.MODE_ORB, min_move2=0.05 ** 2, max_move2=10.0 ** 2)
+    c = pkg.Context(w, h, device=0, **kw)
+    for t, fr in enumerate(frames):
+        rc, g = c.add_frame(*fr)
+        for side in (0, 1):
+            k, d = c.frame_keypoints(side, with_descriptors=True)
+            assert k.tobytes() == feats[t][side][0].tobytes() and d.tobytes() == feats[t][side][1].tobytes(), (t, side)
+        if t == 0:
+            continue
+        r, (t1l_r, t1r_r, t2l_r), pnp, pose = ref[t - 1]
+        assert rc == (0 if r["ok"] else r["fail_stage"])
+        _check_record(g, r, pnp)
+        t1l, t1r, _, t2l, inl = c.last_tracks()
+        assert t1l.tobytes() == t1l_r.tobytes() and t1r.tobytes() == t1r_r.tobytes() and t2l.tobytes() == t2l_r.tobytes()
+        assert inl.tobytes() == pnp["mask"].tobytes()
+        assert relfro(c.get_pose(), pose) <= CHAIN_TIGHT
+    c.close()
+    c = pkg.Context(w, h, device=0, max_batch=len(frames) - 1, **kw)
+    L = tc.stack([tc.from_numpy(f[0]) for f in frames]).cuda()
+    R = tc.stack([tc.from_numpy(f[1]) for f in frames]).cuda()
+    res = c.track_batch(L, R)
+    for p, (r, _, pnp, pose) in enumerate(ref):
+        _check_record(res[p], r, pnp)
+        assert relfro(res[p]["pose"].reshape(4, 4), pose) <= CHAIN_TIGHT
+    c.close()
+
+
+def test_hd_whole_step_on_exactly_2000_strongest_corners(pkg, oracle, tc, synth):
+    """BASELINE config #4 as SURVEY.md 8(d) words it: 1920x1080, EXACTLY 2000 points per frame = the 2000
+    highest-response FAST(20) corners (ties: row-major first).  The whole step is composed from the stage API:
+    svo_fast_detect -> selection -> svo_circular_match -> svo_triangulate -> svo_pnp_ransac -> gates."""
+    w, h = 1920, 1080
+    seq, frames = _render(synth, tc, w, h, 3, 1)
+    P1, P2 = seq.proj()
+    prm = oracle.make_params(P1, P2)
+    c = pkg.Context(w, h, device=0, P1=P1, P2=P2, max_keypoints=1 << 16)
+    pose_g, pose_r = np.eye(4), np.eye(4)
+    for t in (1, 2):
+        (L0, R0), (L1, R1) = frames[t - 1], frames[t]
+        kp = c.fast_detect(L0, threshold=20)
+        ref_kp = oracle.fast(L0, thr=20)
+        assert kp.tobytes() == ref_kp.tobytes() and len(kp) >= 2000
+        sel = ref_kp[np.sort(np.argsort(-ref_kp["response"], kind="stable")[:2000])]
+        assert len(sel) == 2000
+        for s, im in enumerate((L0, R0, L1, R1)):
+            c.build_pyramid(s, im)
+        pts = np.stack([sel["x"], sel["y"]], 1).astype(np.float32)
+        res, _, pose_r = oracle.lk_track_step(prm, L0, R0, L1, R1, sel, pose_r, want_tracks=True, threads=8)
+        got = c.circular_match((0, 1, 2, 3), pts)
+        assert got[0].shape[0] == res["n_tracked"] > 300
+        for k in range(4):
+            assert got[k].tobytes() == res["tracks"][k].tobytes()
+        X = oracle.triangulate(P1, P2, res["tracks"][0], res["tracks"][1])
+        Xg = c.triangulate(P1, P2, got[0], got[1])
+        assert Xg.tobytes() == X.tobytes()
+        pnp = oracle.pnp_ransac(X, res["tracks"][3], _K(P1))
+        sg = c.pnp_ransac(Xg, got[3], _K(P1))
+        assert sg["best_iter"] == pnp["best_iter"] and sg["ransac_iters"] == pnp["ransac_iters"] and sg["lm_iters"] == pnp["lm_iters"]
+        assert sg["n_inliers"] == pnp["n_inliers"] == res["n_inliers"] and np.array_equal(sg["mask"], pnp["mask"])
+        assert res["ok"] == 1
+        rc, pose_g, _ = oracle.gate_and_accumulate(sg["R"], sg["tvec"], pose_g)     # the gates are a few f64 ops: the oracle's on HIP's R, t
+        assert rc >= 0
+        assert relfro(pose_g, pose_r) <= POSE_TOL and relfro(pose_g, pose_r) <= TIGHT * 10
+    c.close()
