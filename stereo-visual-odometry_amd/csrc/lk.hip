@@ -50,7 +50,11 @@ constexpr int kSlots = 4;                                 // points per wave
 // exactly these words for the row pairs (r, r+1), (r+1, r+2), (r+2, r+3) of every lane's 10 columns;
 // formed while staging (4 v_perm per staged dword pair, 12 per lane) they replace the 30 v_perm +
 // 12 v_alignbyte every lane spent on its own copy, and the lane's reads become plain dword reads.
-constexpr int kQPairs = 23, kQCols = 28, kQTileDw = kQPairs * kQCols;   // 644 dwords per slot; two slots at a time
+// Stored COLUMN-MAJOR with 29 words per column, like the J tile below and for the same reason: a lane's
+// reads of its row pairs (row, row+1, row+2) of column offI + 7 seg + j then fall on banks 11 seg + row + d
+// (mod 32) -- conflict-free -- where the row-major order was 2-way conflicted for every row stride below 53
+// (half of all LDS-array cycles of the patch build; SQ_LDS_BANK_CONFLICT was 30 % of SQ_LDS_IDX_ACTIVE).
+constexpr int kQPairs = 23, kQCols = 28, kQColDw = 29, kQTileDw = kQCols * kQColDw;   // 812 dwords per slot
 // J tile: the same row-pair column words, 27 pairs x 28 columns around the window (3 spare on every side:
 // a window drifts that far at one level only rarely, and then the tile is staged again), stored
 // COLUMN-MAJOR with 29 words per column: lane (row, seg) reads column cx + 7 seg + k, pair cy + row, so
@@ -58,12 +62,14 @@ constexpr int kQPairs = 23, kQCols = 28, kQTileDw = kQPairs * kQCols;   // 644 d
 // row-major order is 2-way conflicted for every stride below 53.
 constexpr int kJPairs = 27, kJCols = 28, kJColDw = 29, kJTileDw = kJCols * kJColDw;   // 812 dwords per slot
 constexpr int kJMargin = 3;
-constexpr int kLdsDwPerWave = 2 * kQTileDw > kSlots * kJTileDw ? 2 * kQTileDw : kSlots * kJTileDw;   // 3248 dwords
+static_assert(kQTileDw == kJTileDw && kQColDw == kJColDw, "slot s's J tile takes over slot s's I tile");
+constexpr int kLdsDwPerWave = kSlots * kJTileDw;                                         // 3248 dwords
 constexpr int W_BITS = 14;
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+typedef const uint32_t __attribute__((address_space(3))) lds_cu32;
 
 // cvFloor: one instruction (floor + convert; the compiler's __float2int_rd is v_floor_f32 + v_cvt_i32_f32,
 // and on gfx950 conversions issue at half the rate of plain 32-bit adds -- profiles/r02_valu_roof.txt)
@@ -84,6 +90,13 @@ __device__ __forceinline__ int dot2_k(uint32_t a, uint32_t b, int k)
 {
     int r;
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+// first link of a chain that starts from 0: the inline constant instead of a zeroed accumulator (v_mov + v_dot2c)
+__device__ __forceinline__ int dot2_0(uint32_t a, uint32_t b)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 __device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -125,7 +138,7 @@ __device__ __forceinline__ bool window_oob(int ix, int iy, int w, int h)
 
 
 // per-lane constants of the pixel role
-struct PixLane { int row, seg; bool on; };
+struct PixLane { int row, seg; uint32_t onmask, qoff; };   // qoff: byte offset of the lane's first I-tile word inside a slot tile
 
 // ---- phase A for one slot: this lane's 7 patch pixels from the staged I tile -------------------
 // Tile rows row..row+3 = image rows ipy+row-1..ipy+row+2, bytes j = 0..9 = image columns
@@ -141,19 +154,22 @@ struct PixLane { int row, seg; bool on; };
 // the second term does not change, so the per-iteration mismatch chain starts from the negated
 // constant instead of subtracting I from every J sample (exact: integers, |partial| < 2^29).
 template <bool EDGE>
-__device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane &pl, int offI, uint32_t Wau,
+__device__ __forceinline__ void patch_slot(uint32_t tile_addr, const PixLane &pl, uint32_t Wau,
                                            uint32_t Wbu, int ipx, int ipy, int w, int h,
                                            uint32_t (&IxP)[4], uint32_t (&IyP)[4], int &nIIx, int &nIIy,
                                            int &pA11, int &pA12, int &pA22)
 {
     uint32_t IvP[4];
-    // (lane 63 carries no window pixel: zero weights make its I, Ix, Iy and sums vanish)
-    const uint32_t Wa = pl.on ? Wau : 0u, Wb = pl.on ? Wbu : 0u;
+    // (lane 63 carries no window pixel: zero weights make its I, Ix, Iy and sums vanish; `onmask` is
+    //  all ones in the pixel lanes, zero in lane 63 -- one v_and per weight word)
+    const uint32_t Wa = Wau & pl.onmask, Wb = Wbu & pl.onmask;
     uint32_t Q01[10], Q12[10], Q23[10];
     {
-        const uint32_t *q0 = tileI + pl.row * kQCols + offI + pl.seg * 7;
+        // ONE address per slot (tile_addr: the slot's tile + offI columns, wave-uniform; qoff: the lane's
+        // column / row-pair offset): everything else is an immediate offset of the reads
+        lds_cu32 *q0 = (lds_cu32 *)(size_t)(tile_addr + pl.qoff);
 #pragma unroll
-        for (int j = 0; j < 10; j++) { Q01[j] = q0[j]; Q12[j] = q0[kQCols + j]; Q23[j] = q0[2 * kQCols + j]; }
+        for (int j = 0; j < 10; j++) { Q01[j] = q0[j * kQColDw]; Q12[j] = q0[j * kQColDw + 1]; Q23[j] = q0[j * kQColDw + 2]; }
     }
     // vertical Scharr passes, rows A | B packed.  Both passes carry a factor 4 (coefficients 12 / 40
     // instead of 3 / 10; |4 d| <= 16320 still fits 16 bits): the interpolated derivative
@@ -200,11 +216,11 @@ __device__ __forceinline__ void patch_slot(const uint32_t *tileI, const PixLane 
         IvP[m] = perm_b32((uint32_t)iv[2 * m + 1], (uint32_t)iv[2 * m], 0x05040100u);
         IxP[m] = perm_b32((uint32_t)ix[2 * m + 1], (uint32_t)ix[2 * m], 0x07060302u);      // the two high halves
         IyP[m] = perm_b32((uint32_t)iy[2 * m + 1], (uint32_t)iy[2 * m], 0x07060302u);
-        pA11 = dot2(IxP[m], IxP[m], pA11);
-        pA12 = dot2(IxP[m], IyP[m], pA12);
-        pA22 = dot2(IyP[m], IyP[m], pA22);
-        sIIx = dot2(IvP[m], IxP[m], sIIx);
-        sIIy = dot2(IvP[m], IyP[m], sIIy);
+        pA11 = m == 0 ? dot2_0(IxP[m], IxP[m]) : dot2(IxP[m], IxP[m], pA11);
+        pA12 = m == 0 ? dot2_0(IxP[m], IyP[m]) : dot2(IxP[m], IyP[m], pA12);
+        pA22 = m == 0 ? dot2_0(IyP[m], IyP[m]) : dot2(IyP[m], IyP[m], pA22);
+        sIIx = m == 0 ? dot2_0(IvP[m], IxP[m]) : dot2(IvP[m], IxP[m], sIIx);
+        sIIy = m == 0 ? dot2_0(IvP[m], IyP[m]) : dot2(IvP[m], IyP[m], sIIy);
     }
     nIIx = -sIIx; nIIy = -sIIy;
 }
@@ -287,7 +303,9 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
                                          int wave_off, int lane)
 {
     PixLane pl;
-    pl.row = min(lane / 3, kWin - 1); pl.seg = lane - (lane / 3) * 3; pl.on = lane < 63;
+    pl.row = min(lane / 3, kWin - 1); pl.seg = lane - (lane / 3) * 3; pl.onmask = lane < 63 ? ~0u : 0u;
+    pl.qoff = (uint32_t)((pl.seg * 7 * kQColDw + pl.row) * 4);
+    asm volatile("" : "+v"(pl.onmask));                       // keep it a mask (one v_and per weight word), not a select
     const float half = 10.f;                     // (winSize - 1) * 0.5
     const float FLT_SCALE = 1.f / (1 << 20);
 
@@ -295,12 +313,13 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
     int nIIx[kSlots], nIIy[kSlots];
     // lane part of the J sample offset, the wave's LDS region included (bytes from the workgroup array)
     const int lane_off = (pl.seg * 7 * kJColDw + pl.row) * 4 + wave_off;
-    int q_pr[3], q_dc4[3], q_dst[3], jq_dst[3];   // staging item lane + 64 t = row pair * 7 + dword column
+    int q_pr[3], q_dc4[3], jq_dst[3];   // staging item lane + 64 t = row pair * 7 + dword column
 #pragma unroll
     for (int t = 0; t < 3; t++) {
         const int i = lane + 64 * t;
-        q_pr[t] = i / 7; q_dc4[t] = 4 * (i - q_pr[t] * 7); q_dst[t] = q_pr[t] * kQCols + q_dc4[t]; jq_dst[t] = q_dc4[t] * kJColDw + q_pr[t];
+        q_pr[t] = i / 7; q_dc4[t] = 4 * (i - q_pr[t] * 7); jq_dst[t] = q_dc4[t] * kJColDw + q_pr[t];
     }
+    const uint32_t lds_base = (uint32_t)(size_t)(lds_cu32 *)lds;   // byte address of the wave's LDS region
     int vround = 1 << (W_BITS - 5 - 1 + 7);                   // rounding of the J samples, scaled like the column words
     asm volatile("" : "+v"(vround));                          // keep it in a VGPR (see mismatch_slot)
     status = 1;
@@ -367,10 +386,9 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
             for (int t = 0; t < 3; t++) {
                 if (lane + 64 * t < kQPairs * 7) {
                     const uint32_t top = rI[s][t][0], bot = rI[s][t][1];
-                    uint4 q;
-                    q.x = perm_b32(bot, top, 0x0c040c00u); q.y = perm_b32(bot, top, 0x0c050c01u);
-                    q.z = perm_b32(bot, top, 0x0c060c02u); q.w = perm_b32(bot, top, 0x0c070c03u);
-                    *(uint4 *)(qt + q_dst[t]) = q;
+                    uint32_t *d = qt + jq_dst[t];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) d[c * kQColDw] = perm_b32(bot, top, 0x0c040c00u + 0x00010001u * c);
                 }
             }
         }
@@ -386,15 +404,14 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
         for (int s = 0; s < kSlots; s++) {
             pA[s][0] = pA[s][1] = pA[s][2] = 0;
             if (!((m_on >> (16 * s)) & 1ull)) continue;
-            const int offIs = __builtin_amdgcn_readlane(offI, 16 * s);
+            const uint32_t qaddr = lds_base + (uint32_t)((s * kQTileDw + __builtin_amdgcn_readlane(offI, 16 * s) * kQColDw) * 4);
             const uint32_t W01s = __builtin_amdgcn_readlane(WIa, 16 * s), W23s = __builtin_amdgcn_readlane(WIb, 16 * s);
             const int ipxs = __builtin_amdgcn_readlane(ipx, 16 * s), ipys = __builtin_amdgcn_readlane(ipy, 16 * s);
-            const uint32_t *qt = lds + s * kQTileDw;
             if (__builtin_expect(ipxs < 0 || ipxs + kWin >= w || ipys < 0 || ipys + kWin >= h, 0))
-                patch_slot<true>(qt, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
+                patch_slot<true>(qaddr, pl, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
                                  pA[s][0], pA[s][1], pA[s][2]);
             else
-                patch_slot<false>(qt, pl, offIs, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
+                patch_slot<false>(qaddr, pl, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
                                   pA[s][0], pA[s][1], pA[s][2]);
         }
         wave_lds_fence();                        // the J tiles reuse the I tiles' LDS
@@ -462,7 +479,8 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
                 if (!((m_it >> (16 * s)) & 1ull)) continue;
                 const int joffs = __builtin_amdgcn_readlane(joff, 16 * s);
                 const uint32_t Was = __builtin_amdgcn_readlane(Wa, 16 * s), Wbs = __builtin_amdgcn_readlane(Wb, 16 * s);
-                const uint32_t *pj = lds_wg + ((joffs + lane_off) >> 2);
+                // byte address = workgroup array + slot part (SGPR) + lane part: one add, no re-alignment of an index
+                lds_cu32 *pj = (lds_cu32 *)(size_t)((uint32_t)(size_t)(lds_cu32 *)lds_wg + (uint32_t)(joffs + lane_off));
                 uint32_t C[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) C[k] = pj[k * kJColDw];

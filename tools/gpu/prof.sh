@@ -4,7 +4,7 @@
 # Summaries -> gpurun_out/prof_*; tools/gpu/lk_pmc_json.py turns the lk_kernel rows into
 # profiles/rNN_lk_pmc.json (what bench.py's roofline object reads); copy what is to be judged into profiles/.
 mkdir -p gpurun_out
-CACHE=/tmp/s0_frames.pt
+CACHE=/tmp/s0_frames_c2.pt
 BARGS="--cpu-pairs 0 --no-secondary --chunks 2 --frames-cache $CACHE"
 python bench.py --steps 2 --warmup 1 $BARGS > gpurun_out/bench_cache.log 2>&1; echo "cache exit=$?"
 R=$GRAFT_REPO_ROOT
@@ -21,6 +21,6 @@ for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   f=$(find /tmp/prof_pmc$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 $R/tools/gpu/pmc_summary.py "$f" > $R/gpurun_out/prof_pmc$i.txt
 done
-cat $R/gpurun_out/prof_pmc*.txt > $R/gpurun_out/prof_pmc_summary.txt
+cat $R/gpurun_out/prof_pmc[0-9].txt > $R/gpurun_out/prof_pmc_summary.txt
 grep lk_kernel $R/gpurun_out/prof_pmc_summary.txt
 python3 $R/tools/gpu/lk_pmc_json.py $R/gpurun_out/prof_pmc_summary.txt $R/gpurun_out/prof_kernel_stats.csv > $R/gpurun_out/lk_pmc.json; cat $R/gpurun_out/lk_pmc.json
