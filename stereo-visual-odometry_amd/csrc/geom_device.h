@@ -154,6 +154,68 @@ __device__ inline void jacobi_svd_d(double *At, int as, double *W, double *Vt, i
     jacobi_finish_d<M, N>(At, as, W, Vt, vs, sort_rows);
 }
 
+// NP disjoint pairs (i_q, j_q) of At in ONE instruction stream (no Vt).  A lone wave issues a dependent f64
+// chain at one instruction per ~8 cycles, and a rotation is mostly such chains (the dot product, then
+// sqrt - div - sqrt - div of ~15 dependent instructions each): two independent pairs interleave into the
+// gaps, so a second pair costs a fraction of the first.  The arithmetic of a pair is exactly
+// jacobi_pair_d's; lanes whose pair needs no rotation compute on and store nothing; the whole call is
+// skipped when no lane of the wave rotates anything.
+template <int M, int N, int NP>
+__device__ __forceinline__ bool jacobi_pairs_d(double *At, int as, double *W, int ws, const int (&pi)[NP], const int (&pj)[NP])
+{
+    constexpr int m = M;
+    const double eps = SVO_DBL_EPS * 10;
+    double x[NP][M], y[NP][M], a[NP], b[NP], p[NP];
+    bool rot[NP], any = false;
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        const double *Ai = At + (pi[q] * m) * as, *Aj = At + (pj[q] * m) * as;
+#pragma unroll
+        for (int k = 0; k < m; k++) { x[q][k] = Ai[k * as]; y[q][k] = Aj[k * as]; }
+        a[q] = W[pi[q] * ws]; b[q] = W[pj[q] * ws];
+    }
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        double pp = 0;
+#pragma unroll
+        for (int k = 0; k < m; k++) pp += x[q][k] * y[q][k];
+        p[q] = pp;
+        rot[q] = !(fabs(pp) <= eps * sqrt(a[q] * b[q]));
+        any = any || rot[q];
+    }
+    if (!__any(any)) return false;
+    // (starting gamma's square root beside the convergence test's, ahead of this branch, measured 2 % slower)
+    double c[NP], sn[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        const double p2 = p[q] * 2;
+        const double beta = a[q] - b[q], gamma = sqrt(p2 * p2 + beta * beta);
+        jacobi_cs_d(p2, beta, gamma, c[q], sn[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        double na = 0, nb = 0;
+#pragma unroll
+        for (int k = 0; k < m; k++) {
+            const double t0 = c[q] * x[q][k] + sn[q] * y[q][k];
+            const double t1 = -sn[q] * x[q][k] + c[q] * y[q][k];
+            x[q][k] = t0; y[q][k] = t1;
+            na += t0 * t0; nb += t1 * t1;
+        }
+        a[q] = na; b[q] = nb;
+    }
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        if (rot[q]) {
+            double *Ai = At + (pi[q] * m) * as, *Aj = At + (pj[q] * m) * as;
+#pragma unroll
+            for (int k = 0; k < m; k++) { Ai[k * as] = x[q][k]; Aj[k * as] = y[q][k]; }
+            W[pi[q] * ws] = a[q]; W[pj[q] * ws] = b[q];
+        }
+    }
+    return any;
+}
+
 // The sweeps of jacobi_svd_d by the NW waves of a workgroup: lane = matrix (the lane-interleaved LDS
 // image; W in LDS too), wave = one of the pairs that can be rotated at the same time.  A rotation touches rows i, j and W[i], W[j] only, so rotations of disjoint pairs commute
 // exactly; the cyclic-by-rows order (0,1),(0,2),...,(10,11) is therefore equivalent -- bit for bit --
@@ -161,24 +223,59 @@ __device__ inline void jacobi_svd_d(double *At, int as, double *W, double *Vt, i
 // that share a row are ordered by their sum in the cyclic order (same i: by j; same j: by i; (a,b)
 // before (b,d): a < d; (c,a) before (a,b): c < b), and the pairs of one stage are disjoint.  For 12
 // columns 21 stages of up to 6 pairs replace 66 sequential pairs (6 columns: 9 stages of up to 3
-// replace 15); one workgroup barrier per stage.  Every wave of the workgroup must call this.  A matrix that has
+// replace 15); one workgroup barrier per stage.  21 is also the depth of the dependency graph (the
+// chain (0,1) ... (0,11), (1,11) ... (10,11)), so no schedule has fewer stages.  A stage with more
+// pairs than waves (five stages of the 12-column problem with four waves) gives its first waves TWO
+// pairs each, rotated in one interleaved instruction stream (jacobi_pairs_d) instead of one after the
+// other.  Every wave of the workgroup must call this.  A matrix that has
 // converged keeps being swept while others have not (a sweep without rotation changes nothing).
 template <int M, int N, int NW>
 __device__ inline void jacobi_sweeps_coop(double *At, int as, double *W, int ws, double *Vt, int vs, int wave)
 {
     constexpr int max_iter = M > 30 ? M : 30;
+    constexpr bool kPairs = N / 2 <= 2 * NW;                 // a stage never has more than two pairs per wave
+#ifdef SVO_PNP_DIAG
+    long long t_pair = 0, t_bar = 0; int n_sweeps = 0;
+#endif
     for (int iter = 0; iter < max_iter; iter++) {
         bool changed = false;
         for (int s = 1; s <= 2 * N - 3; s++) {
             const int i_lo = s > N - 1 ? s - (N - 1) : 0, cnt = (s - 1) / 2 - i_lo + 1;
-            for (int q = wave; q < cnt; q += NW) {
-                const int i = i_lo + q;
-                if (jacobi_pair_d<M, N>(At, as, W, ws, Vt, vs, i, s - i)) changed = true;
+#ifdef SVO_PNP_DIAG
+            const long long t0 = clock64();
+#endif
+            if (kPairs && Vt == nullptr) {
+                if (wave + NW < cnt) {                                  // this wave has two pairs in the stage
+                    const int i0 = i_lo + wave, i1 = i0 + NW;
+                    const int pi[2] = {i0, i1}, pj[2] = {s - i0, s - i1};
+                    if (jacobi_pairs_d<M, N, 2>(At, as, W, ws, pi, pj)) changed = true;
+                } else if (wave < cnt) {
+                    const int pi[1] = {i_lo + wave}, pj[1] = {s - i_lo - wave};
+                    if (jacobi_pairs_d<M, N, 1>(At, as, W, ws, pi, pj)) changed = true;
+                }
+            } else {
+                for (int q = wave; q < cnt; q += NW) {
+                    const int i = i_lo + q;
+                    if (jacobi_pair_d<M, N>(At, as, W, ws, Vt, vs, i, s - i)) changed = true;
+                }
             }
+#ifdef SVO_PNP_DIAG
+            const long long t1 = clock64();
+#endif
             __syncthreads();
+#ifdef SVO_PNP_DIAG
+            t_pair += t1 - t0; t_bar += clock64() - t1;
+#endif
         }
+#ifdef SVO_PNP_DIAG
+        n_sweeps++;
+#endif
         if (!__syncthreads_or(changed)) break;
     }
+#ifdef SVO_PNP_DIAG
+    if (N == 12 && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0)
+        printf("pnp_hyp diag: wave %d sweeps %d  in pairs %lld  at barriers %lld cycles\n", wave, n_sweeps, t_pair, t_bar);
+#endif
 }
 
 // The right-singular vector of the SMALLEST singular value of a 4x4 matrix (cv::SVD::compute +
@@ -668,6 +765,191 @@ __device__ inline void epnp5_d(Epnp5 &e, double *big, int bs, double Rout[9], do
     double v[48];
     epnp5_load_v_d(big, bs, v);
     epnp5_back_d<0>(e, v, big, bs, Rout, tout);
+}
+
+// ---- the same back part for a caller that keeps the hypothesis' state in MEMORY between the phases ----
+// (pnp_hyp_kernel: the front runs on one wave, the 12x12 SVD on four, the three beta approximations on
+// three; carried in registers across all of that, pws / us / alphas / cws / v / L were 300+ live f64
+// values per lane and most of the kernel ran out of scratch memory).  `hand` is the hand-over record of
+// the lane's hypothesis, element e at hand[e * hs]:
+//   0..14 pws   15..24 us   25..44 alphas   45..56 cws   57..104 v (ut rows 11, 10, 9, 8)
+// Every value is loaded where it is used and dies there; expressions and summation orders are those of
+// epnp5_back_d / epnp_R_and_t_d above, so the bits are the same.
+constexpr int kEpnpHandPws = 0, kEpnpHandUs = 15, kEpnpHandAlphas = 25, kEpnpHandCws = 45, kEpnpHandV = 57, kEpnpHandDoubles = 105;
+
+// rows [row0, row0 + nrows) of compute_L_6x10 from the sorted 12x12 image (rows 11..8 = v) into Lm (element e at
+// Lm[e * ls]); the three beta approximations share one L, so the rows are computed once, by different waves
+template <int ROW0, int NROWS>
+__device__ inline void epnp5_L_rows_d(const double *big, int bs, double *Lm, int ls)
+{
+#pragma unroll
+    for (int i = ROW0; i < ROW0 + NROWS; i++) {
+        const int a = i < 3 ? 0 : i < 5 ? 1 : 2, b = i < 3 ? i + 1 : i < 5 ? i - 1 : 3;
+        double dv[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) dv[q][c] = big[((11 - q) * 12 + 3 * a + c) * bs] - big[((11 - q) * 12 + 3 * b + c) * bs];
+        double *row = Lm + 10 * i * ls;
+        row[0 * ls] = dot3_d(dv[0], dv[0]);
+        row[1 * ls] = 2.0 * dot3_d(dv[0], dv[1]);
+        row[2 * ls] = dot3_d(dv[1], dv[1]);
+        row[3 * ls] = 2.0 * dot3_d(dv[0], dv[2]);
+        row[4 * ls] = 2.0 * dot3_d(dv[1], dv[2]);
+        row[5 * ls] = dot3_d(dv[2], dv[2]);
+        row[6 * ls] = 2.0 * dot3_d(dv[0], dv[3]);
+        row[7 * ls] = 2.0 * dot3_d(dv[1], dv[3]);
+        row[8 * ls] = 2.0 * dot3_d(dv[2], dv[3]);
+        row[9 * ls] = dot3_d(dv[3], dv[3]);
+    }
+}
+// compute_rho from the control points of the hand-over record into rho_m[0..5]
+__device__ inline void epnp5_rho_d(const double *hand, int hs, double *rho_m, int rs)
+{
+    double cws[4][3];
+#pragma unroll
+    for (int i = 0; i < 12; i++) cws[i / 3][i % 3] = hand[(kEpnpHandCws + i) * hs];
+    rho_m[0 * rs] = dist2_d(cws[0], cws[1]); rho_m[1 * rs] = dist2_d(cws[0], cws[2]);
+    rho_m[2 * rs] = dist2_d(cws[0], cws[3]); rho_m[3 * rs] = dist2_d(cws[1], cws[2]);
+    rho_m[4 * rs] = dist2_d(cws[1], cws[3]); rho_m[5 * rs] = dist2_d(cws[2], cws[3]);
+}
+
+// compute_ccs + compute_pcs + solve_for_sign + estimate_R_and_t + reprojection_error, operands from `hand`
+__device__ inline double epnp_R_and_t_mem_d(const double *hand, int hs, double fu, double fv, double uc, double vc,
+                                            const double (&betas)[4], double R[9], double t[3], double *ws, int st)
+{
+    const int n = 5;
+    double ccs[4][3], pcs[15];
+#pragma unroll
+    for (int i = 0; i < 4; i++) ccs[i][0] = ccs[i][1] = ccs[i][2] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) ccs[j][k] += betas[i] * hand[(kEpnpHandV + 12 * i + 3 * j + k) * hs];
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        double a[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) a[q] = hand[(kEpnpHandAlphas + 4 * i + q) * hs];
+#pragma unroll
+        for (int j = 0; j < 3; j++) pcs[3 * i + j] = a[0] * ccs[0][j] + a[1] * ccs[1][j] + a[2] * ccs[2][j] + a[3] * ccs[3][j];
+    }
+    if (pcs[2] < 0.0) {
+#pragma unroll
+        for (int i = 0; i < 3 * n; i++) pcs[i] = -pcs[i];          // (the ccs are not used after this point)
+    }
+    double pws[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) pws[i] = hand[(kEpnpHandPws + i) * hs];
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < n; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { pc0[j] += pcs[3 * i + j]; pw0[j] += pws[3 * i + j]; }
+#pragma unroll
+    for (int j = 0; j < 3; j++) { pc0[j] /= n; pw0[j] /= n; }
+    double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, abt_d[3];
+    double *abt_ut = ws, *abt_vt = ws + 9 * st;
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        const double *pc = pcs + 3 * i, *pw = pws + 3 * i;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
+            abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
+            abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
+        }
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) abt_ut[(j * 3 + i) * st] = abt[i * 3 + j];
+    jacobi_svd_d<3, 3>(abt_ut, st, abt_d, abt_vt, st, false);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            R[i * 3 + j] = abt_ut[(0 * 3 + i) * st] * abt_vt[(0 * 3 + j) * st] + abt_ut[(1 * 3 + i) * st] * abt_vt[(1 * 3 + j) * st] +
+                           abt_ut[(2 * 3 + i) * st] * abt_vt[(2 * 3 + j) * st];
+    const double det = R[0] * R[4] * R[8] + R[1] * R[5] * R[6] + R[2] * R[3] * R[7] -
+                       R[2] * R[4] * R[6] - R[1] * R[3] * R[8] - R[0] * R[5] * R[7];
+    if (det < 0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
+    t[0] = pc0[0] - dot3_d(R, pw0);
+    t[1] = pc0[1] - dot3_d(R + 3, pw0);
+    t[2] = pc0[2] - dot3_d(R + 6, pw0);
+    double sum2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        const double *pw = pws + 3 * i;
+        double Xc = dot3_d(R, pw) + t[0], Yc = dot3_d(R + 3, pw) + t[1];
+        double inv_Zc = 1.0 / (dot3_d(R + 6, pw) + t[2]);
+        double ue = uc + fu * Xc * inv_Zc, ve = vc + fv * Yc * inv_Zc;
+        double u = hand[(kEpnpHandUs + 2 * i) * hs], vv = hand[(kEpnpHandUs + 2 * i + 1) * hs];
+        sum2 += sqrt((u - ue) * (u - ue) + (vv - ve) * (vv - ve));
+    }
+    return sum2 / n;
+}
+
+// find_betas_approx_N + gauss_newton + R, t, reprojection error of ONE approximation N = 1, 2, 3
+// (L and rho in memory, element e at Lm[e * ls] / rho_m[e * ls]: read where they are used)
+template <int N>
+__device__ inline double epnp5_betas_pose_d(const double *Lm, const double *rho_m, int ls, const double *hand, int hs, double fu,
+                                            double fv, double uc, double vc, double *ws, int st, double Rout[9], double tout[3])
+{
+    double betas[4], bb[5], rho[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) rho[i] = rho_m[i * ls];
+    {
+        constexpr int nc = N == 1 ? 4 : (N == 2 ? 3 : 5);
+        double Lr[6 * nc];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < nc; j++) {
+                const int col = N == 1 ? (j == 0 ? 0 : j == 1 ? 1 : j == 2 ? 3 : 6) : j;
+                Lr[i * nc + j] = Lm[(10 * i + col) * ls];
+            }
+        svd_solve_d<6, nc>(Lr, rho, bb, ws, st);
+    }
+    if (N == 1) {
+        if (bb[0] < 0) {
+            betas[0] = sqrt(-bb[0]);
+            betas[1] = -bb[1] / betas[0]; betas[2] = -bb[2] / betas[0]; betas[3] = -bb[3] / betas[0];
+        } else {
+            betas[0] = sqrt(bb[0]);
+            betas[1] = bb[1] / betas[0]; betas[2] = bb[2] / betas[0]; betas[3] = bb[3] / betas[0];
+        }
+    } else {
+        if (bb[0] < 0) {
+            betas[0] = sqrt(-bb[0]);
+            betas[1] = (bb[2] < 0) ? sqrt(-bb[2]) : 0.0;
+        } else {
+            betas[0] = sqrt(bb[0]);
+            betas[1] = (bb[2] > 0) ? sqrt(bb[2]) : 0.0;
+        }
+        if (bb[1] < 0) betas[0] = -betas[0];
+        betas[2] = N == 3 ? bb[3] / betas[0] : 0.0;
+        betas[3] = 0.0;
+    }
+    for (int it = 0; it < 5; it++) {
+        double A[24], b[6], x[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double r[10];
+#pragma unroll
+            for (int q = 0; q < 10; q++) r[q] = Lm[(10 * i + q) * ls];
+            double *ra = A + i * 4;
+            ra[0] = 2 * r[0] * betas[0] + r[1] * betas[1] + r[3] * betas[2] + r[6] * betas[3];
+            ra[1] = r[1] * betas[0] + 2 * r[2] * betas[1] + r[4] * betas[2] + r[7] * betas[3];
+            ra[2] = r[3] * betas[0] + r[4] * betas[1] + 2 * r[5] * betas[2] + r[8] * betas[3];
+            ra[3] = r[6] * betas[0] + r[7] * betas[1] + r[8] * betas[2] + 2 * r[9] * betas[3];
+            b[i] = rho[i] - (r[0] * betas[0] * betas[0] + r[1] * betas[0] * betas[1] +
+                             r[2] * betas[1] * betas[1] + r[3] * betas[0] * betas[2] +
+                             r[4] * betas[1] * betas[2] + r[5] * betas[2] * betas[2] +
+                             r[6] * betas[0] * betas[3] + r[7] * betas[1] * betas[3] +
+                             r[8] * betas[2] * betas[3] + r[9] * betas[3] * betas[3]);
+        }
+        epnp_qr_solve_d(A, b, x);
+        for (int i = 0; i < 4; i++) betas[i] += x[i];
+    }
+    return epnp_R_and_t_mem_d(hand, hs, fu, fv, uc, vc, betas, Rout, tout, ws, st);
 }
 
 // cv::Rodrigues vector -> matrix (+ 3x9 Jacobian)

@@ -117,6 +117,7 @@ struct PnpArgs {
     int phase_base, phase_cap, phase_index;                 // hypotheses [phase_base, phase_base + phase_cap) in this phase
     int score_chunk;                                        // points per scoring workgroup (grid.z chunks)
     int refit_svd;                                          // 1: always take the SVD route of the refit's solves (SVO_REFIT_SVD=1; tests)
+    double *hand;                                           // EPnP hand-over records: per item kPhaseBlocks x 105 x 64 doubles (pnp_hyp_body)
 };
 
 __device__ inline double wave_allsum_f64(double v)
@@ -205,18 +206,28 @@ __global__ __launch_bounds__(64) void pnp_begin_kernel(PnpArgs a)
 // of the 12x12 M^T M, 66 pairs per sweep), so the block is spread over the CU's four SIMDs:
 //   * wave 0 runs the lane-private front part (control points, barycentric coordinates, M^T M);
 //   * all four waves rotate DISJOINT pairs of the 12x12 problem at the same time
-//     (jacobi_sweeps_coop: 21 barrier-separated stages instead of 66 sequential pairs, same bits);
+//     (jacobi_sweeps_coop: 21 barrier-separated stages instead of 66 sequential pairs, same bits; a
+//     stage with five or six pairs gives a wave two of them in one interleaved instruction stream);
 //   * waves 0..2 run epnp's three beta approximations (N = 1, 2, 3) side by side; wave 0 applies
 //     compute_pose's selection rule.
-// LDS: the lane-interleaved 12x12 image + the singular values (156 doubles per lane, 78 KB -- two
-// workgroups per CU); after the SVD the same area is the hand-over buffer and the three waves'
-// workspaces.  Two builds of the same body: the batched path launches thousands of blocks beside the
+// Between the phases the hypothesis' state lives in MEMORY, not in registers: the front writes pws / us /
+// alphas / cws (57 doubles) to a lane-interleaved hand-over record in the workspace (global memory: the
+// LDS is full of the 12x12 image), wave 0 adds the four null-space vectors after the SVD, and the back part
+// loads what it needs where it needs it (epnp5_L_rho_d, epnp5_betas_pose_d).  Carried in registers across
+// the whole kernel the same state was 300+ live f64 values per lane: 1 122 spilled VGPRs in the
+// 256-register build, 243 in the 512-register one.  No wave leaves before the last barrier.
+// LDS: the lane-interleaved 12x12 image + the singular values (156 doubles per lane); after the SVD the same
+// area holds L and rho (shared by the three approximations: 66 doubles) and the three waves' workspaces:
+// 188 doubles per lane, 94 KB -- one workgroup per CU, which is also what the launch beside the next
+// batch's front end wants (two would lock every LDS-staged front-end kernel out of the CU).
+// Two builds of the same body: the batched path launches thousands of blocks beside the
 // next batch's front end and gets 256 registers per wave (two waves per SIMD: a 512-register wave owns
 // a SIMD's register file and starves the kernels it overlaps -- ORB mode: +1 ms per 256 pairs); the
 // LATENCY build, for launches that leave the chip mostly empty (the online path: one pair's 64
 // hypotheses are all there is), takes all 512.
-constexpr size_t kPnpLdsBytes = (size_t)((144 + 12) * 64) * sizeof(double);
-constexpr size_t kPnpLdsBytesBeside = 84 * 1000;           // > 80 KB: one workgroup per CU (see launch_pnp_pipeline)
+constexpr int kPnpLdsDoubles = 66 + 40 + 27 + 55;          // per lane: L + rho + the three solve workspaces (> the 144 + 12 of the SVD)
+constexpr size_t kPnpLdsBytes = (size_t)(kPnpLdsDoubles * 64) * sizeof(double);   // 94 KB: ONE workgroup per CU
+constexpr int kPhaseBlocks = kPhaseHyps / kHypBlock;       // hand-over records: one per block of a phase
 __device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem_w)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
@@ -224,22 +235,29 @@ __device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem_
     const int h = blockIdx.x * kHypBlock + lane;             // hypothesis index inside the phase
     if (st->next_base != a.phase_base) return;               // phase not needed (uniform for the block)
     if (blockIdx.x == gridDim.x - 1) {
-        if (wave) return;
-        // the drawer: subsets of the NEXT phase into the other buffer (see pnp_begin_kernel)
+        // the drawer: subsets of the NEXT phase into the other buffer (see pnp_begin_kernel); this block
+        // has no barrier
         const int next = a.phase_base + a.phase_cap, niters = a.iterations > 1 ? a.iterations : 1;
         const int n = st->n;
-        if (next < niters && n > 5 && st->phase_hyps > 0) {
+        if (wave == 0 && next < niters && n > 5 && st->phase_hyps > 0) {
             const int more = niters - next < kPhaseHyps ? niters - next : kPhaseHyps;
             const uint64_t rng = draw_subsets(st->rng, n, more, a.subsets + ((int64_t)b * 2 + (a.phase_index + 1) % 2) * kPhaseHyps * 5, lane);
             if (lane == 0) st->rng = rng;
         }
         return;
     }
-    if (blockIdx.x * kHypBlock >= st->phase_hyps) return;    // block beyond the phase
+    if (blockIdx.x * kHypBlock >= st->phase_hyps) return;    // block beyond the phase (uniform)
     const bool active = h < st->phase_hyps;                  // idle lanes solve points 0..4 (they take part in the barriers)
     double *big = pnp_smem_w + lane, *W = pnp_smem_w + 144 * 64 + lane;
-    Epnp5 e;
+    double *hand = a.hand + ((int64_t)b * kPhaseBlocks + blockIdx.x) * (kEpnpHandDoubles * 64) + lane;   // element e at hand[e * 64]
+#ifdef SVO_PNP_DIAG
+    long long tq[6]; tq[0] = clock64();
+#define PNP_STAMP(i) tq[i] = clock64()
+#else
+#define PNP_STAMP(i)
+#endif
     if (wave == 0) {
+        Epnp5 e;
         const float *X3 = a.X3 + (int64_t)b * a.stride * 3;
         const float2 *img = a.img + (int64_t)b * a.stride;
         const int *my = a.subsets + (((int64_t)b * 2 + a.phase_index % 2) * kPhaseHyps + h) * 5;
@@ -255,58 +273,66 @@ __device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem_
             e.us[2 * i + 1] = (double)yn * fy + cy;
         }
         epnp5_front_d(e, big, 64);
+        for (int i = 0; i < 15; i++) hand[(kEpnpHandPws + i) * 64] = e.pws[i];
+        for (int i = 0; i < 10; i++) hand[(kEpnpHandUs + i) * 64] = e.us[i];
+        for (int i = 0; i < 20; i++) hand[(kEpnpHandAlphas + i) * 64] = e.alphas[i];
+        for (int i = 0; i < 12; i++) hand[(kEpnpHandCws + i) * 64] = e.cws[i / 3][i % 3];
         jacobi_init_d<12, 12>(big, 64, W, 64, nullptr, 0);
     }
     __syncthreads();
+    PNP_STAMP(1);
     jacobi_sweeps_coop<12, 12, 4>(big, 64, W, 64, nullptr, 0, wave);
-    if (wave == 3) return;
-    // epnp's three beta approximations on waves 0..2: wave 0 hands its lane-private state over through LDS
-    double *xfer = pnp_smem_w + lane;                        // 57 doubles per lane: rows 0..4 of the image (rows 8..11 are still needed)
+    PNP_STAMP(2);
     if (wave == 0) {
         double d12[12];
         jacobi_finish_d<12, 12>(big, 64, d12, nullptr, 0, true);
-        for (int i = 0; i < 15; i++) xfer[i * 64] = e.pws[i];
-        for (int i = 0; i < 10; i++) xfer[(15 + i) * 64] = e.us[i];
-        for (int i = 0; i < 20; i++) xfer[(25 + i) * 64] = e.alphas[i];
-        for (int i = 0; i < 12; i++) xfer[(45 + i) * 64] = e.cws[i / 3][i % 3];
+        for (int i = 0; i < 4; i++)                          // ut rows 11, 10, 9, 8
+            for (int k = 0; k < 12; k++) hand[(kEpnpHandV + i * 12 + k) * 64] = big[((11 - i) * 12 + k) * 64];
     }
-    __syncthreads();
-    if (wave) {
-        e.fu = a.fx; e.fv = a.fy; e.uc = a.cx; e.vc = a.cy;
-        for (int i = 0; i < 15; i++) e.pws[i] = xfer[i * 64];
-        for (int i = 0; i < 10; i++) e.us[i] = xfer[(15 + i) * 64];
-        for (int i = 0; i < 20; i++) e.alphas[i] = xfer[(25 + i) * 64];
-        for (int i = 0; i < 12; i++) e.cws[i / 3][i % 3] = xfer[(45 + i) * 64];
-    }
-    double v[48];
-    epnp5_load_v_d(big, 64, v);
-    __syncthreads();                                         // the whole area is free now
+    __syncthreads();                                         // sorted image + hand-over record complete
+    // L (6 x 10) and rho are the same for the three approximations: computed once, two rows per wave and rho by
+    // the fourth, into the dead rows 0..5 of the image (the null-space vectors they are read from are rows 8..11)
+    double *Lm = big, *rho_m = big + 60 * 64;
+    if (wave == 0) epnp5_L_rows_d<0, 2>(big, 64, Lm, 64);
+    else if (wave == 1) epnp5_L_rows_d<2, 2>(big, 64, Lm, 64);
+    else if (wave == 2) epnp5_L_rows_d<4, 2>(big, 64, Lm, 64);
+    else epnp5_rho_d(hand, 64, rho_m, 64);
+    __syncthreads();                                         // everything behind L and rho is free now
+    PNP_STAMP(3);
     PnpHyp out;
-    double rep;
-    // workspaces: svd_solve of 6 x 4 / 6 x 3 / 6 x 5 (M*N + N*N doubles: 40, 27, 55), results from 122 on
-    double *ws = big + (wave == 0 ? 0 : wave == 1 ? 40 : 67) * 64;
-    if (wave == 0) rep = epnp5_back_d<1>(e, v, ws, 64, out.R, out.t);
-    else if (wave == 1) rep = epnp5_back_d<2>(e, v, ws, 64, out.R, out.t);
-    else rep = epnp5_back_d<3>(e, v, ws, 64, out.R, out.t);
-    if (wave) {
-        double *dst = big + (122 + (wave - 1) * 13) * 64;
+    double rep = 0;
+    // workspaces behind L and rho: svd_solve of 6 x 4 / 6 x 3 / 6 x 5 (M*N + N*N doubles: 40, 27, 55); a wave's
+    // results go to the start of its own workspace
+    double *ws = big + (66 + (wave == 0 ? 0 : wave == 1 ? 40 : 67)) * 64;
+    if (wave == 0) rep = epnp5_betas_pose_d<1>(Lm, rho_m, 64, hand, 64, a.fx, a.fy, a.cx, a.cy, ws, 64, out.R, out.t);
+    else if (wave == 1) rep = epnp5_betas_pose_d<2>(Lm, rho_m, 64, hand, 64, a.fx, a.fy, a.cx, a.cy, ws, 64, out.R, out.t);
+    else if (wave == 2) rep = epnp5_betas_pose_d<3>(Lm, rho_m, 64, hand, 64, a.fx, a.fy, a.cx, a.cy, ws, 64, out.R, out.t);
+    PNP_STAMP(4);
+#ifdef SVO_PNP_DIAG
+    if (blockIdx.x == 0 && b == 0 && lane == 0)
+        printf("pnp_hyp diag: phase_base %d wave %d  front %lld  sweeps %lld  finish+L %lld  back %lld cycles\n", a.phase_base, wave,
+               tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3]);
+#endif
+    if (wave == 1 || wave == 2) {
+        double *dst = ws;
         for (int i = 0; i < 9; i++) dst[i * 64] = out.R[i];
         for (int i = 0; i < 3; i++) dst[(9 + i) * 64] = out.t[i];
         dst[12 * 64] = rep;
     }
     __syncthreads();
-    if (wave) return;
-    // epnp::compute_pose: "N = 1; if (rep[2] < rep[1]) N = 2; if (rep[3] < rep[N]) N = 3"
+    if (wave == 0) {
+        // epnp::compute_pose: "N = 1; if (rep[2] < rep[1]) N = 2; if (rep[3] < rep[N]) N = 3"
 #pragma unroll
-    for (int w = 1; w <= 2; w++) {
-        const double *src = big + (122 + (w - 1) * 13) * 64;
-        if (src[12 * 64] < rep) {
-            rep = src[12 * 64];
-            for (int i = 0; i < 9; i++) out.R[i] = src[i * 64];
-            for (int i = 0; i < 3; i++) out.t[i] = src[(9 + i) * 64];
+        for (int w = 1; w <= 2; w++) {
+            const double *src = big + (66 + (w == 1 ? 40 : 67)) * 64;
+            if (src[12 * 64] < rep) {
+                rep = src[12 * 64];
+                for (int i = 0; i < 9; i++) out.R[i] = src[i * 64];
+                for (int i = 0; i < 3; i++) out.t[i] = src[(9 + i) * 64];
+            }
         }
+        if (active) a.hyp[(int64_t)b * kPhaseHyps + h] = out;
     }
-    if (active) a.hyp[(int64_t)b * kPhaseHyps + h] = out;
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void pnp_hyp_kernel_wide(PnpArgs a)
 {
@@ -752,13 +778,15 @@ int stage_chain_relative(svo_ctx *ctx, const double *T, const int32_t *ok, int n
 // ------------------------------------------------------------------------------------------
 // workspace layout inside ctx->pnp_ws (n = max_batch items):
 //   [PnpRecord x n][mask bytes x n*cap][PnpState x n][PnpHyp x n*448][counts x n*448][subsets x n*2*448*5]
+//   [EPnP hand-over records x n*7*105*64 doubles]
 static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 static size_t ws_off_mask(int n_items) { return al256(sizeof(PnpRecord) * (size_t)n_items); }
 static size_t ws_off_state(const svo_config &cfg, int n_items) { return al256(ws_off_mask(n_items) + (size_t)n_items * cfg.max_keypoints); }
 static size_t ws_off_hyp(const svo_config &cfg, int n_items) { return al256(ws_off_state(cfg, n_items) + sizeof(PnpState) * (size_t)n_items); }
 static size_t ws_off_counts(const svo_config &cfg, int n_items) { return al256(ws_off_hyp(cfg, n_items) + sizeof(PnpHyp) * (size_t)n_items * kPhaseHyps); }
 static size_t ws_off_subsets(const svo_config &cfg, int n_items) { return al256(ws_off_counts(cfg, n_items) + sizeof(int) * (size_t)n_items * kPhaseHyps); }
-static size_t ws_end(const svo_config &cfg, int n_items) { return al256(ws_off_subsets(cfg, n_items) + sizeof(int) * 2 * 5 * (size_t)n_items * kPhaseHyps); }
+static size_t ws_off_hand(const svo_config &cfg, int n_items) { return al256(ws_off_subsets(cfg, n_items) + sizeof(int) * 2 * 5 * (size_t)n_items * kPhaseHyps); }
+static size_t ws_end(const svo_config &cfg, int n_items) { return al256(ws_off_hand(cfg, n_items) + sizeof(double) * (size_t)n_items * kPhaseBlocks * kEpnpHandDoubles * 64); }
 
 // RANSAC inlier flags of batch item 0 (the online pair): max_keypoints bytes
 const uint8_t *pnp_inlier_mask(const svo_ctx *ctx) { return (const uint8_t *)ctx->pnp_ws + ws_off_mask(ctx->cfg.max_batch); }
@@ -767,7 +795,7 @@ int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
 {
     // called once per context at creation: the EPnP and refit kernels need more dynamic LDS than the default limit
     if (hipFuncSetAttribute((const void *)pnp_hyp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kPnpLdsBytesBeside) != hipSuccess ||
+                            (int)kPnpLdsBytes) != hipSuccess ||
         hipFuncSetAttribute((const void *)pnp_hyp_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPnpLdsBytes) != hipSuccess)
         return SVO_ERR_HIP;
@@ -790,6 +818,7 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
     a.hyp = (PnpHyp *)(ws + ws_off_hyp(cfg, B));
     a.counts = (int *)(ws + ws_off_counts(cfg, B));
     a.subsets = (int *)(ws + ws_off_subsets(cfg, B));
+    a.hand = (double *)(ws + ws_off_hand(cfg, B));
     if (!begun) hipLaunchKernelGGL(pnp_begin_kernel, dim3(n_items), dim3(64), 0, st, a);
     const int niters = a.iterations > 1 ? a.iterations : 1;
     // 1024 points per scoring workgroup; a launch that leaves the chip mostly empty (the online path) takes
@@ -804,15 +833,9 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
         a.phase_base = base; a.phase_cap = cap; a.phase_index = phase;
         if ((blocks + 1) * n_items <= 256)     // the chip is not full: latency matters, registers are free
             hipLaunchKernelGGL(pnp_hyp_kernel_wide, dim3(blocks + 1, n_items), dim3(256), kPnpLdsBytes, st, a);   // + the drawer
-        else
-        {
-            // On the side stream (overlap mode) the blocks run beside the next batch's front end: two of them
-            // per CU would hold 156 of its 160 KB of LDS and lock out every front-end kernel that stages
-            // through LDS (ORB mode: the resize chain stalled for the whole hypothesis kernel, 1.7 ms per 256
-            // pairs).  Asking for a little over half of the LDS keeps it to ONE block per CU there.
-            const size_t lds = st != ctx->stream ? kPnpLdsBytesBeside : kPnpLdsBytes;
-            hipLaunchKernelGGL(pnp_hyp_kernel, dim3(blocks + 1, n_items), dim3(256), lds, st, a);
-        }
+        else        // one block per CU (94 KB of LDS): beside the next batch's front end that is what leaves the
+                    // LDS-staged front-end kernels room on the CU (two 78 KB blocks locked them out: ORB mode, 1.7 ms per step)
+            hipLaunchKernelGGL(pnp_hyp_kernel, dim3(blocks + 1, n_items), dim3(256), kPnpLdsBytes, st, a);
         hipLaunchKernelGGL(pnp_score_kernel, dim3(blocks, n_items, zchunks), dim3(256), 0, st, a);
         hipLaunchKernelGGL(pnp_select_kernel, dim3(n_items), dim3(64), 0, st, a);
         base += cap;

@@ -1,5 +1,5 @@
 import sys, importlib, time, numpy as np, torch
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as e
 pkg=e.load_package(); synth=importlib.import_module(e.PKG_NAME+'.synth')
 dev=torch.device('cuda',0)
