@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 4
+#define SVO_ABI_VERSION 5
 
 /* status codes */
 #define SVO_OK                 0
@@ -103,6 +103,8 @@ typedef struct {                    /* one Tracking::AddFrame step (LK mode) */
 /* ---- lifecycle ------------------------------------------------------------------------- */
 int         svo_abi_version(void);
 void        svo_default_config(svo_config *cfg, int width, int height);   /* default.yaml + KITTI rig */
+int         svo_device_count(int *n);   /* HIP devices visible to this process (ABI v5): the multi-sequence runner deals
+                                           sequences to them; SVO_ERR_HIP with *n = 0 when the runtime finds none */
 int         svo_create(const svo_config *cfg, int device, svo_ctx **out);
 void        svo_destroy(svo_ctx *ctx);
 const char *svo_last_error(const svo_ctx *ctx);

@@ -102,6 +102,13 @@ def load_library():
     return lib
 
 
+def device_count():
+    """svo_device_count: HIP devices visible to this process (0 when there is none)."""
+    n = C.c_int(0)
+    load_library().svo_device_count(C.byref(n))
+    return n.value
+
+
 def default_config(width, height, **overrides):
     cfg = Config()
     load_library().svo_default_config(C.byref(cfg), int(width), int(height))

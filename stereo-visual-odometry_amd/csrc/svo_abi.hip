@@ -53,6 +53,16 @@ static void make_geom(int w, int h, PyrGeom *g)
 extern "C" int svo_wait_results(svo_ctx *ctx);
 extern "C" int svo_abi_version(void) { return SVO_ABI_VERSION; }
 
+extern "C" int svo_device_count(int *n)
+{
+    if (!n) return SVO_ERR_ARG;
+    *n = 0;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) return SVO_ERR_HIP;
+    *n = c;
+    return SVO_OK;
+}
+
 extern "C" void svo_default_config(svo_config *cfg, int width, int height)
 {
     memset(cfg, 0, sizeof(*cfg));
@@ -744,12 +754,24 @@ extern "C" int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, con
     SVO_ARG(ctx->async_tail - ctx->async_head < 2, "two batches are already outstanding: collect one first");
     SVO_HIP(hipSetDevice(ctx->device));
     const int r = (int)(ctx->async_tail & 1), n_pairs = n_frames - 1;
-    if (!ctx->d_async[0]) {
-        for (int k = 0; k < 2; k++) {
-            SVO_HIP(hipMalloc(&ctx->d_async[k], sizeof(svo_step_result) * (size_t)ctx->cfg.max_batch));
-            SVO_HIP(hipEventCreateWithFlags(&ctx->ev_async[k], hipEventDisableTiming));
+    if (!ctx->async_ready) {
+        // all or nothing: a context whose second allocation (or an event, or the stream) failed must not
+        // look set up to the next call
+        auto release = [&]() {
+            for (int k = 0; k < 2; k++) {
+                if (ctx->d_async[k]) { (void)hipFree(ctx->d_async[k]); ctx->d_async[k] = nullptr; }
+                if (ctx->ev_async[k]) { (void)hipEventDestroy(ctx->ev_async[k]); ctx->ev_async[k] = nullptr; }
+            }
+            if (ctx->fetch_stream) { (void)hipStreamDestroy(ctx->fetch_stream); ctx->fetch_stream = nullptr; }
+        };
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < 2 && e == hipSuccess; k++) {
+            e = hipMalloc(&ctx->d_async[k], sizeof(svo_step_result) * (size_t)ctx->cfg.max_batch);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_async[k], hipEventDisableTiming);
         }
-        SVO_HIP(hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking));
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { release(); SVO_HIP(e); }
+        ctx->async_ready = true;
     }
     if (continue_chain) {
         SVO_ARG(ctx->async_tail > 0, "continue_chain needs a previous async batch");

@@ -76,6 +76,7 @@ struct svo_ctx {
     int async_last_pairs = 0;         // pairs of the most recently launched async batch
     const double *seed_dev = nullptr; // device-side seed pose of the next chain launch (continue_chain)
     hipStream_t fetch_stream = nullptr;
+    bool async_ready = false;                 // d_async / ev_async / fetch_stream all exist (set after the last of them succeeded)
     hipEvent_t ev_front = nullptr, ev_back = nullptr;
     bool back_pending = false;
     int *kp_n_snap = nullptr;         // n_prev / n_cur (/ ORB capacity flags) of the batch the pose stage works on: 3 x max_batch

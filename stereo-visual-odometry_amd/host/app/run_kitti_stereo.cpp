@@ -1,12 +1,49 @@
 // run_kitti_stereo <config.yaml> -- drop-in entry point (reference app/run_kitti_stereo.cpp).
 // Unlike the reference it returns non-zero on a wrong argument count instead of dereferencing
 // argv[1].  Optional second argument: pose file (KITTI format).
+//
+// Additive: run_kitti_stereo a.yaml b.yaml ... [--poses-dir DIR] [--devices N]
+//   several sequences (one YAML each) dealt longest-first to the node's HIP devices, one worker thread, System and
+//   context per device (lzb_vio::RunSequences; SURVEY.md 8e: "degrades to hipGetDeviceCount() devices").  A sequence's
+//   poses go to its YAML's pose_file key, else to DIR/<yaml basename>.poses.txt when --poses-dir is given.
 #include "lzb_vio/System.h"
+
+static bool is_yaml(const std::string &s)
+{
+    auto ends = [&](const char *e) { const size_t n = strlen(e); return s.size() >= n && s.compare(s.size() - n, n, e) == 0; };
+    return ends(".yaml") || ends(".yml");
+}
 
 int main(int argc, char **argv)
 {
-    if (argc < 2 || argc > 3) {
-        fprintf(stderr, "usage: %s config.yaml [poses.txt]\n", argv[0]);
+    std::vector<std::string> yamls, rest;
+    std::string poses_dir;
+    int devices = 0;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "--poses-dir" && i + 1 < argc) poses_dir = argv[++i];
+        else if (a == "--devices" && i + 1 < argc) devices = atoi(argv[++i]);
+        else if (is_yaml(a)) yamls.push_back(a);
+        else rest.push_back(a);
+    }
+    if (yamls.size() >= 2 && rest.empty()) {
+        std::vector<std::string> pose_files;
+        for (const auto &y : yamls) {
+            std::string f;
+            if (!poses_dir.empty()) {
+                const size_t slash = y.find_last_of('/');
+                f = poses_dir + "/" + (slash == std::string::npos ? y : y.substr(slash + 1)) + ".poses.txt";
+            }
+            pose_files.push_back(f);
+        }
+        std::vector<lzb_vio::SequenceReport> rep;
+        const int failed = lzb_vio::RunSequences(yamls, pose_files, devices, &rep);
+        for (const auto &r : rep)
+            fprintf(stderr, "%s: device %d, %d frames, %.3f s%s\n", r.yaml.c_str(), r.device, r.frames, r.seconds, r.ok ? "" : "  [FAILED]");
+        return failed ? 1 : 0;
+    }
+    if (argc < 2 || argc > 3 || yamls.size() > 1 || !poses_dir.empty() || devices) {
+        fprintf(stderr, "usage: %s config.yaml [poses.txt]\n       %s a.yaml b.yaml ... [--poses-dir DIR] [--devices N]\n", argv[0], argv[0]);
         return 2;
     }
     std::string config_file_path = argv[1];

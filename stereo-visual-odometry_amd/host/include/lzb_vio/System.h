@@ -31,6 +31,11 @@ public:
     bool SetTracksFile(const std::string &path);
     Tracking::Ptr GetTracking() { return tracking_; }
     int FramesProcessed() const { return current_image_index_; }
+    // additive: the HIP device this System's context lives on (before the first frame; default 0), and the
+    // sequence it will read: the dataset directory and the number of consecutive stereo frames found there
+    void SetDevice(int device) { tracking_->SetDevice(device); }
+    const std::string &DatasetPath() const { return dataset_path_; }
+    int CountFrames() const;
 
 private:
     TrackingStatus GetFrontendStatus() const { return tracking_->GetStatus(); }
@@ -50,11 +55,25 @@ private:
     bool inited_ = false;
     std::string dataset_path_;
     FILE *pose_file_ = nullptr, *tracks_file_ = nullptr;
+    // additive YAML keys batch_size / decode_threads, read once in the constructor (Config is process-wide:
+    // another System may have loaded ITS file by the time Run() is called)
+    int batch_size_ = 1, decode_threads_ = 0;
 };
 
 // 8-bit grayscale image readers used by NextFrame_kitti: binary PGM (P5) and PNG (8-bit gray or
 // RGB/RGBA converted with the BT.601 weights cv::imread(IMREAD_GRAYSCALE) uses; zlib inflate).
 bool ReadImageGray(const std::string &path, cv::Mat &out);
+// the same straight into caller-owned rows (`pitch` bytes apart) of a w x h image; a file of another size is refused
+bool ReadImageGrayInto(const std::string &path, uint8_t *dst, int pitch, int w, int h);
+
+// additive: several sequences -- one YAML each, as `run_kitti_stereo a.yaml b.yaml ...` -- dealt
+// longest-first to the HIP devices of the node (svo_device_count; n_devices > 0 uses that many), one worker thread +
+// System + context per device running its sequences back to back; on a single device two workers share the card, so
+// one sequence's image decode overlaps the other's kernels.  pose_files[i] (may be empty) receives sequence i's poses,
+// byte for byte what a single-sequence run writes.  Returns 0, or the number of sequences that could not be run.
+struct SequenceReport { std::string yaml; int device = 0, worker = 0, frames = 0; double seconds = 0; bool ok = false; };
+int RunSequences(const std::vector<std::string> &yamls, const std::vector<std::string> &pose_files, int n_devices,
+                 std::vector<SequenceReport> *report);
 
 }  // namespace lzb_vio
 #endif

@@ -34,6 +34,8 @@ public:
     // additive (the reference has no getter for frame_pose_)
     Pose4x4 GetPose() const { return frame_pose_; }
     const svo_step_result &LastResult() const { return last_; }
+    void SetDevice(int device) { device_ = device; }         // HIP device of the context (before the first frame); default 0
+    int Device() const { return device_; }
     void SetFillFeatures(bool on) { fill_features_ = on; }   // populate Frame::features_* / *_Descriptors_ (costs a D2H)
     // the matched tracks of the pair just tracked + RANSAC inlier flags (what displayTracking drew)
     bool GetLastTracks(std::vector<cv::Point2f> &t1_left, std::vector<cv::Point2f> &t1_right,
@@ -73,6 +75,8 @@ private:
     double Px_ = 0, Py_ = 0, Pz_ = 0;
 
     svo_ctx *ctx_ = nullptr;
+    int device_ = 0;
+    long max_keypoints_key_ = 0;                             // additive YAML key max_keypoints, read once (0 = absent)
     int ctx_w_ = 0, ctx_h_ = 0, ctx_batch_ = 0;
     int async_pairs_[2] = {0, 0};
     unsigned async_head_ = 0, async_tail_ = 0;

@@ -111,10 +111,21 @@ void ORBextractor::operator()(cv::InputArray image, cv::InputArray /*mask*/, std
     if (!keep_pyramid_) return;
     for (int l = 0; l < nlevels; l++) {
         int w = 0, h = 0;
-        if (svo_orb_read_level(ctx_, l, nullptr, &w, &h) != SVO_OK) return;
+        std::vector<uint8_t> tight;
+        bool ok = svo_orb_read_level(ctx_, l, nullptr, &w, &h) == SVO_OK;
+        if (ok) {
+            tight.resize((size_t)w * h);
+            ok = svo_orb_read_level(ctx_, l, tight.data(), &w, &h) == SVO_OK;
+        }
+        if (!ok) {
+            // never leave the PREVIOUS image's levels behind a failed read-back: the public pyramid is either
+            // this image's or empty, and Ok() reports the failure
+            err_ = svo_last_error(ctx_);
+            LZB_LOG("ERROR", "ORBextractor: svo_orb_read_level(%d): %s", l, err_.c_str());
+            for (int q = l; q < nlevels; q++) mvImagePyramid[(size_t)q] = cv::Mat();
+            return;
+        }
         cv::Mat lvl(h, w);
-        std::vector<uint8_t> tight((size_t)w * h);
-        if (svo_orb_read_level(ctx_, l, tight.data(), &w, &h) != SVO_OK) return;
         for (int y = 0; y < h; y++) memcpy(lvl.ptr(y), tight.data() + (size_t)y * w, (size_t)w);
         mvImagePyramid[(size_t)l] = lvl;
     }

@@ -4,6 +4,9 @@
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
+#include <algorithm>
+#include <sched.h>
+#include <sys/stat.h>
 #include <thread>
 #include <zlib.h>
 
@@ -51,64 +54,117 @@ static bool read_pgm(const std::vector<uint8_t> &b, cv::Mat &out)
 
 static uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
 
-// 8-bit, non-interlaced PNG: gray (type 0), gray+alpha (4), RGB (2), RGBA (6)
-static bool read_png(const std::vector<uint8_t> &b, cv::Mat &out)
+// PNG row filters (RFC 2083 section 6) undone in place: row = filtered bytes in, reconstructed bytes out;
+// prev = the reconstructed row above (all zero for the first row); bpp = bytes per pixel.  One loop per
+// filter type (the per-byte switch of the first version cost more than the inflate it followed).
+static bool png_unfilter_row(int ft, uint8_t *row, const uint8_t *prev, size_t n, size_t bpp)
+{
+    switch (ft) {
+    case 0: return true;
+    case 1: for (size_t i = bpp; i < n; i++) row[i] = (uint8_t)(row[i] + row[i - bpp]); return true;
+    case 2: for (size_t i = 0; i < n; i++) row[i] = (uint8_t)(row[i] + prev[i]); return true;
+    case 3:
+        for (size_t i = 0; i < bpp && i < n; i++) row[i] = (uint8_t)(row[i] + (prev[i] >> 1));
+        for (size_t i = bpp; i < n; i++) row[i] = (uint8_t)(row[i] + ((row[i - bpp] + prev[i]) >> 1));
+        return true;
+    case 4:
+        for (size_t i = 0; i < bpp && i < n; i++) row[i] = (uint8_t)(row[i] + prev[i]);     // a = c = 0: the predictor is b
+        for (size_t i = bpp; i < n; i++) {
+            const int a = row[i - bpp], bb = prev[i], c = prev[i - bpp];
+            const int pp = a + bb - c, pa = abs(pp - a), pb = abs(pp - bb), pc = abs(pp - c);
+            row[i] = (uint8_t)(row[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c)));
+        }
+        return true;
+    default: return false;
+    }
+}
+
+// 8-bit, non-interlaced PNG: gray (type 0), gray+alpha (4), RGB (2), RGBA (6).  The IDAT chunks are
+// inflated as ONE zlib stream fed chunk by chunk (no concatenated copy), a band of rows at a time (the
+// filtered bytes stay in cache for the unfilter pass), and a gray image is reconstructed straight into
+// its destination rows -- `dst(w, h, &pitch)` is asked for them once the header is known, so the batched
+// runner's decoder threads write into page-locked memory with no cv::Mat in between.
+template <typename GetDst>
+static bool png_decode(const std::vector<uint8_t> &b, GetDst dst_for)
 {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (b.size() < 33 || memcmp(b.data(), sig, 8) != 0) return false;
-    size_t p = 8;
     int w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
-    std::vector<uint8_t> idat;
-    while (p + 12 <= b.size()) {
-        uint32_t len = be32(&b[p]);
+    std::vector<std::pair<size_t, size_t>> idat;            // (offset, length) of every IDAT payload, in file order
+    size_t idat_bytes = 0;
+    for (size_t p = 8; p + 12 <= b.size();) {
+        const uint32_t len = be32(&b[p]);
         const uint8_t *type = &b[p + 4];
-        if (p + 12 + len > b.size()) return false;
+        if (p + 12 + (size_t)len > b.size()) return false;
         if (!memcmp(type, "IHDR", 4)) {
+            if (len < 13) return false;
             w = (int)be32(&b[p + 8]); h = (int)be32(&b[p + 12]);
             depth = b[p + 16]; ctype = b[p + 17]; interlace = b[p + 20];
         } else if (!memcmp(type, "IDAT", 4)) {
-            idat.insert(idat.end(), &b[p + 8], &b[p + 8 + len]);
+            if (len) { idat.emplace_back(p + 8, (size_t)len); idat_bytes += len; }
         } else if (!memcmp(type, "IEND", 4)) break;
-        p += 12 + len;
+        p += 12 + (size_t)len;
     }
-    if (w <= 0 || h <= 0 || w > kMaxImageDim || h > kMaxImageDim || depth != 8 || interlace != 0) return false;
-    int ch = ctype == 0 ? 1 : ctype == 4 ? 2 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
+    if (w <= 0 || h <= 0 || w > kMaxImageDim || h > kMaxImageDim || depth != 8 || interlace != 0 || idat.empty()) return false;
+    const int ch = ctype == 0 ? 1 : ctype == 4 ? 2 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
     if (!ch) return false;
     const size_t stride = (size_t)w * ch;
     // deflate expands by at most ~1032x: a header promising more pixels than the IDAT bytes can hold is corrupt
-    if ((stride + 1) * (size_t)h > idat.size() * 1032 + 64) return false;
-    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
-    uLongf rawlen = (uLongf)raw.size();
-    if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return false;
-    std::vector<uint8_t> prev(stride, 0), cur(stride);
-    out.create(h, w);
-    for (int y = 0; y < h; y++) {
-        const uint8_t *src = &raw[(stride + 1) * (size_t)y];
-        const int ft = src[0];
-        for (size_t i = 0; i < stride; i++) {
-            int a = i >= (size_t)ch ? cur[i - ch] : 0, bb = prev[i], c = i >= (size_t)ch ? prev[i - ch] : 0, x = src[1 + i];
-            int pr;
-            switch (ft) {
-            case 0: pr = 0; break;
-            case 1: pr = a; break;
-            case 2: pr = bb; break;
-            case 3: pr = (a + bb) >> 1; break;
-            case 4: { int pp = a + bb - c, pa = abs(pp - a), pb = abs(pp - bb), pc = abs(pp - c);
-                      pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c); break; }
-            default: return false;
+    // (refused before anything is allocated from it)
+    if ((stride + 1) * (size_t)h > idat_bytes * 1032 + 64) return false;
+    int pitch = 0;
+    uint8_t *out = dst_for(w, h, &pitch);
+    if (!out || pitch < w) return false;
+
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit(&zs) != Z_OK) return false;
+    size_t chunk = 0;
+    zs.next_in = const_cast<Bytef *>(&b[idat[0].first]); zs.avail_in = (uInt)idat[0].second;
+    const int band = 32;                                    // rows inflated per call
+    std::vector<uint8_t> raw((stride + 1) * (size_t)band), keep(ch > 1 ? stride : 0), zero(stride, 0);
+    const uint8_t *prev = zero.data();
+    bool ok = true;
+    for (int y0 = 0; ok && y0 < h; y0 += band) {
+        const int rows = h - y0 < band ? h - y0 : band;
+        zs.next_out = raw.data(); zs.avail_out = (uInt)((stride + 1) * (size_t)rows);
+        while (ok && zs.avail_out > 0) {
+            if (zs.avail_in == 0) {
+                if (++chunk >= idat.size()) { ok = false; break; }
+                zs.next_in = const_cast<Bytef *>(&b[idat[chunk].first]); zs.avail_in = (uInt)idat[chunk].second;
             }
-            cur[i] = (uint8_t)(x + pr);
+            const int rc = inflate(&zs, Z_NO_FLUSH);
+            if (rc == Z_STREAM_END) { ok = zs.avail_out == 0; break; }
+            if (rc != Z_OK && !(rc == Z_BUF_ERROR && zs.avail_in == 0)) ok = false;
         }
-        uint8_t *d = out.ptr(y);
-        if (ch <= 2) for (int x = 0; x < w; x++) d[x] = cur[(size_t)x * ch];
-        else for (int x = 0; x < w; x++) {
-            // cv::imread(IMREAD_GRAYSCALE) colour conversion: (R*4899 + G*9617 + B*1868 + 8192) >> 14
-            const uint8_t *q = &cur[(size_t)x * ch];
-            d[x] = (uint8_t)((q[0] * 4899 + q[1] * 9617 + q[2] * 1868 + 8192) >> 14);
+        for (int r = 0; ok && r < rows; r++) {
+            uint8_t *src = &raw[(stride + 1) * (size_t)r];
+            uint8_t *d = out + (size_t)(y0 + r) * pitch;
+            if (ch == 1) {                                  // reconstructed in the destination row itself
+                memcpy(d, src + 1, stride);
+                ok = png_unfilter_row(src[0], d, prev, stride, 1);
+                prev = d;
+            } else {
+                ok = png_unfilter_row(src[0], src + 1, prev, stride, (size_t)ch);
+                if (ch == 2) for (int x = 0; x < w; x++) d[x] = src[1 + (size_t)x * 2];
+                else for (int x = 0; x < w; x++) {
+                    // cv::imread(IMREAD_GRAYSCALE) colour conversion: (R*4899 + G*9617 + B*1868 + 8192) >> 14
+                    const uint8_t *q = src + 1 + (size_t)x * ch;
+                    d[x] = (uint8_t)((q[0] * 4899 + q[1] * 9617 + q[2] * 1868 + 8192) >> 14);
+                }
+                // the band buffer is reused: the last reconstructed row of a band is kept for the next one
+                if (r == rows - 1) { memcpy(keep.data(), src + 1, stride); prev = keep.data(); }
+                else prev = src + 1;
+            }
         }
-        prev.swap(cur);
     }
-    return true;
+    inflateEnd(&zs);
+    return ok;
+}
+
+static bool read_png(const std::vector<uint8_t> &b, cv::Mat &out)
+{
+    return png_decode(b, [&](int w, int h, int *pitch) { out.create(h, w); *pitch = (int)out.step; return out.ptr(0); });
 }
 
 bool ReadImageGray(const std::string &path, cv::Mat &out)
@@ -117,6 +173,21 @@ bool ReadImageGray(const std::string &path, cv::Mat &out)
     if (!read_file(path, b) || b.size() < 8) return false;
     if (b[0] == 'P' && b[1] == '5') return read_pgm(b, out);
     return read_png(b, out);
+}
+
+// The same decode straight into caller-owned rows (`pitch` bytes apart) of a w x h image; a file of
+// another size is refused.  Used by the batched runner's decoder threads on page-locked memory.
+bool ReadImageGrayInto(const std::string &path, uint8_t *dst, int pitch, int w, int h)
+{
+    std::vector<uint8_t> b;
+    if (!dst || !read_file(path, b) || b.size() < 8) return false;
+    if (b[0] == 'P' && b[1] == '5') {
+        cv::Mat m;
+        if (!read_pgm(b, m) || m.cols != w || m.rows != h) return false;
+        for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * pitch, m.ptr(y), (size_t)w);
+        return true;
+    }
+    return png_decode(b, [&](int fw, int fh, int *p) -> uint8_t * { *p = pitch; return (fw == w && fh == h) ? dst : nullptr; });
 }
 
 // ---- System ------------------------------------------------------------------------------------
@@ -135,6 +206,39 @@ System::System(std::string &config_path) : config_file_path_(config_path)
     // the reference's per-frame Feature carriers
     if (Config::Has("tracks_file")) SetTracksFile(Config::Get<std::string>("tracks_file"));
     if (Config::Has("fill_features") && Config::Get<int>("fill_features") != 0) tracking_->SetFillFeatures(true);
+    batch_size_ = Config::Has("batch_size") ? Config::Get<int>("batch_size") : 1;
+    decode_threads_ = Config::Has("decode_threads") ? Config::Get<int>("decode_threads") : 0;    // 0: the usable cores
+}
+
+// cores this process may run on (the affinity mask, not the machine's core count), at most 64
+static int usable_cores()
+{
+    cpu_set_t set;
+    int n = 0;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    return n < 1 ? 1 : n > 64 ? 64 : n;
+}
+
+// consecutive stereo frames present under dataset_path_ (both cameras, .png or .pgm), from index 0
+int System::CountFrames() const
+{
+    auto have = [&](int index) {
+        char name[32];
+        struct stat st;
+        for (int cam = 0; cam < 2; cam++) {
+            bool ok = false;
+            for (const char *ext : {"png", "pgm"}) {
+                snprintf(name, sizeof(name), "/image_%d/%06d.%s", cam, index, ext);
+                if (stat((dataset_path_ + name).c_str(), &st) == 0) { ok = true; break; }
+            }
+            if (!ok) return false;
+        }
+        return true;
+    };
+    int n = 0;
+    while (have(n)) n++;
+    return n;
 }
 
 System::~System()
@@ -185,9 +289,8 @@ void System::WritePoseRow(const double *pose16)
 
 void System::Run()
 {
-    const int batch = Config::Has("batch_size") ? Config::Get<int>("batch_size") : 1;
-    if (batch > 1) {
-        RunBatched(batch, Config::Has("decode_threads") ? Config::Get<int>("decode_threads") : 8);
+    if (batch_size_ > 1) {
+        RunBatched(batch_size_, decode_threads_);
         Shutdown();
         return;
     }
@@ -271,27 +374,34 @@ void System::RunBatched(int B, int decode_threads)
                 LZB_LOG("ERROR", "svo_host_alloc: %s", svo_last_error(ctx));
                 return;
             }
-    const int T = decode_threads < 1 ? 1 : decode_threads;
+    // decode_threads < 1: every core this process may use.  A work item is ONE image (left and right of a
+    // frame are inflated side by side), handed out through a counter, decoded straight into the page-locked chunk.
+    const int T = decode_threads < 1 ? usable_cores() : decode_threads;
     // decodes frames first .. first+count-1 into slots slot0.. of buffer k; returns how many
     // consecutive frames (from `first`) were read
     auto decode = [&](int k, int slot0, int first, int count) -> int {
-        std::vector<char> ok((size_t)count, 0);
-        std::vector<std::thread> pool;
-        for (int t = 0; t < T && t < count; t++)
-            pool.emplace_back([&, t]() {
-                cv::Mat l, r;
-                for (int i = t; i < count; i += T) {
-                    if (!ReadStereo(first + i, l, r) || l.cols != w || l.rows != h || r.cols != w || r.rows != h) continue;
-                    for (int y = 0; y < h; y++) {
-                        memcpy(pin[k][0] + (size_t)(slot0 + i) * fbytes + (size_t)y * pitch, l.ptr(y), (size_t)w);
-                        memcpy(pin[k][1] + (size_t)(slot0 + i) * fbytes + (size_t)y * pitch, r.ptr(y), (size_t)w);
-                    }
-                    ok[(size_t)i] = 1;
+        std::vector<char> ok((size_t)count * 2, 0);
+        std::atomic<int> next_item(0);
+        auto work = [&]() {
+            char name[32];
+            for (;;) {
+                const int it = next_item.fetch_add(1);
+                if (it >= 2 * count) break;
+                const int i = it >> 1, cam = it & 1;
+                uint8_t *dst = pin[k][cam] + (size_t)(slot0 + i) * fbytes;
+                for (const char *ext : {"png", "pgm"}) {
+                    snprintf(name, sizeof(name), "/image_%d/%06d.%s", cam, first + i, ext);
+                    if (ReadImageGrayInto(dataset_path_ + name, dst, pitch, w, h)) { ok[(size_t)it] = 1; break; }
                 }
-            });
+            }
+        };
+        std::vector<std::thread> pool;
+        const int nt = T < 2 * count ? T : 2 * count;
+        for (int t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
         for (auto &th : pool) th.join();
         int n = 0;
-        while (n < count && ok[(size_t)n]) n++;
+        while (n < count && ok[(size_t)2 * n] && ok[(size_t)2 * n + 1]) n++;
         return n;
     };
     auto upload = [&](int k, int n) {
@@ -352,5 +462,72 @@ void System::RunBatched(int B, int decode_threads)
 
 void System::Shutdown() {}
 void System::Reset() {}
+
+// ---- several sequences on the node's devices ---------------------------------------------------------
+int RunSequences(const std::vector<std::string> &yamls, const std::vector<std::string> &pose_files, int n_devices,
+                 std::vector<SequenceReport> *report)
+{
+    const int n_seq = (int)yamls.size();
+    if (n_seq == 0) return 0;
+    if (n_devices <= 0 && (svo_device_count(&n_devices) != SVO_OK || n_devices <= 0)) {
+        LZB_LOG("ERROR", "no HIP device: %d sequences not run (there is no CPU path)", n_seq);
+        return n_seq;
+    }
+    // Config is a process-wide singleton, as in the reference (src/config.cpp:26): the Systems are BUILT one after
+    // the other on this thread -- each reads its own YAML completely in its constructor -- and only then run
+    std::vector<std::unique_ptr<System>> sys((size_t)n_seq);
+    std::vector<int> frames((size_t)n_seq, 0);
+    for (int i = 0; i < n_seq; i++) {
+        std::string path = yamls[(size_t)i];
+        sys[(size_t)i].reset(new System(path));
+        if (i < (int)pose_files.size() && !pose_files[(size_t)i].empty() && !sys[(size_t)i]->SetPoseFile(pose_files[(size_t)i]))
+            LZB_LOG("ERROR", "cannot open %s for writing", pose_files[(size_t)i].c_str());
+        frames[(size_t)i] = sys[(size_t)i]->CountFrames();
+    }
+    // one worker per device; a lone device gets two (one sequence decodes while the other's kernels run)
+    const int n_workers = n_devices == 1 ? (n_seq > 1 ? 2 : 1) : (n_devices < n_seq ? n_devices : n_seq);
+    // longest-processing-time-first deal (ties: lower sequence index, lower worker)
+    std::vector<int> order((size_t)n_seq);
+    for (int i = 0; i < n_seq; i++) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return frames[(size_t)a] > frames[(size_t)b]; });
+    std::vector<std::vector<int>> mine((size_t)n_workers);
+    std::vector<long> load((size_t)n_workers, 0);
+    for (int s : order) {
+        int best = 0;
+        for (int wk = 1; wk < n_workers; wk++) if (load[(size_t)wk] < load[(size_t)best]) best = wk;
+        mine[(size_t)best].push_back(s);
+        load[(size_t)best] += frames[(size_t)s] > 1 ? frames[(size_t)s] - 1 : 0;
+    }
+    std::vector<SequenceReport> rep((size_t)n_seq);
+    std::vector<double> busy((size_t)n_workers, 0.0);
+    std::vector<std::thread> pool;
+    for (int wk = 0; wk < n_workers; wk++)
+        pool.emplace_back([&, wk]() {
+            const int dev = wk % n_devices;
+            for (int s : mine[(size_t)wk]) {
+                SequenceReport &r = rep[(size_t)s];
+                r.yaml = yamls[(size_t)s]; r.device = dev; r.worker = wk;
+                const auto t0 = std::chrono::steady_clock::now();
+                sys[(size_t)s]->SetDevice(dev);
+                sys[(size_t)s]->Run();
+                r.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                r.frames = sys[(size_t)s]->FramesProcessed();
+                r.ok = r.frames > 0 && r.frames == frames[(size_t)s];
+                busy[(size_t)wk] += r.seconds;
+                sys[(size_t)s].reset();                          // closes the pose file, releases the context
+            }
+        });
+    for (auto &th : pool) th.join();
+    int failed = 0;
+    for (int wk = 0; wk < n_workers; wk++) {
+        std::string list;
+        for (int s : mine[(size_t)wk]) list += (list.empty() ? "" : ",") + std::to_string(s);
+        fprintf(stderr, "worker %d (device %d): sequences [%s], %ld pairs, busy %.3f s\n", wk, wk % n_devices, list.c_str(),
+                load[(size_t)wk], busy[(size_t)wk]);
+    }
+    for (const auto &r : rep) failed += r.ok ? 0 : 1;
+    if (report) *report = rep;
+    return failed;
+}
 
 }  // namespace lzb_vio

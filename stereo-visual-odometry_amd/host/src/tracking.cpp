@@ -13,6 +13,10 @@ Tracking::Tracking(System *system, Parameter::Ptr parameter, Sensors::Ptr sensor
     parameter_ = parameter;
     memset(&last_, 0, sizeof(last_));
     Readparameter();
+    // Config is a process-wide singleton (as in the reference, src/config.cpp:26): everything this object
+    // needs from it is read NOW, so several System objects -- one per sequence -- can be built one after
+    // the other and then run side by side
+    max_keypoints_key_ = Config::Has("max_keypoints") ? Config::Get<int>("max_keypoints") : 0;
 }
 
 Tracking::~Tracking()
@@ -75,7 +79,7 @@ bool Tracking::EnsureContext(int width, int height, int max_batch)
     // than what the ORB extractor is asked for.  A frame that still exceeds it fails its pairs with
     // SVO_FAIL_CAPACITY, which is logged as an error below.
     {
-        long cap = Config::Has("max_keypoints") ? Config::Get<int>("max_keypoints") : (long)width * height / 24;
+        long cap = max_keypoints_key_ > 0 ? max_keypoints_key_ : (long)width * height / 24;
         if (cap < 8192) cap = 8192;
         if (cap < 2L * nFeatures_) cap = 2L * nFeatures_;
         if (track_mode_ == "ORB_stereof2f_pnp" && cap > 16384) cap = 16384;     // 16-bit indices in the ORB kernels
@@ -104,7 +108,7 @@ bool Tracking::EnsureContext(int width, int height, int max_batch)
     }
     memcpy(cfg.P1, sensors_->projMatr1_, sizeof(cfg.P1));
     memcpy(cfg.P2, sensors_->projMatr2_, sizeof(cfg.P2));
-    int rc = svo_create(&cfg, 0, &ctx_);
+    int rc = svo_create(&cfg, device_, &ctx_);
     if (rc != SVO_OK) {
         LZB_LOG("ERROR", "svo_create failed (%d): a HIP device is required, there is no CPU path", rc);
         ctx_ = nullptr;
@@ -268,12 +272,12 @@ bool Tracking::CollectUploaded(std::vector<svo_step_result> &out)
     const size_t first = out.size();
     out.resize(first + (size_t)n);
     int rc = svo_collect_results(ctx_, out.data() + first, n);
-    async_head_++;
-    if (rc < 0) {
+    if (rc < 0) {                                            // the context's ring did not advance either: stay in step with it
         LZB_LOG("ERROR", "svo_collect_results: %s", svo_last_error(ctx_));
         out.resize(first);
         return false;
     }
+    async_head_++;
     for (size_t i = first; i < out.size(); i++)
         if (out[i].fail_stage == SVO_FAIL_CAPACITY)
             LZB_LOG("ERROR", "pair %zu of the batch: a frame has more keypoints than the context's capacity "

@@ -341,3 +341,49 @@ def test_image_readers_survive_corrupted_files(host_built, tmp_path):
     err = r.stderr.decode()
     assert r.returncode == 0 and "AddressSanitizer" not in err and "runtime error" not in err, err[-3000:]
     assert f"image1 ok=1 rows=40 cols=57 hash={_hash(img)}" in r.stdout.decode()
+
+
+@pytest.mark.gpu
+def test_run_kitti_stereo_multi_sequence(host_built, synth, tmp_path):
+    """`run_kitti_stereo a.yaml b.yaml c.yaml` (lzb_vio::RunSequences, SURVEY.md 8e): three short sequences of
+    different lengths, modes and runners dealt to the node's devices (one GPU here: two worker threads, two
+    contexts on the card) -- every pose file equals the single-sequence run's byte for byte."""
+    specs = [("s0", 9, 21, "LK_stereof2f_pnp", "batch_size: 4\n"), ("s1", 6, 22, "ORB_stereof2f_pnp", ""),
+             ("s2", 13, 23, "LK_stereof2f_pnp", "batch_size: 5\ndecode_threads: 2\n")]
+    yamls = []
+    for name, n, seed, mode, extra in specs:
+        seq = synth.StereoSequence(width=416, height=128, n_frames=n, seed=seed)
+        d = tmp_path / name
+        for cam in (0, 1):
+            os.makedirs(d / f"image_{cam}")
+        for t in range(n):
+            L, R = (x.numpy() for x in seq.render(t))
+            _write_pgm(d / "image_0" / f"{t:06d}.pgm", L)
+            _write_pgm(d / "image_1" / f"{t:06d}.pgm", R)
+        y = tmp_path / f"{name}.yaml"
+        _write_yaml(y, str(d), fx=seq.fx, fy=seq.fy, cx=seq.cx, cy=seq.cy, mode=mode)
+        with open(y, "a", encoding="utf-8") as f:
+            f.write(extra)
+        yamls.append(str(y))
+    exe = os.path.join(host_built, "run_kitti_stereo")
+    single = []
+    for y in yamls:
+        r = subprocess.run([exe, y, y + ".single.txt"], capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        single.append(open(y + ".single.txt", "rb").read())
+    os.makedirs(tmp_path / "out")
+    r = subprocess.run([exe] + yamls + ["--poses-dir", str(tmp_path / "out")], capture_output=True, timeout=600)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err[-2000:]
+    assert "worker 0 (device 0)" in err and "worker 1 (device 0)" in err        # one device: two workers share it
+    # longest first: s2 (12 pairs) alone on worker 0, s0 (8) and s1 (5) on worker 1
+    assert "worker 0 (device 0): sequences [2], 12 pairs" in err and "worker 1 (device 0): sequences [0,1], 13 pairs" in err
+    for (name, n, _, _, _), want in zip(specs, single):
+        got = open(tmp_path / "out" / f"{name}.yaml.poses.txt", "rb").read()
+        assert got == want and len(got.splitlines()) == n
+    # a sequence that cannot be read makes the run fail loudly (and the others still finish)
+    bad = tmp_path / "bad.yaml"
+    _write_yaml(bad, str(tmp_path / "nowhere"))
+    r = subprocess.run([exe, yamls[0], str(bad), "--poses-dir", str(tmp_path / "out")], capture_output=True, timeout=300)
+    assert r.returncode == 1 and "[FAILED]" in r.stderr.decode()
+    assert open(tmp_path / "out" / "s0.yaml.poses.txt", "rb").read() == single[0]
