@@ -57,7 +57,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="stereo pairs per step (per GPU)")
     ap.add_argument("--chunks", type=int, default=4, help="distinct B-pair chunks of the sequence rendered (steps cycle through them)")
-    ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs of the 1-thread cpu_baseline sample (0 = skip cpu_baseline)")
+    ap.add_argument("--cpu-pairs", type=int, default=100, help="pairs of the 1-thread cpu_baseline sample: BASELINE config #1 says "
+                    "\"first 100 pairs\" (0 = skip cpu_baseline)")
+    ap.add_argument("--e2e-frames", type=int, default=513, help="frames of the end-to-end leg (run_kitti_stereo from PGM and PNG "
+                    "files on disk, process start included; 0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the m1 / online legs (value, roofline, cpu_baseline only)")
     ap.add_argument("--no-timing-marks", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the pose stage in stream order")
@@ -127,6 +130,73 @@ def kernel_source_hash():
         with open(os.path.join(entry.PKG_DIR, "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def newest_profile(name, src_hash=None):
+    """profiles/rNN_<name>_pmc.json of the highest round (whose source hash matches, when one is given)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{name}_pmc.json")), reverse=True):
+        prof = json.load(open(path))
+        if src_hash is None or prof.get("source_sha256_16") == src_hash:
+            prof["_file"] = os.path.relpath(path, ROOT)
+            return prof
+    return None
+
+
+def e2e_leg(args, L, R, P1, width):
+    """run_kitti_stereo (the reference's CLI, batched runner) on a KITTI-layout directory of the bench's own S0 frames,
+    once from PGM and once from PNG files (the reference's input format): pairs/s from process start to exit."""
+    import shutil
+    import subprocess
+    import tempfile
+    from PIL import Image
+    host = os.path.join(entry.PKG_DIR, "host")
+    exe = os.path.join(host, "run_kitti_stereo")
+    if not os.path.exists(exe):
+        return {"error": "run_kitti_stereo is not built (run __graft_entry__.build())"}
+    n = min(args.e2e_frames, L.shape[0])
+    fl = L[:n, :, :width].cpu().numpy()
+    fr = R[:n, :, :width].cpu().numpy()
+    root = tempfile.mkdtemp(prefix="svo_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    res = {"frames": n, "runner": f"run_kitti_stereo, batch_size {args.batch}, decode_threads = usable cores", "definition":
+           "wall time of the process (start-up, HIP context, file read + decode, H2D, tracking, pose file) / (frames - 1); files in " +
+           ("/dev/shm" if root.startswith("/dev/shm") else "the temp dir")}
+    try:
+        for fmt in ("pgm", "png"):
+            d = os.path.join(root, fmt)
+            for cam, fs in ((0, fl), (1, fr)):
+                os.makedirs(os.path.join(d, f"image_{cam}"))
+                for t in range(n):
+                    path = os.path.join(d, f"image_{cam}", f"{t:06d}.{fmt}")
+                    if fmt == "pgm":
+                        with open(path, "wb") as f:
+                            f.write(b"P5\n%d %d\n255\n" % (fs[t].shape[1], fs[t].shape[0]))
+                            f.write(fs[t].tobytes())
+                    else:
+                        Image.fromarray(fs[t]).save(path, compress_level=3)
+            mode = "ORB_stereof2f_pnp" if args.mode == "orb" else "LK_stereof2f_pnp"
+            with open(os.path.join(d, "cfg.yaml"), "w") as f:
+                f.write("%YAML:1.0\n" + f"dataset_path: {d}\n" +
+                        "".join(f"camera_{c}.{k}: {v}\n" for c in "lr" for k, v in (("fx", P1[0]), ("fy", P1[5]), ("cx", P1[2]), ("cy", P1[6]))) +
+                        "t_lr0: -0.537\nt_lr1: 0.0\nt_lr2: 0.0\n" + "".join(f"R_lr{i}: {1.0 if i % 4 == 0 else 0.0}\n" for i in range(9)) +
+                        "num_features: 500\nnum_features_init: 20\ninit_landmarks: 5\nfeature_match_error: 3\nnum_features_tracking: 5\n"
+                        "num_features_tracking_bad: 10\nnum_features_needed_for_keyframe: 60\n" + f"track_mode: {mode}\n" +
+                        "inlier_rate: 0.01\niterationsCount: 500\nreprojectionError: 0.5\nconfidence: 0.99\ndisplay_scale: 1\ndisplay_x: 400\n"
+                        "display_y: 200\nminmove: 0.05\nmaxmove: 10\nfMinThFAST: 7\nfIniThFAST: 20\nnLevels: 8\nfScaleFactor: 1.2\nnFeatures: 2000\n" +
+                        f"batch_size: {args.batch}\n")
+            best = None
+            for _ in range(2):                                   # the second run has the files in the page cache for sure
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, os.path.join(d, "cfg.yaml"), os.path.join(d, "poses.txt")], capture_output=True)
+                el = time.perf_counter() - t0
+                if r.returncode != 0:
+                    return {"error": r.stderr.decode()[-400:]}
+                best = el if best is None else min(best, el)
+            rows = sum(1 for _ in open(os.path.join(d, "poses.txt")))
+            res[fmt] = {"pairs_per_s": round((n - 1) / best, 1), "seconds": round(best, 3), "pose_rows": rows}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    return res
 
 
 def usable_cores():
@@ -376,19 +446,22 @@ def main():
             # HBM bytes and VALU instructions per launch from the rocprofv3 PMC passes of this command
             # (profiles/), valid only for the kernel source they were measured on
             traffic, valu = None, None
-            tpath = os.path.join(ROOT, "profiles", "r02_lk_pmc.json")
-            if os.path.exists(tpath) and B == 256:
-                prof = json.load(open(tpath))
-                if prof.get("source_sha256_16") == src_hash:
-                    traffic = prof.get("traffic_bytes")
-                    n_valu = prof.get("valu_wave_instructions")
-                    peak = prof.get("valu_peak_wave_instr_per_cycle_per_simd")
-                    if n_valu and peak:
-                        rate = n_valu / (lk_ms * 1e-3 * N_SIMD * CLOCK_GHZ * 1e9)
-                        valu = {"achieved": round(rate, 4), "peak": peak, "unit": "wave-instructions/cycle/SIMD",
-                                "frac": round(rate / peak, 4), "clock_ghz_assumed": CLOCK_GHZ,
-                                "note": "peak = measured issue rate of v_dot2 / v_perm / v_pk_* / DPP / v_cndmask (4 cycles per "
-                                        "wave-instruction); profiles/r02_valu_roof.txt"}
+            prof = newest_profile("lk", src_hash) if B == 256 else None
+            if prof:
+                traffic = prof.get("traffic_bytes")
+                n_valu = prof.get("valu_wave_instructions")
+                peak = prof.get("valu_peak_wave_instr_per_cycle_per_simd")
+                # shader clock of the profiled launch: GRBM_GUI_ACTIVE counts the cycles of all 8 XCDs over the launch
+                clk = prof.get("clock_ghz_measured") or CLOCK_GHZ
+                if n_valu and peak:
+                    rate = n_valu / (lk_ms * 1e-3 * N_SIMD * clk * 1e9)
+                    valu = {"achieved": round(rate, 4), "peak": peak, "unit": "wave-instructions/cycle/SIMD",
+                            "frac": round(rate / peak, 4), "clock_ghz": clk,
+                            "clock_source": ("GRBM_GUI_ACTIVE / 8 XCDs / launch time of the profiled run" if prof.get("clock_ghz_measured")
+                                             else "MI355X_MICROARCH.md peak clock (no GRBM pass in the profile)"),
+                            "profile": prof["_file"],
+                            "note": "peak = measured issue rate of v_dot2 / v_perm / v_pk_* / DPP / v_cndmask (4 cycles per "
+                                    "wave-instruction); profiles/r02_valu_roof.txt"}
             out["roofline"] = {"bound": "hbm", "kernel": "lk_kernel (4-call circular chain, one launch per step)",
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -402,9 +475,11 @@ def main():
             cf_ms = stage_ms["orb_cellfast"]
             alg_bytes = int(3.09 * W * H * 2 * (B + 1))
             achieved = alg_bytes / (cf_ms * 1e-3) / 1e9
+            oprof = newest_profile("orb") if B == 256 else None
             out["roofline"] = {"bound": "hbm", "kernel": "orb_cellfast_kernel (one launch per step over all pyramid levels)",
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                               "frac": round(achieved / HBM_PEAK_GBS, 5),
+                               "traffic": (oprof or {}).get("cellfast_traffic_bytes"), "profile": (oprof or {}).get("_file"),
                                "launch_ms": round(cf_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
         else:
             out["roofline"] = None
@@ -510,8 +585,52 @@ def main():
                                                  "points_parallel_only": {"value": round(vn, 3),
                                                                           "sample": f"first {nn} pairs in sequence, OpenMP over the LK points, {cores} threads"}}}
             out["vs_cpu_baseline_1_thread"] = round(out["value"] / v1, 1)
+            out["vs_cpu_baseline_all_cores"] = round(out["value"] / vp, 1)
+        elif args.cpu_pairs > 0 and world == 1 and args.mode == "orb":
+            # config #3 on the CPU: ORBextractor on the left and right image of every frame, then the matcher + pose step
+            O = entry.load_oracle()
+            O.build()
+            prm = O.make_params(P1, P2, min_t2=0.05 ** 2, max_t2=10.0 ** 2)
+            cores = usable_cores()
+            from concurrent.futures import ThreadPoolExecutor
+
+            def orb_run(n, workers):
+                fl = L[:n + 1, :, :W].cpu().numpy()
+                fr = R[:n + 1, :, :W].cpu().numpy()
+                c0 = time.perf_counter()
+                if workers == 1:                                 # the reference's order: frame by frame
+                    prev, pose = None, np.eye(4)
+                    for t in range(n + 1):
+                        cur = (O.orb_extract(fl[t])[:2], O.orb_extract(fr[t])[:2])
+                        if prev is not None:
+                            _, pose = O.orb_track_step(prm, *prev[0], *prev[1], *cur[0], pose)
+                        prev = cur
+                else:                                            # every image, then every pair, over the workers
+                    with ThreadPoolExecutor(max_workers=workers) as ex:
+                        feats = list(ex.map(lambda im: O.orb_extract(im)[:2], [im for t in range(n + 1) for im in (fl[t], fr[t])]))
+                        list(ex.map(lambda t: O.orb_track_step(prm, *feats[2 * t - 2], *feats[2 * t - 1], *feats[2 * t], np.eye(4)),
+                                    range(1, n + 1)))
+                return n / (time.perf_counter() - c0)
+
+            n1 = min(args.cpu_pairs, B)
+            v1 = orb_run(n1, 1)
+            np_pairs = min(max(4 * args.cpu_pairs, 2 * cores), B)
+            vp = orb_run(np_pairs, cores)
+            out["cpu_baseline"] = {"value": round(v1, 3), "unit": "stereo pairs/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {n1} pairs of the same S0 frames, oracle/ (CPU restatement of ORBextractor + the "
+                                             f"reference's matcher and pose step, not the reference binary), 1 thread, frame by frame",
+                                   "all_cores": {"value": round(vp, 3), "cores": cores,
+                                                 "sample": f"first {np_pairs} pairs: all {2 * (np_pairs + 1)} extractions, then all pair steps, "
+                                                           f"one 1-thread oracle call per worker thread, {cores} workers "
+                                                           f"({os.cpu_count()} host cpus visible)"}}
+            out["vs_cpu_baseline_1_thread"] = round(out["value"] / v1, 1)
+            out["vs_cpu_baseline_all_cores"] = round(out["value"] / vp, 1)
         else:
             out["cpu_baseline"] = None
+
+        # ---- e2e: the drop-in binary from image FILES (decode + H2D + tracking + pose file, process start included)
+        if world == 1 and args.e2e_frames >= 3 and not args.config5 and not args.no_secondary:
+            out["e2e"] = e2e_leg(args, L, R, P1, W)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

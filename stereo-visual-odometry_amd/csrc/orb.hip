@@ -168,14 +168,16 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
                                                            int64_t cand_img_stride, int64_t cnt_img_stride)
 {
     const int l = level_of_block(g.cell_off, g.nlevels, blockIdx.x);      // blockIdx.x = cell index over all levels
-    // dynamic LDS: three byte planes + the position list, kCellMax columns x (hCell + 6) rows of THIS
-    // level (a static 66 x 66 worst case would cost 21.8 KB and starve the kernel of workgroups
-    // while the previous batch's pose solver holds 74 KB per CU)
+    // dynamic LDS: two byte planes (pixels, cornerness) + the position lists (three planes' worth), kCellMax
+    // columns x (hCell + 6) rows of THIS level (a static 66 x 66 worst case would cost 21.8 KB and starve the
+    // kernel of workgroups while the previous batch's pose solver holds most of the CU's LDS)
     extern __shared__ __attribute__((aligned(16))) uint8_t cf_smem[];
     const int plane = (kCellPitch * (g.hCell[l] + 6) + 15) & ~15;
-    uint8_t *raw = cf_smem, *V = cf_smem + plane, *keep = cf_smem + 2 * plane;
-    uint16_t *list = (uint16_t *)(cf_smem + 3 * plane);
-    __shared__ int s_any, s_found, s_nlist, s_ncand, s_run, s_wtot[kCellThreads / 64];
+    uint8_t *raw = cf_smem, *V = cf_smem + plane;
+    uint16_t *list = (uint16_t *)(cf_smem + 2 * plane);      // survivors of the test, then candidates (compacted in place)
+    uint16_t *klist = list + plane;                          // keypoints after the NMS, in any order (at most a quarter of the
+                                                             // cell's pixels: a fifth plane of bytes holds plane / 2 of them)
+    __shared__ int s_any, s_nlist, s_ncand, s_nkept;
     const int b = blockIdx.z, cell = blockIdx.x - g.cell_off[l];
     const int W = g.w[l], H = g.h[l], pitch = g.pitch[l];
     const int minBX = 16, minBY = 16, maxBX = W - 16, maxBY = H - 16;
@@ -195,9 +197,12 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
     // far above the float error, so truncating (i + 0.5) * (1 / n) is exact
     const int lowTh = min(iniTh, minTh);
     const uint8_t *img = slots + (int64_t)b * slot_stride + g.origin[l];
-    if (tid == 0) { s_any = 0; s_found = 0; s_nlist = 0; s_ncand = 0; s_run = 0; }
-    // V and keep start at zero everywhere (the two planes are contiguous)
-    for (int i = tid; i < plane / 2; i += kCellThreads) ((uint32_t *)V)[i] = 0;
+    if (tid == 0) { s_any = 0; s_nlist = 0; s_ncand = 0; s_nkept = 0; }
+    // V must read 0 wherever the NMS looks and no cornerness is computed.  The rows of the tested pixels are
+    // zeroed by the test loop itself (one dword store beside its five reads); the row above and the row
+    // below them here (a whole-plane clear cost five passes of the workgroup)
+    uint32_t *Vd = (uint32_t *)V;                            // aligned dword view, like rawd
+    if (tid < 2 * (kCellPitch / 4)) Vd[(tid < kCellPitch / 4 ? 2 : ch - 3) * (kCellPitch / 4) + tid % (kCellPitch / 4)] = 0;
     // the cell as aligned dwords (rows of the level are 4-byte aligned; the cell's first column
     // sits `ox` bytes into its first dword, so every LDS row is shifted by ox: rawc = raw + ox)
     const int ox = x0 & 3, nd = (ox + cw + 3) >> 2;
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
     }
     const uint32_t *rawd = (const uint32_t *)raw;           // aligned dword view, kCellPitch / 4 dwords per row
     raw += ox;
+    V += ox;                                                 // the same shift: position p of the cell is raw[p] and V[p]
     __syncthreads();
     // Cornerness only matters where it can reach the threshold in force: a corner at threshold t needs one
     // pixel of each opposite pair (0,8), (4,12) beyond t, so positions failing that 4-pixel test at t keep
@@ -239,6 +245,7 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
                     y = yy + 3; xb = 4 * gq - ox;                            // cell x of the dword's first byte
                     const uint32_t *r = rawd + y * RD + gq;
                     const uint32_t C = r[0], U = r[-3 * RD], D = r[3 * RD], Lf = gq > 0 ? r[-1] : 0u, Rt = r[1];
+                    Vd[y * RD + gq] = 0;                                     // (see the clear of the two outer rows above)
                     const uint32_t Lv = __builtin_amdgcn_alignbyte(C, Lf, 1);    // x - 3 neighbours of the four pixels
                     const uint32_t Rv = __builtin_amdgcn_alignbyte(Rt, C, 3);    // x + 3 neighbours
                     uint32_t sgn[2];
@@ -323,68 +330,53 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
             __syncthreads();
             ncand = s_ncand;
         }
-        int found = 0;
-        for (int i = tid; i < ncand; i += kCellThreads) {
-            const int pos = list[i];
-            const uint8_t *p = &V[pos];
-            const int s = p[0];
-            int k = 0;
-            if (s >= thr) {
+        // strict 3x3 NMS over the candidates; the keypoints go to klist through one LDS atomic per wave and pass
+        for (int i0 = 0; i0 < ncand; i0 += kCellThreads) {
+            const int i = i0 + tid;
+            int pos = 0;
+            bool k = false;
+            if (i < ncand) {
+                pos = list[i];
+                const uint8_t *p = &V[pos];
+                const int s = p[0];
+                if (s >= thr) {
 #define SC(o) (p[o] >= thr ? (int)p[o] : 0)
-                k = s > SC(-1) && s > SC(1) && s > SC(-kCellPitch - 1) && s > SC(-kCellPitch) && s > SC(-kCellPitch + 1) &&
-                    s > SC(kCellPitch - 1) && s > SC(kCellPitch) && s > SC(kCellPitch + 1);
+                    k = s > SC(-1) && s > SC(1) && s > SC(-kCellPitch - 1) && s > SC(-kCellPitch) && s > SC(-kCellPitch + 1) &&
+                        s > SC(kCellPitch - 1) && s > SC(kCellPitch) && s > SC(kCellPitch + 1);
 #undef SC
+                }
             }
-            keep[pos] = (uint8_t)k;
-            found |= k;
+            const unsigned long long m = __ballot(k);
+            if (m) {
+                const int lane = tid & 63;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_nkept, __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (k) klist[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+            }
         }
-        if (found) s_found = 1;
         __syncthreads();
         // "if (vKeysCell.empty()) FAST(..., minThFAST)": strict NMS can empty a cell whose corners tie
-        if (s_found || thr == minTh) break;
+        if (s_nkept > 0 || thr == minTh) break;
         thr = minTh;
-        __syncthreads();
     }
-    // ordered (row-major) emission: the keep plane is scanned as dwords (four pixels per thread),
-    // block-wide exclusive scan of the per-thread counts (three ballots per wave + the wave totals
-    // through LDS) gives every keypoint its slot
+    // ordered (row-major) emission: a cell keeps a handful of keypoints (positions y * pitch + x, so their
+    // numeric order IS the row-major order), and a keypoint's slot is the number of keypoints with a smaller
+    // position -- counted by its thread over the list (LDS broadcast reads) instead of scanning a keep plane
+    // of the whole cell (two passes of the workgroup with three ballots and three barriers each)
     {
         float4 *out = cell_cand + (int64_t)b * cand_img_stride + ((int64_t)g.cell_off[l] + cell) * kCellCap;
-        constexpr int RD = kCellPitch / 4;
-        const int nq = (cw + 3) >> 2, ngroups = nq * ch;
-        const float inv_nq = 1.0f / (float)nq;
-        const int lane = tid & 63, wv = tid >> 6;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        for (int i0 = 0; i0 < ngroups; i0 += kCellThreads) {
-            const int i = i0 + tid;
-            uint32_t kd = 0;
-            int y = 0, xq = 0;
-            if (i < ngroups) {
-                y = (int)(((float)i + 0.5f) * inv_nq); xq = 4 * (i - y * nq);
-                kd = ((const uint32_t *)keep)[y * RD + (xq >> 2)];
+        const int nk = s_nkept;
+        for (int i = tid; i < nk; i += kCellThreads) {
+            const int pos = klist[i];
+            int rank = 0;
+            for (int j = 0; j < nk; j++) rank += klist[j] < pos;
+            if (rank < kCellCap) {
+                const int y = (int)(((float)pos + 0.5f) * (1.0f / (float)kCellPitch)), x = pos - y * kCellPitch;
+                out[rank] = make_float4((float)x + (float)(cj * wCell), (float)y + (float)(ci * hCell), (float)V[pos], 0.f);
             }
-            const int c = (kd & 0xFFu ? 1 : 0) + (kd & 0xFF00u ? 1 : 0) + (kd & 0xFF0000u ? 1 : 0) + (kd & 0xFF000000u ? 1 : 0);
-            const unsigned long long b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4);
-            const int pre = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
-            if (lane == 0) s_wtot[wv] = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-            __syncthreads();
-            int idx = s_run + pre, tot = 0;
-            for (int q = 0; q < kCellThreads / 64; q++) { const int t = s_wtot[q]; if (q < wv) idx += t; tot += t; }
-            if (c) {
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if ((kd >> (8 * j)) & 0xFFu) {
-                        if (idx < kCellCap)
-                            out[idx] = make_float4((float)(xq + j) + (float)(cj * wCell), (float)y + (float)(ci * hCell),
-                                                   (float)V[y * kCellPitch + xq + j], 0.f);
-                        idx++;
-                    }
-            }
-            __syncthreads();
-            if (tid == 0) s_run += tot;
-            __syncthreads();
         }
-        if (tid == 0) *cnt = s_run;          // may exceed kCellCap: flagged by orb_gather_kernel
+        if (tid == 0) *cnt = nk;             // may exceed kCellCap: flagged by orb_gather_kernel
     }
 }
 

@@ -54,6 +54,37 @@ static bool read_pgm(const std::vector<uint8_t> &b, cv::Mat &out)
 
 static uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
 
+static inline int paeth_pred(int a, int b, int c)
+{
+    int pa = b - c, pb = a - c, pc = pa + pb;                // p - a, p - b, p - c for p = a + b - c
+    pa = abs(pa); pb = abs(pb); pc = abs(pc);
+    const int t = pb <= pc ? b : c;
+    return (pa <= pb && pa <= pc) ? a : t;
+}
+
+// Two consecutive Paeth rows of a one-byte-per-pixel image at once.  A Paeth pixel waits for its left
+// neighbour, so a row is one dependent chain of ~8 cycles per pixel (it was half of the decode time of a
+// KITTI-size frame: PNG encoders pick Paeth for most rows of camera images); the row below needs only
+// pixels of the upper row that are at least one column behind, so the two chains run skewed by one pixel and
+// the CPU overlaps them.  A: filtered bytes of the upper row (P = the reconstructed row above it), B: of the
+// lower row; both reconstructed in place.
+static void png_unfilter_paeth2(uint8_t *A, uint8_t *B, const uint8_t *P, size_t n)
+{
+    if (n == 0) return;
+    A[0] = (uint8_t)(A[0] + P[0]);
+    B[0] = (uint8_t)(B[0] + A[0]);
+    if (n == 1) return;
+    A[1] = (uint8_t)(A[1] + paeth_pred(A[0], P[1], P[0]));
+    int aA = A[1], aB = B[0];
+    for (size_t i = 1; i + 1 < n; i++) {
+        const int xa = A[i + 1] + paeth_pred(aA, P[i + 1], P[i]);            // A[i + 1]
+        const int xb = B[i] + paeth_pred(aB, aA, A[i - 1]);                  // B[i]: its upper neighbours A[i], A[i - 1] are done
+        aA = xa & 0xFF; aB = xb & 0xFF;
+        A[i + 1] = (uint8_t)aA; B[i] = (uint8_t)aB;
+    }
+    B[n - 1] = (uint8_t)(B[n - 1] + paeth_pred(aB, A[n - 1], A[n - 2]));
+}
+
 // PNG row filters (RFC 2083 section 6) undone in place: row = filtered bytes in, reconstructed bytes out;
 // prev = the reconstructed row above (all zero for the first row); bpp = bytes per pixel.  One loop per
 // filter type (the per-byte switch of the first version cost more than the inflate it followed).
@@ -69,11 +100,7 @@ static bool png_unfilter_row(int ft, uint8_t *row, const uint8_t *prev, size_t n
         return true;
     case 4:
         for (size_t i = 0; i < bpp && i < n; i++) row[i] = (uint8_t)(row[i] + prev[i]);     // a = c = 0: the predictor is b
-        for (size_t i = bpp; i < n; i++) {
-            const int a = row[i - bpp], bb = prev[i], c = prev[i - bpp];
-            const int pp = a + bb - c, pa = abs(pp - a), pb = abs(pp - bb), pc = abs(pp - c);
-            row[i] = (uint8_t)(row[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c)));
-        }
+        for (size_t i = bpp; i < n; i++) row[i] = (uint8_t)(row[i] + paeth_pred(row[i - bpp], prev[i], prev[i - bpp]));
         return true;
     default: return false;
     }
@@ -142,8 +169,16 @@ static bool png_decode(const std::vector<uint8_t> &b, GetDst dst_for)
             uint8_t *d = out + (size_t)(y0 + r) * pitch;
             if (ch == 1) {                                  // reconstructed in the destination row itself
                 memcpy(d, src + 1, stride);
-                ok = png_unfilter_row(src[0], d, prev, stride, 1);
-                prev = d;
+                if (src[0] == 4 && r + 1 < rows && src[stride + 1] == 4) {      // two Paeth rows: one skewed pass
+                    uint8_t *d2 = d + pitch;
+                    memcpy(d2, src + stride + 2, stride);
+                    png_unfilter_paeth2(d, d2, prev, stride);
+                    prev = d2;
+                    r++;
+                } else {
+                    ok = png_unfilter_row(src[0], d, prev, stride, 1);
+                    prev = d;
+                }
             } else {
                 ok = png_unfilter_row(src[0], src + 1, prev, stride, (size_t)ch);
                 if (ch == 2) for (int x = 0; x < w; x++) d[x] = src[1 + (size_t)x * 2];

@@ -45,9 +45,9 @@ def main():
         tha._write_yaml(os.path.join(d, "online.yaml"), d, fx=seq.fx, fy=seq.fy, cx=seq.cx, cy=seq.cy)
         base = open(os.path.join(d, "online.yaml"), encoding="utf-8").read()
         with open(os.path.join(d, "batched.yaml"), "w", encoding="utf-8") as f:
-            f.write(base + "batch_size: 128\ndecode_threads: 16\n")
+            f.write(base + "batch_size: 128\n")       # decode_threads absent: every core the process may use
         poses = {}
-        for name in ("online", "batched"):
+        for name in (("batched",) if os.environ.get("SVO_SKIP_ONLINE") else ("online", "batched")):
             t0 = time.perf_counter()
             r = subprocess.run([os.path.join(host, "run_kitti_stereo"), os.path.join(d, name + ".yaml"),
                                 os.path.join(d, name + ".txt")], capture_output=True)
@@ -56,9 +56,10 @@ def main():
             poses[name] = np.loadtxt(os.path.join(d, name + ".txt"))
             print(json.dumps({"frames": fmt, "runner": name, "n_frames": n, "seconds": round(el, 3),
                               "pairs_per_s_incl_startup": round((n - 1) / el, 1)}), flush=True)
-        assert poses["online"].shape == poses["batched"].shape
-        print(json.dumps({"frames": fmt, "max_pose_difference_online_vs_batched":
-                          float(np.abs(poses["online"] - poses["batched"]).max())}), flush=True)
+        if "online" in poses:
+            assert poses["online"].shape == poses["batched"].shape
+            print(json.dumps({"frames": fmt, "max_pose_difference_online_vs_batched":
+                              float(np.abs(poses["online"] - poses["batched"]).max())}), flush=True)
 
 
 if __name__ == "__main__":

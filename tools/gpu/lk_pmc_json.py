@@ -44,6 +44,11 @@ out = {
     "sq_active_inst_valu_quadcycles": vals.get("SQ_ACTIVE_INST_VALU"),
     "sq_busy_cycles": vals.get("SQ_BUSY_CYCLES"), "sq_waves": vals.get("SQ_WAVES"),
     "tcc_hit": vals.get("TCC_HIT_sum"), "tcc_miss": vals.get("TCC_MISS_sum"),
+    "lds_bank_conflict_cycles": vals.get("SQ_LDS_BANK_CONFLICT"), "lds_idx_active_cycles": vals.get("SQ_LDS_IDX_ACTIVE"),
+    "wait_inst_any_wave_cycles": vals.get("SQ_WAIT_INST_ANY"), "wave_cycles": vals.get("SQ_WAVE_CYCLES"),
+    "grbm_gui_active": vals.get("GRBM_GUI_ACTIVE"),
+    # shader clock during the launch: GRBM_GUI_ACTIVE sums the busy cycles of the 8 XCDs
+    "clock_ghz_measured": (round(vals["GRBM_GUI_ACTIVE"] / 8 / avg_ns, 4) if vals.get("GRBM_GUI_ACTIVE") and avg_ns else None),
     "valu_peak_wave_instr_per_cycle_per_simd": 0.246,
     "valu_peak_source": "profiles/r02_valu_roof.txt: v_dot2_i32_i16, v_perm_b32, v_alignbyte_b32, v_pk_*, DPP, v_cndmask, v_readlane "
                         "all issue one wave-instruction per 4.06-4.2 cycles per SIMD at 2-8 waves per SIMD (plain 32-bit add/and/shift: 2.03-2.3)",
