@@ -493,16 +493,22 @@ def main():
             hostR[c][:] = R[c * B:c * B + B + 1].cpu().numpy()
 
         def m1_run(n_steps):
-            """upload(0) track(0) | upload(k+1) track(k+1) collect(k) ...: two batches outstanding, so chunk k+1's
+            """upload(0) track(0) upload(1) | track(k) upload(k+1) collect(k-1) ...: two batches outstanding, so chunk k+1's
             H2D and (overlap mode) chunk k's pose stage run beside chunk k+1's front end; every step's records
             reach the host; the pose chain continues across the chunks on the device."""
             ctx.upload_frames(0, hostL[0], hostR[0])
             ctx.track_uploaded_async(0, B + 1)
+            if n_steps > 1:
+                ctx.upload_frames(1, hostL[1 % NC], hostR[1 % NC])
             recs = None
             for k in range(1, n_steps):
-                c = k % NC
-                ctx.upload_frames(k & 1, hostL[c], hostR[c])
                 ctx.track_uploaded_async(k & 1, B + 1, continue_chain=True)
+                # chunk k+1's copy is queued before chunk k-1's records are waited for (the copy itself waits ON THE
+                # DEVICE until chunk k-1's kernels have read the buffer): the pose stage of chunk k-1 runs beside
+                # chunk k's kernels and can finish late, and the next copy must not queue up behind that wait
+                if k + 1 < n_steps:
+                    c = (k + 1) % NC
+                    ctx.upload_frames((k + 1) & 1, hostL[c], hostR[c])
                 recs = ctx.collect_results(B)                       # records of step k - 1 on the host
             recs = ctx.collect_results(B)                           # ... and of the last step
             return recs

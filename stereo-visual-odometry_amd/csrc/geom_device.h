@@ -653,7 +653,7 @@ __device__ inline void epnp5_load_v_d(const double *big, int bs, double (&v)[48]
 
 // -- part 3: betas, R, t.  NSEL = 0: all of epnp's three beta approximations, the best one wins
 // (compute_pose's rule); 1..3: only that approximation -- its pose and its reprojection error, for a
-// caller that runs the three side by side and applies the rule itself (pnp_hyp_kernel_wide).
+// caller that runs the three side by side and applies the rule itself (pnp_hyp_kernel).
 // `big` is workspace only here (64 doubles per lane).
 template <int NSEL = 0>
 __device__ inline double epnp5_back_d(Epnp5 &e, const double (&v)[48], double *big, int bs, double Rout[9], double tout[3])
@@ -893,10 +893,11 @@ template <int N>
 __device__ inline double epnp5_betas_pose_d(const double *Lm, const double *rho_m, int ls, const double *hand, int hs, double fu,
                                             double fv, double uc, double vc, double *ws, int st, double Rout[9], double tout[3])
 {
-    double betas[4], bb[5], rho[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) rho[i] = rho_m[i * ls];
+    double betas[4], bb[5];
     {
+        double rho[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) rho[i] = rho_m[i * ls];
         constexpr int nc = N == 1 ? 4 : (N == 2 ? 3 : 5);
         double Lr[6 * nc];
 #pragma unroll
@@ -940,11 +941,11 @@ __device__ inline double epnp5_betas_pose_d(const double *Lm, const double *rho_
             ra[1] = r[1] * betas[0] + 2 * r[2] * betas[1] + r[4] * betas[2] + r[7] * betas[3];
             ra[2] = r[3] * betas[0] + r[4] * betas[1] + 2 * r[5] * betas[2] + r[8] * betas[3];
             ra[3] = r[6] * betas[0] + r[7] * betas[1] + r[8] * betas[2] + 2 * r[9] * betas[3];
-            b[i] = rho[i] - (r[0] * betas[0] * betas[0] + r[1] * betas[0] * betas[1] +
-                             r[2] * betas[1] * betas[1] + r[3] * betas[0] * betas[2] +
-                             r[4] * betas[1] * betas[2] + r[5] * betas[2] * betas[2] +
-                             r[6] * betas[0] * betas[3] + r[7] * betas[1] * betas[3] +
-                             r[8] * betas[2] * betas[3] + r[9] * betas[3] * betas[3]);
+            b[i] = rho_m[i * ls] - (r[0] * betas[0] * betas[0] + r[1] * betas[0] * betas[1] +
+                                    r[2] * betas[1] * betas[1] + r[3] * betas[0] * betas[2] +
+                                    r[4] * betas[1] * betas[2] + r[5] * betas[2] * betas[2] +
+                                    r[6] * betas[0] * betas[3] + r[7] * betas[1] * betas[3] +
+                                    r[8] * betas[2] * betas[3] + r[9] * betas[3] * betas[3]);
         }
         epnp_qr_solve_d(A, b, x);
         for (int i = 0; i < 4; i++) betas[i] += x[i];

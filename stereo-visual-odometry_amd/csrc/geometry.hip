@@ -220,11 +220,11 @@ __global__ __launch_bounds__(64) void pnp_begin_kernel(PnpArgs a)
 // area holds L and rho (shared by the three approximations: 66 doubles) and the three waves' workspaces:
 // 188 doubles per lane, 94 KB -- one workgroup per CU, which is also what the launch beside the next
 // batch's front end wants (two would lock every LDS-staged front-end kernel out of the CU).
-// Two builds of the same body: the batched path launches thousands of blocks beside the
-// next batch's front end and gets 256 registers per wave (two waves per SIMD: a 512-register wave owns
-// a SIMD's register file and starves the kernels it overlaps -- ORB mode: +1 ms per 256 pairs); the
-// LATENCY build, for launches that leave the chip mostly empty (the online path: one pair's 64
-// hypotheses are all there is), takes all 512.
+// ONE build, one wave per SIMD (324 registers): with the state in memory the body no longer needs the 512 the
+// round-2 kernel took for the online path, and a 256-register build for batches -- kept then so that two waves
+// fit a SIMD beside the next batch's front end -- ran its back part out of scratch memory at half the speed
+// (ORB mode: 27.3 k pairs/s with it, 28.4 k with this one; the front end's waves still find 188 registers
+// per SIMD beside a hypothesis wave).
 constexpr int kPnpLdsDoubles = 66 + 40 + 27 + 55;          // per lane: L + rho + the three solve workspaces (> the 144 + 12 of the SVD)
 constexpr size_t kPnpLdsBytes = (size_t)(kPnpLdsDoubles * 64) * sizeof(double);   // 94 KB: ONE workgroup per CU
 constexpr int kPhaseBlocks = kPhaseHyps / kHypBlock;       // hand-over records: one per block of a phase
@@ -334,12 +334,7 @@ __device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem_
         if (active) a.hyp[(int64_t)b * kPhaseHyps + h] = out;
     }
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void pnp_hyp_kernel_wide(PnpArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) double pnp_smem_w[];
-    pnp_hyp_body(a, pnp_smem_w);
-}
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pnp_hyp_kernel(PnpArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void pnp_hyp_kernel(PnpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double pnp_smem[];
     pnp_hyp_body(a, pnp_smem);
@@ -795,8 +790,6 @@ int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
 {
     // called once per context at creation: the EPnP and refit kernels need more dynamic LDS than the default limit
     if (hipFuncSetAttribute((const void *)pnp_hyp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kPnpLdsBytes) != hipSuccess ||
-        hipFuncSetAttribute((const void *)pnp_hyp_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPnpLdsBytes) != hipSuccess)
         return SVO_ERR_HIP;
     if (hipFuncSetAttribute((const void *)pnp_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -831,11 +824,9 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
         const int hyps = niters - base < cap ? niters - base : cap;
         const int blocks = (hyps + kHypBlock - 1) / kHypBlock;
         a.phase_base = base; a.phase_cap = cap; a.phase_index = phase;
-        if ((blocks + 1) * n_items <= 256)     // the chip is not full: latency matters, registers are free
-            hipLaunchKernelGGL(pnp_hyp_kernel_wide, dim3(blocks + 1, n_items), dim3(256), kPnpLdsBytes, st, a);   // + the drawer
-        else        // one block per CU (94 KB of LDS): beside the next batch's front end that is what leaves the
-                    // LDS-staged front-end kernels room on the CU (two 78 KB blocks locked them out: ORB mode, 1.7 ms per step)
-            hipLaunchKernelGGL(pnp_hyp_kernel, dim3(blocks + 1, n_items), dim3(256), kPnpLdsBytes, st, a);
+        // one block per CU (94 KB of LDS, one wave per SIMD); beside the next batch's front end that leaves the
+        // LDS-staged front-end kernels room on the CU (two 78 KB blocks locked them out: ORB mode, 1.7 ms per step)
+        hipLaunchKernelGGL(pnp_hyp_kernel, dim3(blocks + 1, n_items), dim3(256), kPnpLdsBytes, st, a);   // + the drawer
         hipLaunchKernelGGL(pnp_score_kernel, dim3(blocks, n_items, zchunks), dim3(256), 0, st, a);
         hipLaunchKernelGGL(pnp_select_kernel, dim3(n_items), dim3(64), 0, st, a);
         base += cap;

@@ -477,12 +477,15 @@ void System::RunBatched(int B, int decode_threads)
         // on the device) while chunk c-1's records are fetched and chunk c+1 is decoded
         ok = tracking_->TrackUploadedAsync(k, cur_n, chunk > 0);
         if (ok) outstanding++;
+        if (bg.joinable()) bg.join();
+        // chunk c+1 crosses PCIe on the copy stream beside chunk c's kernels.  Its upload is queued BEFORE the
+        // records of chunk c-1 are waited for: their pose stage runs beside chunk c's kernels and may finish late
+        // (its LDS-heavy blocks wait for room behind the LK launch), and a copy queued only after that wait would
+        // start when chunk c is nearly done -- the GPU would idle for the length of the copy
+        const bool more = ok && nn >= 2 && upload(k ^ 1, nn);
         auto t_now = std::chrono::steady_clock::now();
         if (ok && outstanding == 2) { ok = flush(std::chrono::duration<double>(t_now - t_prev).count(), B); outstanding--; }
         t_prev = t_now;
-        if (bg.joinable()) bg.join();
-        // chunk c+1 crosses PCIe on the copy stream beside chunk c's kernels
-        const bool more = ok && nn >= 2 && upload(k ^ 1, nn);
         if (!ok || !more) break;
         next += nn - 1;
         k ^= 1;
