@@ -38,11 +38,31 @@
 //
 // Algorithmic HBM bytes (SURVEY.md 8d gather convention): per point per call
 //   sum over 4 levels (24*24 + 22*22) + 8 in + 8 out + 1 status = 4257 B.
+#include <cstring>
 #include "svo_device.h"
 #include <type_traits>
 #include "svo_kernels.h"
 
 namespace svo {
+
+// Diagnostic build (-DSVO_LK_STAMP=k, tools/gpu/lk_stamps.sh): every wave adds the s_memtime cycles it spends in
+// section k of lk_call4 (between stamp points k and k + 1; k = 8: the whole call) to a counter read back with
+// svo_debug_lk_stamps.  ONE section per build: a stamp drains the LDS queue and waits for the scalar memory
+// unit, and stamping every section at once tripled the kernel's time and measured mostly the stamps.
+#ifdef SVO_LK_STAMP
+__device__ unsigned long long g_lk_stamp[2 * 1024];      // 1024 slots (by workgroup) against atomic contention; summed on read-back
+__device__ __forceinline__ uint32_t lk_now() { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_amdgcn_s_memtime()); }
+#define LK_STAMP_DECL uint32_t lk_t_ = 0, lk_acc_ = 0, lk_n_ = 0
+#define LK_AT(i) do { if ((i) == SVO_LK_STAMP) lk_t_ = lk_now(); else if ((i) == SVO_LK_STAMP + 1) { lk_acc_ += lk_now() - lk_t_; lk_n_++; } } while (0)
+#define LK_CALL_BEGIN do { if (SVO_LK_STAMP == 8) lk_t_ = lk_now(); } while (0)
+#define LK_CALL_END(lane) do { if (SVO_LK_STAMP == 8) { lk_acc_ += lk_now() - lk_t_; lk_n_++; } \
+    if ((lane) == 0) { atomicAdd(&g_lk_stamp[2 * (blockIdx.x & 1023)], (unsigned long long)lk_acc_); atomicAdd(&g_lk_stamp[2 * (blockIdx.x & 1023) + 1], (unsigned long long)lk_n_); } } while (0)
+#else
+#define LK_STAMP_DECL
+#define LK_AT(i)
+#define LK_CALL_BEGIN
+#define LK_CALL_END(lane)
+#endif
 
 constexpr int kSlots = 4;                                 // points per wave
 // I tile: 24 rows x 28 bytes of the level, staged as ROW-PAIR COLUMN WORDS: Q[p][c] = byte c of tile
@@ -302,6 +322,8 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
                                          float2 &outPt, int &status, bool live, uint32_t *lds, const uint32_t *lds_wg,
                                          int wave_off, int lane)
 {
+    LK_STAMP_DECL;
+    LK_CALL_BEGIN;
     PixLane pl;
     pl.row = min(lane / 3, kWin - 1); pl.seg = lane - (lane / 3) * 3; pl.onmask = lane < 63 ? ~0u : 0u;
     pl.qoff = (uint32_t)((pl.seg * 7 * kQColDw + pl.row) * 4);
@@ -347,6 +369,7 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
     request_I(g.nlevels - 1);
     for (int level = g.nlevels - 1; level >= 0; --level) {
         const int w = g.w[level], h = g.h[level], pitch = g.pitch[level];
+        LK_AT(0);
         // ---- control: window position and weights of every slot
         const float lscale = 1.f / (float)(1 << level);
         float px = prevPt.x * lscale, py = prevPt.y * lscale;
@@ -400,6 +423,7 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
             tile_loads(rJ[s], slotJ, slotJ + pitch, (uint32_t)(g.origin[level] + ty0s * pitch + tx0s), q_src, lane, kJPairs * 7);
         }
         wave_lds_fence();
+        LK_AT(1);                                // 0 -> 1: level control, I staging, J requests
 #pragma unroll
         for (int s = 0; s < kSlots; s++) {
             pA[s][0] = pA[s][1] = pA[s][2] = 0;
@@ -414,6 +438,7 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
                 patch_slot<false>(qaddr, pl, W01s, W23s, ipxs, ipys, w, h, IxP[s], IyP[s], nIIx[s], nIIy[s],
                                   pA[s][0], pA[s][1], pA[s][2]);
         }
+        LK_AT(2);                                // 1 -> 2: patch_slot x 4
         wave_lds_fence();                        // the J tiles reuse the I tiles' LDS
 #pragma unroll
         for (int s = 0; s < kSlots; s++) {
@@ -444,10 +469,12 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
 
         // ---- iterations (all slots in lockstep; a slot drops out when it converges or leaves)
         if (level > 0) request_I(level - 1);
+        LK_AT(3);                                // 2 -> 3: J stores, A reduction, 2x2 set-up, next level's I requests
         float pdx = 0.f, pdy = 0.f;
         bool it_on = lvl_on;
         for (int j = 0; j < kLkMaxIter; j++) {
             if (!__any(it_on)) break;
+            LK_AT(4);
             const int inx = cv_floor(qx), iny = cv_floor(qy);
             if (it_on && window_oob(inx, iny, w, h)) {
                 if (level == 0) status = 0;
@@ -472,6 +499,7 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
                 }
                 wave_lds_fence();
             }
+            LK_AT(5);                            // 4 -> 5: iteration control: floor, weights, restage test
             int pb[kSlots][2];
 #pragma unroll
             for (int s = 0; s < kSlots; s++) {
@@ -486,6 +514,7 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
                 for (int k = 0; k < 8; k++) C[k] = pj[k * kJColDw];
                 mismatch_slot(C, Was, Wbs, IxP[s], IyP[s], nIIx[s], nIIy[s], vround, pb[s][0], pb[s][1]);
             }
+            LK_AT(6);                            // 5 -> 6: slot pixel work: J reads, bilinear + mismatch dot products
             float b1f, b2f;
             {
                 int v[8];
@@ -517,6 +546,7 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
                 }
                 pdx = dlx; pdy = dly;
             }
+            LK_AT(7);                            // 6 -> 7: reduce-scatter, solve, convergence tests
         }
         if (live && status && level == 0) {
             // err is requested by the reference: the final window must still be inside (A.4 step 7)
@@ -525,6 +555,7 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
         }
     }
     outPt = make_float2(nx, ny);
+    LK_CALL_END(lane);
 }
 
 // Grid: ONE dimension, a.gx workgroups per batch item; the workgroups of an item walk its points in
@@ -631,6 +662,18 @@ __global__ __launch_bounds__(1024) void compact_kernel(CompactArgs a)
     }
     if (threadIdx.x == 0) a.m_out[b] = base_s;
 }
+
+#ifdef SVO_LK_STAMP
+extern "C" int svo_debug_lk_stamps(unsigned long long out[2], int reset)
+{
+    static unsigned long long h[2 * 1024];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lk_stamp), sizeof(h)) != hipSuccess) return -1;
+    out[0] = out[1] = 0;
+    for (int i = 0; i < 1024; i++) { out[0] += h[2 * i]; out[1] += h[2 * i + 1]; }
+    if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_lk_stamp), h, sizeof(h)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 void launch_lk(const LkArgs &a0, int batch, int max_pts, hipStream_t st)
 {
