@@ -54,6 +54,8 @@ int main(int argc, char **argv)
     }
     vo->Run();
     fprintf(stderr, "processed %d frames\n", vo->FramesProcessed());
+    if (vo->LoopSeconds() > 0)
+        fprintf(stderr, "batched loop: %d pairs in %.6f s\n", vo->FramesProcessed() - 1, vo->LoopSeconds());
     delete vo;
     return 0;
 }

@@ -31,6 +31,9 @@ public:
     bool SetTracksFile(const std::string &path);
     Tracking::Ptr GetTracking() { return tracking_; }
     int FramesProcessed() const { return current_image_index_; }
+    // additive: seconds RunBatched spent from its first decode to its last pose row (decode + H2D + tracking + pose
+    // file; process start, context creation and buffer allocation excluded); 0 for the per-frame loop
+    double LoopSeconds() const { return loop_seconds_; }
     // additive: the HIP device this System's context lives on (before the first frame; default 0), and the
     // sequence it will read: the dataset directory and the number of consecutive stereo frames found there
     void SetDevice(int device) { tracking_->SetDevice(device); }
@@ -58,6 +61,7 @@ private:
     // additive YAML keys batch_size / decode_threads, read once in the constructor (Config is process-wide:
     // another System may have loaded ITS file by the time Run() is called)
     int batch_size_ = 1, decode_threads_ = 0;
+    double loop_seconds_ = 0;
 };
 
 // 8-bit grayscale image readers used by NextFrame_kitti: binary PGM (P5) and PNG (8-bit gray or

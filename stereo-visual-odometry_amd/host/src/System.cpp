@@ -445,6 +445,7 @@ void System::RunBatched(int B, int decode_threads)
         return rc == SVO_OK;
     };
 
+    const auto t_loop = std::chrono::steady_clock::now();    // context, buffers and frame 0's size are known: the loop proper
     int k = 0, next = 0;
     int cur_n = decode(0, 0, 0, B + 1);
     next = cur_n;
@@ -494,6 +495,7 @@ void System::RunBatched(int B, int decode_threads)
     }
     while (ok && outstanding > 0) { ok = flush(0.0, 0); outstanding--; }
     svo_sync(ctx);
+    loop_seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
     for (int q = 0; q < 2; q++)
         for (int cam = 0; cam < 2; cam++) svo_host_free(ctx, pin[q][cam]);
 }
