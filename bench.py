@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1: nccl (= RCCL, the real path) or gloo (rehearsal of the "
                          "multi-rank control flow with several ranks sharing one GPU: collectives on CPU copies)")
+    ap.add_argument("--dist-single", action="store_true",
+                    help="with --gpus 1: initialise the process group anyway (a communicator of ONE rank) and send every gather / "
+                         "barrier / all-reduce of the N > 1 path through it -- the rehearsal of the RCCL calls a one-GPU box allows")
     ap.add_argument("--frames-cache", default="", help="torch file to load/save the rendered S0 frames "
                     "(keeps profiler traces free of the renderer's torch kernels)")
     args = ap.parse_args()
@@ -240,8 +243,14 @@ def main():
     if gloo:                                       # rehearsal: every rank on the same card
         local_rank = local_rank % max(n_dev, 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.dist_single
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:            # only a --dist-single run gets here without one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if gloo:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -325,7 +334,7 @@ def main():
         elif args.config5:  # no collective per step (the ranks run different step counts): keep the records
             acc[s_][off:off + n, :16] = mg.field_view(res, trel_off, n, 16)
             acc[s_][off:off + n, 16] = mg.int_field(res, ok_off, n).to(torch.float64)
-        elif world > 1:
+        elif dist_on:
             mg.gather_poses(host(mg.poses_view(res, pose_off, B)), rank, world, dst=0)
 
     def step(items):
@@ -334,7 +343,7 @@ def main():
         ctx.track_batch(Lk, Rk, results=res_buf[k & 1])
         # svo_track_batch(k) has already ordered the context's stream after the pose stage of batch
         # k-1 (it reuses that stage's buffers), so batch k-1's records are complete here
-        if k > 0 and (world > 1 or by_pairs or args.config5):
+        if k > 0 and (dist_on or by_pairs or args.config5):
             collect(res_buf[(k - 1) & 1], items[(k - 1) % len(items)])
         state["k"] = k + 1
 
@@ -342,7 +351,7 @@ def main():
         """Records of the last step: wait for its pose stage, then collect them; config #5: chain every
         sequence on the device and send the full pose lists to rank 0 (one ragged gather)."""
         k = state["k"]
-        if k > 0 and (world > 1 or by_pairs or args.config5):
+        if k > 0 and (dist_on or by_pairs or args.config5):
             ctx.wait_results()
             collect(res_buf[(k - 1) & 1], items[(k - 1) % len(items)])
         if args.config5:
@@ -371,7 +380,7 @@ def main():
     if not args.no_timing_marks:
         ctx.enable_timing(True)
         ctx.get_timing()                          # clear the log
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -381,7 +390,7 @@ def main():
         drain(plan)                               # every step's records are collected inside the timed region
     torch.cuda.synchronize()
     busy = time.perf_counter() - t0               # this rank's own busy time (config #5: ranks differ)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = mg.max_over_ranks(elapsed, coll_dev, world)
@@ -424,7 +433,8 @@ def main():
         out = {
             "metric": "stereo frames/sec on KITTI-00 1241x376; LK-kernel achieved HBM GB/s vs peak",
             "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "ranks": world,
-            "dist_backend": (args.dist_backend + (" (RCCL)" if not gloo else " (rehearsal: ranks share a card)")) if world > 1 else None,
+            "dist_backend": (args.dist_backend + (" (RCCL)" if not gloo else " (rehearsal: ranks share a card)") +
+                             (", one-rank communicator (--dist-single)" if world == 1 else "")) if dist_on else None,
             "steps": steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(steps, 1), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
@@ -647,7 +657,7 @@ def main():
         if world == 1 and args.e2e_frames >= 3 and not args.config5 and not args.no_secondary:
             out["e2e"] = e2e_leg(args, L, R, P1, W)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
     ctx.close()
 

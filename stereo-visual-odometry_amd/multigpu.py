@@ -40,11 +40,17 @@ def steps_for(lengths, seqs, batch):
     return sum((max(lengths[s] - 1, 0) + batch - 1) // batch for s in seqs)
 
 
+def _solo(world):
+    """One rank and no process group: the collectives are identities.  (One rank WITH a group -- `bench.py
+    --dist-single`, the one-GPU rehearsal of the RCCL calls -- goes through torch.distributed like any other size.)"""
+    return world == 1 and not (dist.is_available() and dist.is_initialized())
+
+
 def gather_ragged(x, rank, world, dst=0):
     """Gathers per-rank tensors of DIFFERENT leading length (n_r, k) to dst: lengths are exchanged
     first, messages are padded to the longest, the padding is cut off again on dst.  Returns the
     list of world tensors on dst, None elsewhere."""
-    if world == 1:
+    if _solo(world):
         return [x]
     n = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
     lens = [torch.zeros_like(n) for _ in range(world)]
@@ -92,7 +98,7 @@ def gather_relative(T_rel_inv, ok, rank, world, dst=0):
     message per rank (chunks padded to the longest), returns (T (N, 16), ok (N,)) in sequence order
     on dst, None elsewhere.  `lengths` need not match across ranks."""
     n = torch.tensor([T_rel_inv.shape[0]], dtype=torch.int64, device=T_rel_inv.device)
-    if world == 1:
+    if _solo(world):
         return T_rel_inv.reshape(-1, 16), ok
     lens = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(lens, n)
@@ -112,7 +118,7 @@ def gather_relative(T_rel_inv, ok, rank, world, dst=0):
 def gather_poses(poses, rank, world, dst=0):
     """poses: (n, 16) float64 tensor of this rank.  Returns the list of all ranks' tensors on dst,
     None elsewhere.  One gather per call; with world == 1 it is the identity."""
-    if world == 1:
+    if _solo(world):
         return [poses]
     buf = [torch.empty_like(poses) for _ in range(world)] if rank == dst else None
     dist.gather(poses, buf, dst=dst)
@@ -121,7 +127,7 @@ def gather_poses(poses, rank, world, dst=0):
 
 def max_over_ranks(seconds, device, world):
     """The slowest rank's wall time (the bench contract: MAX over ranks)."""
-    if world == 1:
+    if _solo(world):
         return float(seconds)
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -220,6 +220,26 @@ def test_bench_refuses_more_nccl_ranks_than_gpus():
     assert f"needs {n} GPU(s)" in r.stderr.decode() and not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--steps", "3"], ["--config5", "--chunks", "1"], ["--steps", "3", "--shard", "pairs"]])
+def test_bench_rccl_calls_on_a_one_rank_communicator(extra):
+    """The `nccl` (= RCCL) branch on the one GPU a test box has: `--dist-single` initialises a process group of ONE
+    rank and every collective of the N > 1 path (barrier, gather of poses / relative motions, the ragged gather of
+    config #5's full pose lists, the max all-reduce) goes through RCCL on device tensors.  Not a scaling measurement --
+    it is the only execution of that branch this pipeline allows, and it catches API misuse the gloo runs cannot."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = _bench("--gpus", "1", "--dist-single", "--warmup", "1", "--batch", "64", "--cpu-pairs", "0", "--e2e-frames", "0",
+               "--no-secondary", *extra, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and "nccl (RCCL), one-rank communicator" in out["dist_backend"] and out["value"] > 0
+    if "--config5" in extra:
+        n_pairs = sum(n - 1 for n in (4541, 1101, 4661, 801, 271, 2761, 1101, 1101))
+        assert out["config"]["config5"]["poses_gathered"] == {"sequences": 8, "pairs": n_pairs, "bytes": n_pairs * 128}
+
+
 def test_bench_gpus_flag_is_checked_without_a_gpu():
     """CPU box: the launcher still starts N ranks, every rank finds no card and exits non-zero, the parent
     returns that code (and prints no JSON line); a WORLD_SIZE that contradicts --gpus is refused too;
