@@ -1143,73 +1143,149 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     }
 }
 
-// ---- BruteForce-Hamming match: 16 query rows per workgroup, first minimum ----------------------
-// The scan is O(Nq * Nt) and, with one query per wave, was bound by L2 bandwidth (every wave
-// re-read the whole train set).  Here a workgroup stages train rows 256 at a time in LDS
-// (dword-transposed: conflict-free) and each of its four waves scores them against FOUR queries
-// held in registers, so a train row is fetched from L2 once per 16 queries.  A lane keeps
-// (distance << 16 | train index) per query; unsigned min == "first minimum" because a lane sees
-// its train rows in ascending order and the wave reduction is a min over the same keys.
-constexpr int kMatchQ = 4;                    // queries per wave
-__global__ __launch_bounds__(256) void orb_match_kernel(const uint8_t *q, const int *nq_p, int nq_fixed, int64_t q_stride,
+// ---- BruteForce-Hamming match on the matrix cores: first minimum over all train rows ----------
+// All-pairs Hamming distance IS a dense contraction: with the query bits as +-1 and the train bits as 0 / 1,
+//   dot(q, t) = 2 pop(q & t) - pop(t)   and   hamming(q, t) = pop(q) + pop(t) - 2 pop(q & t) = pop(q) - dot(q, t),
+// so for a query the nearest train row is the one of LARGEST dot product, and the distance follows from it --
+// exact integers, the same winner and the same distance as the popcount scan this replaces (which sat at its
+// VALU roof: 8 xor + 8 v_bcnt per descriptor pair, 1.2 ms per 256 pairs).  v_mfma_i32_32x32x32_i8 does 32 x 32
+// descriptor pairs x 32 bits per instruction (operand lane maps checked with exact integers:
+// tools/gpu/mfma_i8_probe.hip):
+//   * workgroup = 8 waves = 256 queries; a wave keeps its 32 queries as the B operand of all eight k-steps in
+//     32 registers (bits spread to bytes with one multiply per nibble, once per wave);
+//   * train rows are read PACKED (32 bytes each: the traffic of the old kernel / 8) 64 at a time, spread to 0 / 1
+//     bytes by the staging threads (a dword of bits -> 32 bytes) into a double-buffered LDS tile whose 16-byte
+//     chunks are XOR-swizzled by the row (conflict-free ds_write_b128 / ds_read_b128), one barrier per tile;
+//   * A = 32 train rows, so a lane holds 16 train rows x ONE query column: the running maximum of
+//     ((dot + 256) << 16 | 0xFFFF - train index) stays inside the lane (16 v_lshl_or + 8 v_max3 per 32 x 32 block,
+//     no cross-lane step until the two lane halves are merged at the very end); the key's low half makes the
+//     maximum the FIRST minimum of the distance, as cv::BFMatcher returns it.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+constexpr int kMmT = 64;                         // train rows per LDS tile
+// NW waves = 32 NW queries per workgroup: 8 for batches (a train tile is spread once per 256 queries), 4 for launches
+// that leave the chip mostly empty (the online pair: one wave per SIMD runs its tile loop twice as fast as two)
+
+// 4 bits -> 4 bytes of 0 / 1 (bit b of the nibble -> byte b)
+__device__ __forceinline__ uint32_t spread_nibble(uint32_t n) { return (n * 0x00204081u) & 0x01010101u; }
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void orb_match_kernel(const uint8_t *q, const int *nq_p, int nq_fixed, int64_t q_stride,
                                                         const uint8_t *t, const int *nt_p, int nt_fixed, int64_t t_stride,
                                                         int n_stride, int *idx, float *dist, int64_t out_stride)
 {
-    __shared__ uint32_t tile[8][256];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[2][kMmT * 256];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // per-item row counts sit n_stride ints apart (image slots: left / right of consecutive frames)
     const int nq = nq_p ? nq_p[(int64_t)b * n_stride] : nq_fixed, nt = nt_p ? nt_p[(int64_t)b * n_stride] : nt_fixed;
-    const int i0 = blockIdx.x * (4 * kMatchQ);
+    constexpr int kMmQ = 32 * NW, kStage = 8 / NW;                   // staging items (train row, packed dword) per thread
+    static_assert(NW == 8 || NW == 4, "512 staging items per tile over 64 NW threads");
+    const int i0 = blockIdx.x * kMmQ;
     if (i0 >= nq) return;                                            // uniform over the workgroup
-    const int iq = i0 + wave * kMatchQ;
-    uint32_t Q[kMatchQ][8];
+    const int r = lane & 31, h = lane >> 5;
+    const int iq = i0 + wave * 32 + r;                               // this lane's query (both lane halves: the same one)
+    // ---- B operand: the query's bits [32 s + 16 h, + 16) of every k-step s as +-1 bytes; pop(q)
+    v4i_t Bq[8];
+    int popq = 0;
+    {
+        const uint32_t *qr = (const uint32_t *)(q + (int64_t)b * q_stride + (int64_t)min(iq, nq - 1) * 32);   // duplicates of the last row are not stored
 #pragma unroll
-    for (int k = 0; k < kMatchQ; k++) {
-        const int i = min(iq + k, nq - 1);                           // duplicates of the last row are not stored
-        const uint4 *qr = (const uint4 *)(q + (int64_t)b * q_stride + (int64_t)i * 32);
-        const uint4 a0 = qr[0], a1 = qr[1];
-        Q[k][0] = a0.x; Q[k][1] = a0.y; Q[k][2] = a0.z; Q[k][3] = a0.w;
-        Q[k][4] = a1.x; Q[k][5] = a1.y; Q[k][6] = a1.z; Q[k][7] = a1.w;
-    }
-    uint32_t best[kMatchQ];
+        for (int s = 0; s < 8; s++) {
+            const uint32_t w = qr[s];
+            popq += __popc(w);
+            const uint32_t half = (w >> (16 * h)) & 0xFFFFu;
 #pragma unroll
-    for (int k = 0; k < kMatchQ; k++) best[k] = 0xFFFFFFFFu;
-    const uint8_t *tb = t + (int64_t)b * t_stride;
-    for (int j0 = 0; j0 < nt; j0 += 256) {
-        __syncthreads();
-        if (j0 + tid < nt) {
-            const uint4 *tr = (const uint4 *)(tb + (int64_t)(j0 + tid) * 32);
-            const uint4 t0 = tr[0], t1 = tr[1];
-            tile[0][tid] = t0.x; tile[1][tid] = t0.y; tile[2][tid] = t0.z; tile[3][tid] = t0.w;
-            tile[4][tid] = t1.x; tile[5][tid] = t1.y; tile[6][tid] = t1.z; tile[7][tid] = t1.w;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const int r = lane + 64 * s, j = j0 + r;
-            if (j0 + 64 * s >= nt) break;                            // uniform
-            uint32_t T[8];
-#pragma unroll
-            for (int w = 0; w < 8; w++) T[w] = tile[w][r];
-#pragma unroll
-            for (int k = 0; k < kMatchQ; k++) {
-                uint32_t d = 0;
-#pragma unroll
-                for (int w = 0; w < 8; w++) d += __popc(Q[k][w] ^ T[w]);
-                const uint32_t key = j < nt ? ((d << 16) | (uint32_t)j) : 0xFFFFFFFFu;
-                best[k] = min(best[k], key);
+            for (int c = 0; c < 4; c++) {
+                const uint32_t x = spread_nibble((half >> (4 * c)) & 15u);          // 0 / 1 bytes
+                Bq[s][c] = (int)(x | ((x ^ 0x01010101u) * 0xFFu));                  // 1 -> 0x01, 0 -> 0xFF (= -1)
             }
         }
     }
+    // per-lane constants of the result rows: register g of a 32 x 32 block holds train row (g & 3) + 8 (g >> 2) + 4 h
+    uint32_t Crow[16];
 #pragma unroll
-    for (int k = 0; k < kMatchQ; k++) {
-        uint32_t key = best[k];
+    for (int g = 0; g < 16; g++) Crow[g] = 0xFFFFu - (uint32_t)((g & 3) + 8 * (g >> 2) + 4 * h);
+    const uint8_t *tb = t + (int64_t)b * t_stride;
+    // ---- staging: item = (train row of the tile, packed dword w) -> 32 bytes of 0 / 1 = k-step w; kStage items per thread
+    struct Bits { uint32_t v[kStage]; };
+    auto load_bits = [&](int j0) -> Bits {
+        Bits o;
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, m, 64));
-        if (lane == 0 && iq + k < nq) {
-            idx[(int64_t)b * out_stride + iq + k] = nt > 0 ? (int)(key & 0xFFFFu) : -1;
-            dist[(int64_t)b * out_stride + iq + k] = nt > 0 ? (float)(int)(key >> 16) : (float)(1 << 30);
+        for (int e = 0; e < kStage; e++) {
+            const int it = tid + e * 64 * NW, j = j0 + (it >> 3);
+            o.v[e] = j < nt ? *(const uint32_t *)(tb + (int64_t)j * 32 + 4 * (it & 7)) : 0u;
         }
+        return o;
+    };
+    auto store_tile = [&](uint8_t *dst, const Bits &in) {
+#pragma unroll
+        for (int e = 0; e < kStage; e++) {
+            const int it = tid + e * 64 * NW, srow = it >> 3, sw = it & 7;
+            const uint32_t bits = in.v[e];
+            uint4 lo, hi;
+            lo.x = spread_nibble(bits & 15u); lo.y = spread_nibble((bits >> 4) & 15u); lo.z = spread_nibble((bits >> 8) & 15u); lo.w = spread_nibble((bits >> 12) & 15u);
+            hi.x = spread_nibble((bits >> 16) & 15u); hi.y = spread_nibble((bits >> 20) & 15u); hi.z = spread_nibble((bits >> 24) & 15u); hi.w = spread_nibble(bits >> 28);
+            uint8_t *row = dst + srow * 256;
+            *(uint4 *)(row + 16 * ((2 * sw) ^ (srow & 15))) = lo;                   // chunk 2 s + h of the row, XOR-swizzled
+            *(uint4 *)(row + 16 * ((2 * sw + 1) ^ (srow & 15))) = hi;
+        }
+    };
+    uint32_t best = 0;
+    const int ntiles = (nt + kMmT - 1) / kMmT;
+    // the packed bits of a tile are requested kMmAhead tiles before they are spread into LDS: a tile's products take
+    // ~2 k cycles, a global load under load 2-5 k -- one tile ahead, every round of the workgroup waited for memory
+    constexpr int kMmAhead = 4;
+    Bits pre[kMmAhead];
+#pragma unroll
+    for (int d = 0; d < kMmAhead; d++) pre[d] = load_bits(d * kMmT);            // (rows beyond nt read as zero)
+    if (ntiles > 0) { store_tile(tile[0], pre[0]); pre[0] = load_bits(kMmAhead * kMmT); }
+    __syncthreads();
+    for (int tl0 = 0; tl0 < ntiles; tl0 += kMmAhead) {
+#pragma unroll
+        for (int d = 0; d < kMmAhead; d++) {
+            const int tl = tl0 + d;
+            if (tl >= ntiles) break;                                            // uniform
+            const uint8_t *cur = tile[d & 1];                                   // kMmAhead is even: tile tl lives in buffer tl & 1 = d & 1
+#pragma unroll
+            for (int m = 0; m < 2; m++) {                                       // the tile's two blocks of 32 train rows
+                const int base = tl * kMmT + 32 * m;
+                if (base >= nt) break;                                          // uniform
+                v16i_t acc;
+#pragma unroll
+                for (int g = 0; g < 16; g++) acc[g] = 256;                      // dot + 256 >= 0
+                const uint8_t *arow = cur + (32 * m + r) * 256;
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const v4i_t a = *(const v4i_t *)(arow + 16 * ((2 * s + h) ^ (r & 15)));
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bq[s], acc, 0, 0, 0);
+                }
+                uint32_t key[16];
+#pragma unroll
+                for (int g = 0; g < 16; g++) key[g] = ((uint32_t)acc[g] << 16) | Crow[g];
+                if (nt - base < 32) {                                           // the last block: rows beyond nt never win
+#pragma unroll
+                    for (int g = 0; g < 16; g++) if ((int)(0xFFFFu - Crow[g]) >= nt - base) key[g] = 0u;
+                }
+                uint32_t mx = 0;
+#pragma unroll
+                for (int g = 0; g < 16; g++) mx = max(mx, key[g]);
+                // the block's first row is train `base`: the low half becomes 0xFFFF - global index (no borrow: indices < 65536)
+                best = max(best, mx > 0u ? mx - (uint32_t)base : 0u);
+            }
+            if (tl + 1 < ntiles) {
+                // tile tl + 1 -> the other buffer (its readers passed the barrier below one tile ago), then its register is
+                // free for tile tl + 1 + kMmAhead
+                store_tile(tile[(d + 1) & 1], pre[(d + 1) % kMmAhead]);
+                pre[(d + 1) % kMmAhead] = load_bits((tl + 1 + kMmAhead) * kMmT);
+            }
+            __syncthreads();
+        }
+    }
+    best = max(best, (uint32_t)__shfl_xor((int)best, 32, 64));                      // the two lane halves hold different rows of the same query
+    if (h == 0 && iq < nq) {
+        const int dot = (int)(best >> 16) - 256;
+        idx[(int64_t)b * out_stride + iq] = nt > 0 ? (int)(0xFFFFu - (best & 0xFFFFu)) : -1;
+        dist[(int64_t)b * out_stride + iq] = nt > 0 ? (float)(popq - dot) : (float)(1 << 30);
     }
 }
 
@@ -1554,7 +1630,7 @@ void orb_snapshot_counts(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep,
 
 void orb_launch_match_fixed(svo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, hipStream_t st)
 {
-    hipLaunchKernelGGL(orb_match_kernel, dim3((nq + 4 * kMatchQ - 1) / (4 * kMatchQ), 1), dim3(256), 0, st, q, (const int *)nullptr, nq, (int64_t)0, t,
+    hipLaunchKernelGGL(orb_match_kernel<4>, dim3((nq + 127) / 128, 1), dim3(256), 0, st, q, (const int *)nullptr, nq, (int64_t)0, t,
                        (const int *)nullptr, nt, (int64_t)0, 0, ctx->orb_midx[0], ctx->orb_mdist[0], (int64_t)ctx->orb_kp_cap);
 }
 
@@ -1567,11 +1643,19 @@ int orb_match_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipS
     const int *N = ctx->orb_n;
     const svo_keypoint *K = (const svo_keypoint *)ctx->orb_kps;
     const int64_t fs = (int64_t)fstep * 2;                         // image slots per pair step
+    // an image never holds more keypoints than the per-level quotas allow (+ the extractor's slack): the grid is sized
+    // by that, not by the capacity of the buffers (three quarters of the workgroups were launched to return at once)
+    int max_kp = 0;
+    for (int l = 0; l < ctx->orb_geom.nlevels; l++) max_kp += ctx->orb_geom.quota[l] + 8;
+    if (max_kp > cap) max_kp = cap;
+    const bool small = (int64_t)n_pairs * ((max_kp + 255) / 256) < 256;              // fewer workgroups than CUs: latency shape
+    const int qblocks = small ? (max_kp + 127) / 128 : (max_kp + 255) / 256, qthreads = small ? 256 : 512;
+    auto kern = small ? orb_match_kernel<4> : orb_match_kernel<8>;
     // match1: last.left -> last.right ; match2: last.left -> cur.left  (src/tracking.cpp:543-544)
-    hipLaunchKernelGGL(orb_match_kernel, dim3((cap + 4 * kMatchQ - 1) / (4 * kMatchQ), n_pairs), dim3(256), 0, st, D + (size_t)(2 * fp0) * cap * 32,
+    hipLaunchKernelGGL(kern, dim3(qblocks, n_pairs), dim3(qthreads), 0, st, D + (size_t)(2 * fp0) * cap * 32,
                        N + 2 * fp0, 0, fs * cap * 32, D + (size_t)(2 * fp0 + 1) * cap * 32, N + 2 * fp0 + 1, 0, fs * cap * 32,
                        (int)fs, ctx->orb_midx[0], ctx->orb_mdist[0], (int64_t)cap);
-    hipLaunchKernelGGL(orb_match_kernel, dim3((cap + 4 * kMatchQ - 1) / (4 * kMatchQ), n_pairs), dim3(256), 0, st, D + (size_t)(2 * fp0) * cap * 32,
+    hipLaunchKernelGGL(kern, dim3(qblocks, n_pairs), dim3(qthreads), 0, st, D + (size_t)(2 * fp0) * cap * 32,
                        N + 2 * fp0, 0, fs * cap * 32, D + (size_t)(2 * fc0) * cap * 32, N + 2 * fc0, 0, fs * cap * 32,
                        (int)fs, ctx->orb_midx[1], ctx->orb_mdist[1], (int64_t)cap);
     OrbFilterArgs f{};

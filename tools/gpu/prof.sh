@@ -9,7 +9,7 @@ BARGS="--cpu-pairs 0 --no-secondary --chunks 2 --frames-cache $CACHE"
 python bench.py --steps 2 --warmup 1 $BARGS > gpurun_out/bench_cache.log 2>&1; echo "cache exit=$?"
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --kernel-include-regex "svo::" --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 10 --warmup 2 $BARGS > $R/gpurun_out/prof_stats.log 2>&1; echo "stats exit=$?"
+rm -rf /tmp/prof_stats; rocprofv3 --kernel-trace --stats --kernel-include-regex "svo::" --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 10 --warmup 2 $BARGS > $R/gpurun_out/prof_stats.log 2>&1; echo "stats exit=$?"
 grep '^{' $R/gpurun_out/prof_stats.log | tail -1 > $R/gpurun_out/prof_bench_line.json
 f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/prof_kernel_stats.csv && cat "$f" | cut -c1-160
 i=0
