@@ -14,7 +14,7 @@ for line in open(sys.argv[1]):
     parts = line.split()
     if len(parts) < 3 or "svo::" not in line:
         continue
-    kern = parts[0].split("(")[0].replace("svo::", "")
+    kern = line.split("(")[0].replace("void ", "").strip().replace("svo::", "")      # templated kernels print as "void svo::name<..>("
     name = [p for p in parts if p.isupper() or p.endswith("_sum")]
     if not name:
         continue
@@ -24,7 +24,7 @@ for line in open(sys.argv[1]):
 dur = {}
 if len(sys.argv) > 2 and os.path.exists(sys.argv[2]):
     for row in csv.DictReader(open(sys.argv[2])):
-        dur[row["Name"].split("(")[0].replace("svo::", "")] = (float(row["AverageNs"]) * 1e-6, int(row["Calls"]))
+        dur[row["Name"].split("(")[0].replace("void ", "").strip().replace("svo::", "")] = (float(row["AverageNs"]) * 1e-6, int(row["Calls"]))
 out = {"command": "tools/gpu/pmc_orb.sh: rocprofv3 --pmc <one group per run> -- python3 bench.py --mode orb --batch 256 --steps 1 --warmup 1 "
                   "--no-overlap (256 S0 pairs per step: 514 images through the extractor)", "kernels": {}}
 for k, v in sorted(vals.items()):
