@@ -24,7 +24,7 @@ namespace svo {
 
 // ------------------------------------------------------------------------------------------
 struct PnpState;
-struct PnpBeginArgs { PnpState *state; int *counts; int *subsets; int iterations; };
+struct PnpBeginArgs { PnpState *state; int *counts; int *subsets; int iterations, first_cap; };
 __device__ void pnp_begin_item(const PnpBeginArgs &a, int n, int b, int lane);
 
 struct TriArgs {
@@ -98,7 +98,13 @@ struct PnpRecord {                 // device-side record of one solve
 };
 
 constexpr int kHypBlock = 64;                  // hypotheses per EPnP workgroup (one per lane)
-constexpr int kPhaseHyps = 448;                // hypotheses of a phase after the first: 64 + 448 = 512 >= iterationsCount 500
+constexpr int kPhaseHyps = 512;                // capacity of a phase (hypotheses, counts, subsets, hand-over records per item)
+// The FIRST phase is 64 hypotheses where the adaptive stop usually ends the search inside them (LK mode: ~20
+// iterations at 70 % inliers -- anything more would be computed to be thrown away), and the whole iterationsCount
+// (<= 512: one phase) where it never does (ORB mode: ~18 % inliers, always the full 500): the lone pair of the
+// online path then pays ONE hypothesis launch instead of two in sequence (237 us each).  The subsets of the first
+// phase are drawn by the begin workgroup, which runs beside the triangulation launch.
+inline int pnp_first_cap(const svo_config &cfg) { return cfg.track_mode == SVO_MODE_ORB ? kPhaseHyps : 64; }
 struct PnpState {                              // per item, lives across the launches of one solve
     double bestRt[12];
     uint64_t rng;
@@ -117,6 +123,7 @@ struct PnpArgs {
     int phase_base, phase_cap, phase_index;                 // hypotheses [phase_base, phase_base + phase_cap) in this phase
     int score_chunk;                                        // points per scoring workgroup (grid.z chunks)
     int refit_svd;                                          // 1: always take the SVD route of the refit's solves (SVO_REFIT_SVD=1; tests)
+    int first_cap;                                          // hypotheses of the first phase (pnp_first_cap)
     double *hand;                                           // EPnP hand-over records: per item kPhaseBlocks x 105 x 64 doubles (pnp_hyp_body)
 };
 
@@ -185,7 +192,7 @@ __device__ void pnp_begin_item(const PnpBeginArgs &a, int n, int b, int lane)
     int *sub = a.subsets + (int64_t)b * 2 * kPhaseHyps * 5;         // phase 0 -> buffer 0
     int hyps = 0;
     if (n >= 5) {
-        hyps = niters < kHypBlock ? niters : kHypBlock;
+        hyps = niters < a.first_cap ? niters : a.first_cap;
         if (n > 5) rng = draw_subsets(rng, n, hyps, sub, lane);
         else { hyps = 1; if (lane < 5) sub[lane] = lane; }          // npoints == model_points: one solve, all inliers
     }
@@ -197,7 +204,7 @@ __device__ void pnp_begin_item(const PnpBeginArgs &a, int n, int b, int lane)
 }
 __global__ __launch_bounds__(64) void pnp_begin_kernel(PnpArgs a)
 {
-    const PnpBeginArgs ba{a.state, a.counts, a.subsets, a.iterations};
+    const PnpBeginArgs ba{a.state, a.counts, a.subsets, a.iterations, a.first_cap};
     pnp_begin_item(ba, a.n_pts ? a.n_pts[blockIdx.x] : a.n_fixed, blockIdx.x, threadIdx.x);
 }
 
@@ -820,7 +827,7 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
     const int zchunks = max_pts > 0 ? (max_pts + a.score_chunk - 1) / a.score_chunk : 1;
     int phase = 0;
     for (int base = 0; base < niters; phase++) {
-        const int cap = base == 0 ? kHypBlock : kPhaseHyps;
+        const int cap = base == 0 ? a.first_cap : kPhaseHyps;
         const int hyps = niters - base < cap ? niters - base : cap;
         const int blocks = (hyps + kHypBlock - 1) / kHypBlock;
         a.phase_base = base; a.phase_cap = cap; a.phase_index = phase;
@@ -856,6 +863,7 @@ void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const floa
     a.begin.counts = (int *)(ws + ws_off_counts(ctx->cfg, B));
     a.begin.subsets = (int *)(ws + ws_off_subsets(ctx->cfg, B));
     a.begin.iterations = ctx->cfg.iterations;
+    a.begin.first_cap = pnp_first_cap(ctx->cfg);
     hipLaunchKernelGGL(triangulate_kernel, dim3(gx + 1, n_items), dim3(64), 0, ctx->stream, a);
 }
 
@@ -867,6 +875,7 @@ void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n
     // K = P1[:, :3] (src/tracking.cpp:476-477)
     a.fx = ctx->cfg.P1[0]; a.fy = ctx->cfg.P1[5]; a.cx = ctx->cfg.P1[2]; a.cy = ctx->cfg.P1[6];
     a.iterations = ctx->cfg.iterations; a.reproj_err = ctx->cfg.reproj_err;
+    a.first_cap = pnp_first_cap(ctx->cfg);
     a.confidence = (double)ctx->cfg.confidence;
     a.mask = (uint8_t *)ctx->pnp_ws + ws_off_mask(ctx->cfg.max_batch);
     launch_pnp_pipeline(ctx, a, n_items, ctx->cfg.max_keypoints, st, /*begun by launch_triangulate_batch*/ true);
@@ -930,6 +939,7 @@ int stage_pnp_ransac(svo_ctx *ctx, const svo_pt3f *obj, const svo_pt2f *img, int
     a.stride = 0; a.n_pts = nullptr; a.n_fixed = n;
     a.fx = K[0]; a.fy = K[4]; a.cx = K[2]; a.cy = K[5];
     a.iterations = iterations; a.reproj_err = reproj_err; a.confidence = confidence;
+    a.first_cap = pnp_first_cap(ctx->cfg);                   // (the stage call of a context follows its track_mode too)
     uint8_t *ws_mask = (uint8_t *)ctx->pnp_ws + ws_off_mask(ctx->cfg.max_batch);
     if (mem == SVO_MEM_HOST) {
         if (n > 0) {
