@@ -871,6 +871,525 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
     }
 }
 
+// ---- DistributeOctTree, the passes in parallel over the nodes -----------------------------------
+// ORB-SLAM2's loop (ORBextractor.cpp:553-700) is serial only in appearance.  A pass over the list divides EVERY node
+// that holds more than one key; the children go to the FRONT of the list, so nothing a pass creates is visited by
+// it: the divisions of a pass are independent, and the list it leaves behind is a pure function of the old list:
+//     [ children of the LAST divided node (n4, n3, n2, n1 without the empty ones), ..., children of the FIRST ]
+//     followed by the undivided nodes in their old order.
+// The last phase ("sort the nodes to expand by size, divide the largest first, stop when the list holds N nodes")
+// is the same with the sorted order as the processing order and a cut-off: a node's number of non-empty children
+// is known from its keys per quadrant, the list size after the r-th division is a prefix sum, and the divisions up
+// to the first one that reaches N are exactly those the serial loop performs.
+// So a WORKGROUP OF FOUR WAVES owns an (image, level) -- a lone wave issues one instruction every ~5 cycles whatever
+// it does, and the tree is ~10^5 instructions -- and a pass is
+//   (1) the 4-way partition of every processed node's keys, which also counts them per quadrant: ONE THREAD PER NODE
+//       for nodes of <= kQtSmall keys (the usual case from the third pass on: a level-0 tree has ~250 of them with a
+//       handful of keys each, and the serial kernel spent ~3 k cycles of dependent instructions on each), eight LDS
+//       accesses in flight per thread; a wave together, in registers and in place, on a larger node (consecutive
+//       nodes go to different waves: the first passes have 4 and 16 nodes);
+//   (2) prefix sums over the processing order (workgroup scans through the LDS): children created before each node,
+//       the cut-off (rounds of 256 nodes after the one that holds the cut-off are not even partitioned);
+//   (3) the new list, written beside the old one (two node tables): children's creation numbers in creation order
+//       (processing order, then quadrant), the nodes to expand next for the sort of the last phase.
+// The list is an ARRAY in list order -- no links to chase.  A node past the cut-off has had its keys grouped by
+// quadrant without being divided; that is harmless because the only thing read from an undivided node's keys is
+// "largest response, first in candidate order among equals" == smallest candidate index among the maxima, which
+// does not depend on their order.  Output and tie-breaks are those of orb_distribute_kernel (same keypoints byte
+// for byte: the parity tests compare every image's), which stays for configurations whose node tables do not
+// fit the LDS (and behind SVO_ORB_QT_SERIAL=1, to time one against the other).
+constexpr int kQtSmall = 32;
+constexpr int kQpThreads = 256;
+constexpr int kQpScanBuf = 260;             // ints per scan buffer: 256 values, the total, padding to 16 bytes
+struct QpNode { short ulx, uly, brx, bry; unsigned short beg, cnt, seq, pad; };      // 16 bytes
+struct QpLds {
+    KeyArr keys;                            // kLdsKeys
+    uint8_t *resp;                          // kLdsKeys: FAST score per candidate
+    QpNode *cur, *nxt;                      // node tables (list order), node_cap each
+    unsigned long long *xa;                 // nodes to expand: (count << 48 | creation number << 32 | list position)
+    unsigned short *qc;                     // keys per quadrant of proc[r]: 4 per entry
+    unsigned short *proc;                   // list positions in processing order
+    unsigned short *kpre;                   // children created before proc[r] (exclusive prefix)
+    unsigned short *divided;                // per list position: 1 if divided in this pass
+    int *sbuf;                              // two scan buffers
+    int *sh;                                // a few workgroup-wide scalars
+    KeyArr tmp; int tmp_cap;                // scratch keys of the one-thread partitions: the memory of nxt and xa, dead then
+};
+__host__ __device__ inline size_t qplds_bytes(int node_cap)
+{
+    return (size_t)kLdsKeys * 7 + (size_t)node_cap * (16 * 2 + 8 + 8 + 2 * 3) + (size_t)kQpScanBuf * 2 * 4 + 32 + 16;
+}
+__device__ inline QpLds qplds_carve(uint8_t *smem, int node_cap)
+{
+    QpLds L;
+    L.sbuf = (int *)smem; smem += (size_t)kQpScanBuf * 2 * 4;
+    L.sh = (int *)smem; smem += 32;
+    L.keys.xy = (uint32_t *)smem; smem += (size_t)kLdsKeys * 4;
+    L.cur = (QpNode *)smem; smem += (size_t)node_cap * 16;
+    L.nxt = (QpNode *)smem; smem += (size_t)node_cap * 16;
+    L.xa = (unsigned long long *)smem; smem += (size_t)node_cap * 8;
+    L.qc = (unsigned short *)smem; smem += (size_t)node_cap * 8;
+    L.keys.id = (uint16_t *)smem; smem += (size_t)kLdsKeys * 2;
+    L.proc = (unsigned short *)smem; smem += (size_t)node_cap * 2;
+    L.kpre = (unsigned short *)smem; smem += (size_t)node_cap * 2;
+    L.divided = (unsigned short *)smem; smem += (size_t)node_cap * 2;
+    L.resp = smem;
+    L.tmp.xy = (uint32_t *)L.nxt; L.tmp.id = (uint16_t *)L.xa; L.tmp_cap = 4 * node_cap;   // 16 + 8 bytes per node = 4 keys of 4 + 2
+    return L;
+}
+
+// inclusive prefix sum over the wave's lanes on the DPP network (row shifts inside the rows of 16, then the two row
+// broadcasts: the sequence of LLVM's AMDGPUAtomicOptimizer for gfx9) -- six adds, no LDS round trips
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// exclusive prefix sum over the workgroup's 256 threads taken in the order `o` (a permutation of 0..255); every thread
+// gets the total.  Consecutive calls must alternate between the two buffers (a thread may still be reading the
+// previous call's result when another starts the next).
+__device__ __forceinline__ int blk_excl_scan(int v, int o, int *buf, int tid, int &total)
+{
+    buf[o] = v;
+    __syncthreads();
+    if (tid < 64) {
+        const int4 q = *(const int4 *)(buf + 4 * tid);
+        const int s = q.x + q.y + q.z + q.w;
+        const int incl = wave_incl_scan(s);
+        const int ex = incl - s;
+        *(int4 *)(buf + 4 * tid) = make_int4(ex, ex + q.x, ex + q.x + q.y, ex + q.x + q.y + q.z);
+        if (tid == 63) buf[256] = incl;
+    }
+    __syncthreads();
+    total = rfl(buf[256]);
+    return buf[o];
+}
+
+// a wave together on one node: stable 4-way partition in place (keys held in registers between the reads and the
+// writes), nodes of more than 1024 keys through the instance's global scratch (at the node's own offset)
+template <typename Fence>
+__device__ inline void qp_partition(const KeyArr keys, const KeyArr gscratch, int beg, int n, int midx, int midy, int cnt[4], int lane, Fence fence)
+{
+    cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+    if (n <= 64) {
+        const bool valid = lane < n;
+        const uint2 k = valid ? keys.get(beg + lane) : make_uint2(0, 0);
+        const int q = key_quadrant(k, midx, midy);
+        const int r = chunk_rank(valid, q, lane, cnt);
+        const int off = q == 0 ? 0 : (q == 1 ? cnt[0] : (q == 2 ? cnt[0] + cnt[1] : cnt[0] + cnt[1] + cnt[2]));
+        if (valid) keys.set(beg + off + r, k);
+    } else if (n <= 1024) {
+        uint2 k[16];
+        int q[16], r[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            k[c] = make_uint2(0, 0); q[c] = 0; r[c] = 0;
+            if (64 * c >= n) continue;                        // (uniform: chunks past the node's last key cost nothing)
+            k[c] = lane + 64 * c < n ? keys.get(beg + lane + 64 * c) : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            if (64 * c >= n) continue;
+            q[c] = key_quadrant(k[c], midx, midy);
+            r[c] = chunk_rank(lane + 64 * c < n, q[c], lane, cnt);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            if (64 * c >= n) continue;
+            const int off = q[c] == 0 ? 0 : (q[c] == 1 ? cnt[0] : (q[c] == 2 ? cnt[0] + cnt[1] : cnt[0] + cnt[1] + cnt[2]));
+            if (lane + 64 * c < n) keys.set(beg + off + r[c], k[c]);
+        }
+    } else {
+        for (int base = 0; base < n; base += 64) {
+            const bool valid = base + lane < n;
+            const uint2 k = valid ? keys.get(beg + base + lane) : make_uint2(0, 0);
+            chunk_rank(valid, key_quadrant(k, midx, midy), lane, cnt);
+        }
+        int run[4] = {0, 0, 0, 0};
+        const int o1 = cnt[0], o2 = cnt[0] + cnt[1], o3 = cnt[0] + cnt[1] + cnt[2];
+        for (int base = 0; base < n; base += 64) {
+            const bool valid = base + lane < n;
+            const uint2 k = valid ? keys.get(beg + base + lane) : make_uint2(0, 0);
+            const int q = key_quadrant(k, midx, midy);
+            const int r = chunk_rank(valid, q, lane, run);
+            const int off = q == 0 ? 0 : (q == 1 ? o1 : (q == 2 ? o2 : o3));
+            if (valid) gscratch.set(beg + off + r, k);
+        }
+        __threadfence();
+        for (int i = lane; i < n; i += 64) keys.set(beg + i, gscratch.get(beg + i));
+    }
+    fence();
+}
+
+// Diagnostic build (-DSVO_QT_STAMP, tools/gpu/qt_stamps.sh): the (image 0, level 0) instance prints the cycles its first
+// wave spent per section.
+#ifdef SVO_QT_STAMP
+#define QT_AT(i) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_amdgcn_s_memtime()); qt_acc[i] += now_ - qt_last; qt_last = now_; }
+#else
+#define QT_AT(i)
+#endif
+
+__global__ __launch_bounds__(kQpThreads) void orb_distribute_par_kernel(OrbDistArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t qp_smem[];
+    QpLds L = qplds_carve(qp_smem, a.node_cap);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.x, l = blockIdx.y, inst = b * a.g.nlevels + l;
+    const int nkeys = a.lvl_cnt[inst];
+    const float4 *cand = a.lvl_cand + (int64_t)inst * a.cand_cap;
+    int *sel = a.sel + (int64_t)inst * a.sel_cap;
+    const int W = a.g.w[l], H = a.g.h[l];
+    const int minX = 16, maxX = W - 16, minY = 16, maxY = H - 16, N = a.g.quota[l];
+    const int cap = a.node_cap;
+    if (maxX <= minX || maxY <= minY || nkeys == 0) { if (tid == 0) a.sel_cnt[inst] = 0; return; }
+    const int nIni = (int)roundf((float)(maxX - minX) / (maxY - minY));
+    if (nIni <= 0) { if (tid == 0) a.sel_cnt[inst] = 0; return; }
+    const float hX = (float)(maxX - minX) / nIni;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // candidate lists longer than the LDS key arrays (cv::FAST is uncapped; the default capacity is 4 x max_keypoints per
+    // level) are partitioned in the instance's global scratch instead: same code, the fences then cover global memory too
+    const bool keys_global = nkeys > kLdsKeys;
+    KeyArr gk, gt;
+    gk.xy = (uint32_t *)(a.gkeys + (int64_t)inst * a.cand_cap); gk.id = (uint16_t *)(gk.xy + a.cand_cap);
+    gt.xy = (uint32_t *)(a.gtmp + (int64_t)inst * a.cand_cap); gt.id = (uint16_t *)(gt.xy + a.cand_cap);
+    const KeyArr keys = keys_global ? gk : L.keys;
+    auto wfence = [&]() { if (keys_global) __threadfence(); wave_lds_fence(); };
+    auto sync = [&]() { if (keys_global) __threadfence(); __syncthreads(); };
+    int sbsel = 0;
+    auto scan = [&](int v, int o, int &total) -> int {
+        int *bf = L.sbuf + kQpScanBuf * sbsel;
+        sbsel ^= 1;
+        return blk_excl_scan(v, o, bf, tid, total);
+    };
+    bool overflow = false;
+#ifdef SVO_QT_STAMP
+    uint32_t qt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, qt_last = 0, qt_passes = 0;
+    QT_AT(11) qt_acc[11] = 0;
+#endif
+
+    // ---- root nodes: stable binning of the candidates by column strip.  Each wave takes a quarter of the candidate list;
+    // lane i keeps strip i's count in that quarter, then its fill position; two sweeps over the list (global memory,
+    // eight loads in flight).  Empty roots are dropped, their creation numbers are not.
+    const int nroot = min(min(nIni, 64), cap);
+    int n = 0, seq = 0;
+    {
+        const int quarter = ((nkeys + 255) / 256) * 64;
+        const int kbeg = wv * quarter, kend = min(nkeys, kbeg + quarter);
+        int mine_cnt = 0, fill = 0;
+        auto strip_of = [&](float x) { return min((int)(x / hX), nIni - 1); };
+        auto count_chunk = [&](bool valid, int s) {
+            for (int i = 0; i < nroot; i++) {
+                const int c = __popcll(__ballot(valid && s == i));
+                if (lane == i) mine_cnt += c;
+            }
+        };
+        auto place_chunk = [&](bool valid, int s, int k, const float4 &c) {
+            int dst = 0;
+            for (int i = 0; i < nroot; i++) {
+                const unsigned long long m = __ballot(valid && s == i);
+                const int at = __builtin_amdgcn_readlane(fill, i);
+                if (s == i) dst = at + __popcll(m & lt);
+                if (lane == i) fill += __popcll(m);
+            }
+            if (valid && s < nroot) keys.set(dst, make_uint2((uint32_t)(int)c.x | ((uint32_t)(int)c.y << 16), (uint32_t)k));
+            if (valid && !keys_global) L.resp[k] = (uint8_t)(int)c.z;
+        };
+        // a quarter that fits the LDS key arrays is read once and held in registers between the two sweeps
+        constexpr int kRootChunks = (kLdsKeys + 255) / 256;
+        float4 held[kRootChunks];
+        int held_s[kRootChunks];
+        if (!keys_global) {
+#pragma unroll
+            for (int u = 0; u < kRootChunks; u++) held[u] = cand[min(kbeg + 64 * u + lane, nkeys - 1)];
+#pragma unroll
+            for (int u = 0; u < kRootChunks; u++) {
+                held_s[u] = strip_of(held[u].x);
+                if (kbeg + 64 * u < kend) count_chunk(kbeg + 64 * u + lane < kend, held_s[u]);
+            }
+        } else {
+            for (int base = kbeg; base < kend; base += 512) {
+                float cx[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) cx[u] = cand[min(base + 64 * u + lane, nkeys - 1)].x;
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (base + 64 * u < kend) count_chunk(base + 64 * u + lane < kend, strip_of(cx[u]));
+            }
+        }
+        int *rc = L.sbuf;                                                   // [4 waves][64 strips]
+        rc[wv * 64 + lane] = mine_cnt;
+        __syncthreads();
+        const int t0 = rc[lane], t1 = rc[64 + lane], t2 = rc[128 + lane], t3 = rc[192 + lane];
+        const int tot = t0 + t1 + t2 + t3;
+        const int start = wave_incl_scan(tot) - tot;
+        fill = start + (wv > 0 ? t0 : 0) + (wv > 1 ? t1 : 0) + (wv > 2 ? t2 : 0);
+        if (!keys_global) {
+#pragma unroll
+            for (int u = 0; u < kRootChunks; u++)
+                if (kbeg + 64 * u < kend) place_chunk(kbeg + 64 * u + lane < kend, held_s[u], kbeg + 64 * u + lane, held[u]);
+        } else {
+            for (int base = kbeg; base < kend; base += 512) {
+                float4 c4[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) c4[u] = cand[min(base + 64 * u + lane, nkeys - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (base + 64 * u < kend) place_chunk(base + 64 * u + lane < kend, strip_of(c4[u].x), base + 64 * u + lane, c4[u]);
+            }
+        }
+        const bool have = lane < nroot && tot > 0;
+        const unsigned long long hm = __ballot(have);
+        if (wv == 0 && have) {
+            QpNode nd;
+            nd.ulx = (short)(int)(hX * (float)lane); nd.uly = 0; nd.brx = (short)(int)(hX * (float)(lane + 1)); nd.bry = (short)(maxY - minY);
+            nd.beg = (unsigned short)start; nd.cnt = (unsigned short)tot; nd.seq = (unsigned short)lane; nd.pad = 0;
+            L.cur[__popcll(hm & lt)] = nd;
+        }
+        n = __popcll(hm); seq = nroot;
+    }
+    sync();
+    QT_AT(0)
+
+    // One pass.  np nodes to process are listed in L.proc (list positions, processing order); limitN > 0: stop after the
+    // division that brings the list to limitN nodes (the last phase), 0: divide them all.  Swaps the node tables, leaves
+    // the children to expand next in L.xa (n_exp of them), updates n and seq.
+    auto pass = [&](int np, int limitN, int &n_exp) {
+        // (1) partition + keys per quadrant, (2) children before each processed node and the cut-off
+        int carry = 0, ndiv = np, total_kids = 0;
+        bool found = false;
+        const KeyArr tmp = L.tmp;
+        const int o = lane * 4 + wv;                                        // consecutive nodes on different waves
+        for (int r0 = 0; r0 < np && !found; r0 += kQpThreads) {
+            const int r = r0 + o;
+            const bool act = r < np;
+            int beg = 0, cnt = 0, midx = 0, midy = 0;
+            if (act) {
+                const QpNode nd = L.cur[L.proc[r]];
+                beg = nd.beg; cnt = nd.cnt;
+                midx = nd.ulx + ((nd.brx - nd.ulx + 1) >> 1); midy = nd.uly + ((nd.bry - nd.uly + 1) >> 1);   // ceil(d / 2)
+            }
+            if (tid == 0) L.sh[0] = 0x7FFFFFFF;
+            const bool maybe_small = act && cnt <= kQtSmall;
+            int ttot;
+            const int toff = scan(maybe_small ? cnt : 0, o, ttot);
+            const bool small_one = maybe_small && toff + cnt <= L.tmp_cap;
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            if (small_one) {
+                for (int k0 = 0; k0 < cnt; k0 += 8) {                       // copy to the scratch, counting
+                    uint2 kk[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) kk[u] = keys.get(beg + min(k0 + u, cnt - 1));
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (k0 + u < cnt) {
+                            const int q = key_quadrant(kk[u], midx, midy);
+                            c0 += q == 0; c1 += q == 1; c2 += q == 2; c3 += q == 3;
+                            tmp.set(toff + k0 + u, kk[u]);
+                        }
+                }
+                int o0 = beg, o1 = beg + c0, o2 = o1 + c1, o3 = o2 + c2;
+                for (int k0 = 0; k0 < cnt; k0 += 8) {                       // back, each key to its quadrant's range
+                    uint2 kk[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) kk[u] = tmp.get(toff + min(k0 + u, cnt - 1));
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (k0 + u < cnt) {
+                            const int q = key_quadrant(kk[u], midx, midy);
+                            int od;
+                            if (q == 0) od = o0++; else if (q == 1) od = o1++; else if (q == 2) od = o2++; else od = o3++;
+                            keys.set(od, kk[u]);
+                        }
+                }
+            }
+            QT_AT(1)
+            unsigned long long big = __ballot(act && !small_one);
+            while (big) {                                                   // this wave together on a larger node of its own
+                const int src = __ffsll((long long)big) - 1;
+                big &= big - 1;
+                int c[4];
+                qp_partition(keys, gt, __builtin_amdgcn_readlane(beg, src), __builtin_amdgcn_readlane(cnt, src),
+                             __builtin_amdgcn_readlane(midx, src), __builtin_amdgcn_readlane(midy, src), c, lane, wfence);
+                if (lane == src) { c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; }
+            }
+            QT_AT(2)
+            const int kids = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+            int ktot;
+            const int pre = carry + scan(kids, o, ktot);
+            if (act) {
+                *(uint2 *)(L.qc + 4 * r) = make_uint2((uint32_t)c0 | ((uint32_t)c1 << 16), (uint32_t)c2 | ((uint32_t)c3 << 16));
+                L.kpre[r] = (unsigned short)pre;
+            }
+            carry += ktot;
+            total_kids = carry;
+            if (limitN > 0) {
+                // list size after dividing nodes 0..r: n + (children of 0..r) - (r + 1); the first r that reaches limitN
+                if (act && n + pre + kids - (r + 1) >= limitN) atomicMin(L.sh, (r << 16) | (pre + kids));
+                __syncthreads();
+                const int first = rfl(L.sh[0]);
+                if (first != 0x7FFFFFFF) { ndiv = (first >> 16) + 1; total_kids = first & 0xFFFF; found = true; }
+            }
+        }
+        sync();
+        const int n_new = n + total_kids - ndiv;
+        if (n_new > cap || seq + total_kids > 65535) { overflow = true; return; }
+        for (int i = tid; i < n; i += kQpThreads) L.divided[i] = 0;
+        __syncthreads();
+        for (int r = tid; r < ndiv; r += kQpThreads) L.divided[L.proc[r]] = 1;
+        QT_AT(3)
+        // (3) the children of the divided nodes
+        int xcarry = 0;
+        for (int r0 = 0; r0 < ndiv; r0 += kQpThreads) {
+            const int r = r0 + tid;
+            const bool act = r < ndiv;
+            int nx = 0, blk = 0, kids = 0, pre = 0;
+            int cq[4] = {0, 0, 0, 0};
+            if (act) {
+                const QpNode nd = L.cur[L.proc[r]];
+                const uint2 qv = *(const uint2 *)(L.qc + 4 * r);
+                cq[0] = (int)(qv.x & 0xFFFFu); cq[1] = (int)(qv.x >> 16); cq[2] = (int)(qv.y & 0xFFFFu); cq[3] = (int)(qv.y >> 16);
+                pre = L.kpre[r];
+                kids = (cq[0] > 0) + (cq[1] > 0) + (cq[2] > 0) + (cq[3] > 0);
+                blk = total_kids - (pre + kids);        // the block of node r starts where the children of the nodes processed AFTER it end
+                const int midx = nd.ulx + ((nd.brx - nd.ulx + 1) >> 1), midy = nd.uly + ((nd.bry - nd.uly + 1) >> 1);
+                int before = 0, begk = nd.beg;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (cq[q] > 0) {
+                        QpNode ch;
+                        ch.ulx = (short)((q & 1) ? midx : nd.ulx); ch.uly = (short)((q & 2) ? midy : nd.uly);
+                        ch.brx = (short)((q & 1) ? nd.brx : midx); ch.bry = (short)((q & 2) ? nd.bry : midy);
+                        ch.beg = (unsigned short)begk; ch.cnt = (unsigned short)cq[q]; ch.seq = (unsigned short)(seq + pre + before); ch.pad = 0;
+                        L.nxt[blk + (kids - 1 - before)] = ch;              // n4 first ... n1 last
+                        nx += cq[q] > 1;
+                        before++;
+                    }
+                    begk += cq[q];
+                }
+            }
+            // nodes to expand next, in creation order (the sort of the last phase is by (count, creation number))
+            int xtot;
+            const int xpos = xcarry + scan(nx, tid, xtot);
+            xcarry += xtot;
+            if (act && nx) {
+                int before = 0, w = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (cq[q] > 0) {
+                        if (cq[q] > 1) {
+                            L.xa[xpos + w] = ((unsigned long long)(((uint32_t)cq[q] << 16) | (uint32_t)(seq + pre + before)) << 32) |
+                                             (unsigned long long)(blk + (kids - 1 - before));
+                            w++;
+                        }
+                        before++;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        QT_AT(4)
+        // the undivided nodes keep their order behind the children
+        int ucarry = 0;
+        for (int i0 = 0; i0 < n; i0 += kQpThreads) {
+            const int i = i0 + tid;
+            const bool und = i < n && L.divided[i] == 0;
+            int utot;
+            const int rank = ucarry + scan(und ? 1 : 0, tid, utot);
+            ucarry += utot;
+            if (und) L.nxt[total_kids + rank] = L.cur[i];
+        }
+        sync();
+        QpNode *sw = L.cur; L.cur = L.nxt; L.nxt = sw;
+        L.tmp.xy = (uint32_t *)L.nxt;                   // (the scratch keys follow the table that is not the list)
+        n = n_new; seq += total_kids; n_exp = xcarry;
+        QT_AT(5)
+#ifdef SVO_QT_STAMP
+        qt_passes++;
+#endif
+    };
+
+    bool finish = false;
+    int n_exp = 0;
+    while (!finish && !overflow) {
+        const int prevSize = n;
+        // the bulk pass: every node with more than one key, in list order
+        int np = 0;
+        for (int i0 = 0; i0 < n; i0 += kQpThreads) {
+            const int i = i0 + tid;
+            const bool ex = i < n && L.cur[i].cnt > 1;
+            int ptot;
+            const int r = np + scan(ex ? 1 : 0, tid, ptot);
+            np += ptot;
+            if (ex) L.proc[r] = (unsigned short)i;
+        }
+        sync();
+        QT_AT(6)
+        int nToExpand = 0;
+        if (np > 0) pass(np, 0, nToExpand);
+        if (overflow) break;
+        if (n >= N || n == prevSize) finish = true;
+        else if (n + nToExpand * 3 > N) {
+            n_exp = nToExpand;
+            while (!finish && !overflow) {
+                const int prev2 = n, ne = n_exp;
+                if (ne == 0) break;
+                // processing order: descending (count, creation number).  Rank sort in registers: an entry per thread
+                // against every entry, broadcast lane by lane (v_readlane) from one register per 64
+                for (int i0 = 0; i0 < ne; i0 += kQpThreads) {
+                    const unsigned long long e = L.xa[min(i0 + tid, ne - 1)];
+                    const uint32_t me = (uint32_t)(e >> 32);
+                    int rank = 0;
+                    for (int j0 = 0; j0 < ne; j0 += 64) {
+                        // (lanes past the end hold 0, which is larger than nothing: all 64 are compared, unrolled)
+                        const uint32_t x = j0 + lane < ne ? (uint32_t)(L.xa[j0 + lane] >> 32) : 0u;
+#pragma unroll
+                        for (int t = 0; t < 64; t++) rank += (uint32_t)__builtin_amdgcn_readlane((int)x, t) > me;
+                    }
+                    if (i0 + tid < ne) L.proc[rank] = (unsigned short)(uint32_t)e;
+                }
+                sync();
+                QT_AT(7)
+                pass(ne, N, n_exp);
+                if (n >= N || n == prev2) finish = true;
+            }
+            finish = true;
+        }
+    }
+    // ---- leaves in list order -> best response of each (one leaf per thread): the largest, the smallest candidate index
+    // among equals (== the first in candidate order, ORBextractor.cpp:703-722)
+    const int m = min(n, a.sel_cap);
+    for (int j = tid; j < m; j += kQpThreads) {
+        const QpNode nd = L.cur[j];
+        int best = 0x7FFFFFFF, maxR = -1;
+        for (int k0 = 0; k0 < nd.cnt; k0 += 4) {
+            int id[4], rs[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) id[u] = keys.id[nd.beg + min(k0 + u, nd.cnt - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) rs[u] = keys_global ? (int)cand[id[u]].z : (int)L.resp[id[u]];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (rs[u] > maxR || (rs[u] == maxR && id[u] < best)) { best = id[u]; maxR = rs[u]; }
+        }
+        sel[j] = best;
+    }
+    QT_AT(8)
+#ifdef SVO_QT_STAMP
+    if (tid == 0 && inst == 0)
+        printf("qt nkeys %d n %d passes %u | roots %u small %u big %u scan %u kids %u undiv %u proc %u sort %u final %u\n", nkeys, n, qt_passes,
+               qt_acc[0], qt_acc[1], qt_acc[2], qt_acc[3], qt_acc[4], qt_acc[5], qt_acc[6], qt_acc[7], qt_acc[8]);
+#endif
+    if (tid == 0) {
+        a.sel_cnt[inst] = m;
+        if (overflow) atomicOr(a.overflow + b, 1);
+    }
+}
+
 // ---- blur (7x7, sigma 2, reflect-101; integer kernel, (sum + 2^15) >> 16, saturated) -------------
 // One pass: a thread owns 4 adjacent columns of a 28-row band.  A row's four 7-tap sums are two
 // v_dot4_u32_u8 each on byte windows cut from three aligned dwords (reflect-101 at the image edges by
@@ -1484,6 +2003,11 @@ int orb_alloc(svo_ctx *ctx)
             return SVO_ERR_ARG;
         }
         SVO_HIP(hipFuncSetAttribute((const void *)orb_distribute_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        // the node-parallel kernel: positions are 12-bit fields of the expansion keys, candidates must fit its LDS
+        ctx->orb_qt_parallel = qplds_bytes(ctx->orb_node_cap) <= 150 * 1024 && ctx->orb_node_cap <= 4096 && getenv("SVO_ORB_QT_SERIAL") == nullptr;
+        if (ctx->orb_qt_parallel)
+            SVO_HIP(hipFuncSetAttribute((const void *)orb_distribute_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)qplds_bytes(ctx->orb_node_cap)));
     }
     ctx->orb_cand_cap = 4 * ctx->cfg.max_keypoints;      // FAST candidates kept per (image, level)
     const int kCandCap = ctx->orb_cand_cap;
@@ -1592,7 +2116,10 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     d.sel = ctx->orb_sel + (size_t)slot0 * L * ctx->orb_node_cap; d.sel_cnt = ctx->orb_sel_cnt + (size_t)slot0 * L; d.sel_cap = ctx->orb_node_cap;
     d.overflow = ovf;
     d.node_cap = ctx->orb_node_cap;
-    hipLaunchKernelGGL(orb_distribute_kernel, dim3(n_img, L), dim3(64), qlds_bytes(ctx->orb_node_cap), st, d);
+    if (ctx->orb_qt_parallel)
+        hipLaunchKernelGGL(orb_distribute_par_kernel, dim3(n_img, L), dim3(kQpThreads), qplds_bytes(ctx->orb_node_cap), st, d);
+    else
+        hipLaunchKernelGGL(orb_distribute_kernel, dim3(n_img, L), dim3(64), qlds_bytes(ctx->orb_node_cap), st, d);
     timing_mark(ctx, "orb_quadtree");
     OrbDescArgs e{};
     e.g = g; e.slots = slots; e.slot_stride = g.slot_bytes; e.blur = blur; e.blur_img_stride = g.blur_total;

@@ -46,6 +46,7 @@ struct svo_ctx {
     double pose[16];
     // ---- ORB path (allocated on first use: orb_alloc)
     bool orb_ready = false;
+    bool orb_qt_parallel = false;            // the node-parallel quadtree kernel is usable for this configuration
     svo::OrbGeom orb_geom;
     uint8_t *orb_slots = nullptr, *orb_blur = nullptr;
     void *orb_xtab = nullptr, *orb_ytab = nullptr;       // cv::resize coordinate / weight tables
