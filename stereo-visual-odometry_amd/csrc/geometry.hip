@@ -24,7 +24,7 @@ namespace svo {
 
 // ------------------------------------------------------------------------------------------
 struct PnpState;
-struct PnpBeginArgs { PnpState *state; int *counts; int *subsets; int iterations, first_cap; };
+struct PnpBeginArgs { PnpState *state; int *counts; int *subsets; int iterations, first_cap; const uint64_t *stream; };
 __device__ void pnp_begin_item(const PnpBeginArgs &a, int n, int b, int lane);
 
 struct TriArgs {
@@ -124,6 +124,7 @@ struct PnpArgs {
     int score_chunk;                                        // points per scoring workgroup (grid.z chunks)
     int refit_svd;                                          // 1: always take the SVD route of the refit's solves (SVO_REFIT_SVD=1; tests)
     int first_cap;                                          // hypotheses of the first phase (pnp_first_cap)
+    const uint64_t *stream;                                 // cv::RNG(-1)'s first kRngStream states (draw_subsets_stream)
     double *hand;                                           // EPnP hand-over records: per item kPhaseBlocks x 105 x 64 doubles (pnp_hyp_body)
 };
 
@@ -179,6 +180,106 @@ __device__ inline uint64_t draw_subsets(uint64_t rng_in, int n, int count, int *
     return ((uint64_t)hi << 32) | lo;
 }
 
+// The FIRST subsets of a solve, drawn by the 64 lanes together.  RANSACPointSetRegistrator::run seeds its cv::RNG with
+// (uint64)-1 on every call, so the raw 32-bit draws of a solve are a CONSTANT sequence: the context holds the first
+// kRngStream generator states (geom_workspace_init), and only what depends on the data is computed here --
+//   (1) idx[p] = draw p modulo the point count, for the whole stretch at once (LDS);
+//   (2) a subset that starts at position p consumes 5 draws unless it meets a duplicate index: one flag per position
+//       (each lane plays getSubset from its position), gathered by residue of p modulo 5 into bit masks;
+//   (3) the chain "subset k+1 starts where subset k ended" is then a walk over the FLAGGED subsets only (a few per
+//       hundred at a few hundred points): between two of them the starts are an arithmetic progression of step 5,
+//       found with one find-first-set per 64 subsets; a flagged subset is replayed (wave-uniform) for its length;
+//   (4) every subset's five indices are read off the stream from its start, a lane per subset.
+// The result is the serial generator's, draw for draw; when the stretch runs out (tiny point counts redraw a lot)
+// the caller continues with draw_subsets from the state reached.  512 subsets: ~25 us instead of 130 (the scalar
+// chain is ~100 cycles per draw), on the critical path of the online pair in ORB mode.
+constexpr int kRngStream = 4096;
+struct DrawLds { uint16_t idx[kRngStream + 8]; uint16_t pos[kPhaseHyps]; };
+__device__ inline int draw_subsets_stream(const uint64_t *stream, int n, int count, int *dst, int lane, uint64_t *state_out)
+{
+    __shared__ DrawLds s;
+    int T = 5 * count + (count >> 1) + 64;
+    T = T < kRngStream ? T : kRngStream;
+    const FastMod fm = fastmod_make((uint32_t)n);
+    for (int p0 = 0; p0 < T; p0 += 512) {                       // (eight loads in flight)
+        uint64_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = stream[min(p0 + 64 * u + lane, kRngStream - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (p0 + 64 * u + lane < T) s.idx[p0 + 64 * u + lane] = (uint16_t)fastmod((uint32_t)v[u], fm);
+    }
+    wave_lds_fence();
+    // five consecutive draws: all different?  (the common case: a subset of exactly five draws)
+    auto five = [&](int p, uint32_t id[5]) -> bool {
+#pragma unroll
+        for (int i = 0; i < 5; i++) id[i] = s.idx[p + i];       // (idx has 8 entries of slack past the stretch)
+        return id[0] != id[1] && id[0] != id[2] && id[0] != id[3] && id[0] != id[4] && id[1] != id[2] && id[1] != id[3] &&
+               id[1] != id[4] && id[2] != id[3] && id[2] != id[4] && id[3] != id[4];
+    };
+    // getSubset from position p in general: the position after its fifth distinct index, or -1 when the stretch ends first
+    auto play = [&](int p, uint32_t id[5]) -> int {
+        int pp = p;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            for (;;) {
+                if (pp >= T) return -1;
+                id[i] = s.idx[pp++];
+                bool dup = false;
+#pragma unroll
+                for (int j = 0; j < i; j++) dup = dup || id[j] == id[i];
+                if (!dup) break;
+            }
+        }
+        return pp;
+    };
+    // flags by position: word c (positions 64 c + lane) in lane c of (flo, fhi); the last positions of the stretch are flagged
+    const int W = (T + 63) / 64;
+    uint32_t flo = 0, fhi = 0;
+    for (int c = 0; c < W; c++) {
+        const int p = 64 * c + lane;
+        uint32_t id[5];
+        const bool distinct = five(min(p, T), id);
+        const unsigned long long m = __ballot(p + 5 > T || !distinct);
+        if (lane == c) { flo = (uint32_t)m; fhi = (uint32_t)(m >> 32); }
+    }
+    // the walk (wave-uniform): from a subset start p, the next flagged start among p, p + 5, p + 10, ... -- the positions
+    // congruent to p modulo 5 are bits (p + c) % 5, + 5, + 10, ... of word c (64 = 4 modulo 5)
+    int k = 0, p = 0;
+    while (k < count && p < T) {
+        const int r = p % 5;
+        int pn = -1, bit = p & 63;
+        for (int c = p >> 6; c < W; c++, bit = 0) {
+            unsigned long long w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)fhi, c) << 32) |
+                                   (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)flo, c);
+            w &= (0x1084210842108421ull << ((r + c) % 5)) & (~0ull << bit);
+            if (w) { pn = c * 64 + __ffsll((long long)w) - 1; break; }
+        }
+        if (pn < 0) break;                                      // (cannot happen: every class has a flagged position at the end)
+        int take = (pn - p) / 5;
+        take = take < count - k ? take : count - k;
+        for (int j = lane; j < take; j += 64) s.pos[k + j] = (uint16_t)(p + 5 * j);
+        k += take; p += 5 * take;
+        if (k >= count || p >= T) break;
+        // a subset with a redraw (or the end of the stretch): replay it for its length
+        uint32_t id[5];
+        const int pe = play(p, id);                             // (uniform: every lane replays the same subset)
+        if (pe < 0) break;
+        if (lane == 0) s.pos[k] = (uint16_t)p;
+        k++; p = sgpr((uint32_t)pe);
+    }
+    wave_lds_fence();
+    for (int kk = lane; kk < k; kk += 64) {
+        uint32_t id[5];
+        const int ps = s.pos[kk];
+        if (ps + 5 > T || !five(ps, id)) play(ps, id);
+#pragma unroll
+        for (int i = 0; i < 5; i++) dst[kk * 5 + i] = (int)id[i];
+    }
+    *state_out = p == 0 ? ~0ull : stream[p - 1];
+    return k;
+}
+
 // Subsets are double-buffered by phase parity: while the EPnP blocks of phase p run, one extra
 // workgroup of the same launch draws the subsets phase p+1 would need (they depend on the RNG state
 // only, not on the selection), so the serial drawing never sits on the critical path.
@@ -193,8 +294,11 @@ __device__ void pnp_begin_item(const PnpBeginArgs &a, int n, int b, int lane)
     int hyps = 0;
     if (n >= 5) {
         hyps = niters < a.first_cap ? niters : a.first_cap;
-        if (n > 5) rng = draw_subsets(rng, n, hyps, sub, lane);
-        else { hyps = 1; if (lane < 5) sub[lane] = lane; }          // npoints == model_points: one solve, all inliers
+        if (n > 5) {
+            int done = 0;
+            if (a.stream && n <= 65535) done = draw_subsets_stream(a.stream, n, hyps, sub, lane, &rng);
+            if (done < hyps) rng = draw_subsets(rng, n, hyps - done, sub + 5 * done, lane);
+        } else { hyps = 1; if (lane < 5) sub[lane] = lane; }          // npoints == model_points: one solve, all inliers
     }
     if (lane != 0) return;
     st->n = n; st->niters = niters;
@@ -204,7 +308,7 @@ __device__ void pnp_begin_item(const PnpBeginArgs &a, int n, int b, int lane)
 }
 __global__ __launch_bounds__(64) void pnp_begin_kernel(PnpArgs a)
 {
-    const PnpBeginArgs ba{a.state, a.counts, a.subsets, a.iterations, a.first_cap};
+    const PnpBeginArgs ba{a.state, a.counts, a.subsets, a.iterations, a.first_cap, a.stream};
     pnp_begin_item(ba, a.n_pts ? a.n_pts[blockIdx.x] : a.n_fixed, blockIdx.x, threadIdx.x);
 }
 
@@ -387,6 +491,24 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(PnpArgs a)
     if (active && good) atomicAdd(a.counts + (int64_t)b * kPhaseHyps + h, good);
 }
 
+// inclusive prefix maximum over the wave's lanes on the DPP network (row shifts, then the two row broadcasts)
+__device__ __forceinline__ int wave_incl_max(int v)
+{
+    const int lowest = (int)0x80000000;
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+// OpenCV's loop "for (iter = 0; iter < niters; iter++) { count inliers; if better than the best so far: keep, shrink niters }"
+// replayed over the phase's counts.  Only the hypotheses that BEAT every earlier one change anything (a handful in 500:
+// the running maximum is a prefix maximum, found by the 64 lanes together), and between two of them niters is constant,
+// so the replay is a walk over those few in order -- winner, stop and iteration count are the serial loop's.  (One lane
+// reading 500 counts one after the other was 62 us of the online pair in ORB mode.)
 __global__ __launch_bounds__(64) void pnp_select_kernel(PnpArgs a)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -395,32 +517,55 @@ __global__ __launch_bounds__(64) void pnp_select_kernel(PnpArgs a)
     int *counts = a.counts + (int64_t)b * kPhaseHyps;
     const int n = st->n, model_points = 5;
     const int hyps = st->phase_hyps;
-    if (lane == 0) {
+    {
         int niters = st->niters, max_good = st->max_good, best_iter = st->best_iter, iters_done = st->iters_done, owner = -1;
-        for (int h = 0; h < hyps; h++) {
-            const int it = a.phase_base + h;
-            if (it >= niters) break;
-            const int g = n == model_points ? n : counts[h];
-            iters_done = it + 1;
-            if (n == model_points || g > (max_good > model_points - 1 ? max_good : model_points - 1)) {
-                max_good = g; best_iter = it; owner = h;
-                if (n == model_points) { niters = it + 1; break; }
-                niters = ransac_update_iters_d(a.confidence, (double)(n - g) / n, model_points, niters);
+        if (n == model_points) {
+            // one hypothesis on exactly five points: all inliers, one iteration
+            if (a.phase_base < niters) { max_good = n; best_iter = a.phase_base; owner = 0; iters_done = a.phase_base + 1; niters = a.phase_base + 1; }
+        } else if (a.phase_base < niters) {
+            constexpr int kChunks = kPhaseHyps / 64;
+            int g[kChunks];
+#pragma unroll
+            for (int c = 0; c < kChunks; c++) g[c] = c * 64 + lane < hyps ? counts[c * 64 + lane] : (int)0x80000000;
+            int run_max = max_good > model_points - 1 ? max_good : model_points - 1;     // what a hypothesis has to beat
+            int last_event = -1;
+            bool stopped = false;
+#pragma unroll
+            for (int c = 0; c < kChunks; c++) {
+                if (stopped || c * 64 >= hyps) continue;
+                const int incl = wave_incl_max(g[c]);
+                int before = __builtin_amdgcn_update_dpp((int)0x80000000, incl, 0x138, 0xf, 0xf, false);   // wave_shr:1
+                before = max(before, run_max);
+                unsigned long long m = __ballot(g[c] > before);
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int it = a.phase_base + c * 64 + l;
+                    if (it >= niters) { stopped = true; break; }
+                    max_good = __builtin_amdgcn_readlane(g[c], l); best_iter = it; owner = c * 64 + l; last_event = it;
+                    niters = ransac_update_iters_d(a.confidence, (double)(n - max_good) / n, model_points, niters);
+                }
+                run_max = max(run_max, __builtin_amdgcn_readlane(incl, 63));
             }
+            // the last iteration the loop ran: up to the end of the phase or of niters, and at least the last better model's
+            const int upto = a.phase_base + hyps < niters ? a.phase_base + hyps : niters;
+            iters_done = upto > last_event + 1 ? upto : last_event + 1;
         }
-        if (owner >= 0) {
-            const PnpHyp *H = a.hyp + (int64_t)b * kPhaseHyps + owner;
-            for (int i = 0; i < 9; i++) st->bestRt[i] = H->R[i];
-            for (int i = 0; i < 3; i++) st->bestRt[9 + i] = H->t[i];
+        if (lane == 0) {
+            if (owner >= 0) {
+                const PnpHyp *H = a.hyp + (int64_t)b * kPhaseHyps + owner;
+                for (int i = 0; i < 9; i++) st->bestRt[i] = H->R[i];
+                for (int i = 0; i < 3; i++) st->bestRt[9 + i] = H->t[i];
+            }
+            st->niters = niters; st->max_good = max_good; st->best_iter = best_iter; st->iters_done = iters_done;
+            // the next phase, if the rule still wants hypotheses beyond this one (its subsets were drawn
+            // beside this phase's EPnP blocks)
+            const int next = a.phase_base + a.phase_cap;
+            int more = 0;
+            if (next < niters && n > model_points) more = niters - next < kPhaseHyps ? niters - next : kPhaseHyps;
+            st->phase_hyps = more;
+            st->next_base = more > 0 ? next : -1;
         }
-        st->niters = niters; st->max_good = max_good; st->best_iter = best_iter; st->iters_done = iters_done;
-        // the next phase, if the rule still wants hypotheses beyond this one (its subsets were drawn
-        // beside this phase's EPnP blocks)
-        const int next = a.phase_base + a.phase_cap;
-        int more = 0;
-        if (next < niters && n > model_points) more = niters - next < kPhaseHyps ? niters - next : kPhaseHyps;
-        st->phase_hyps = more;
-        st->next_base = more > 0 ? next : -1;
     }
     __syncthreads();
     for (int i = lane; i < kPhaseHyps; i += 64) counts[i] = 0;          // ready for the next phase's atomics
@@ -780,7 +925,7 @@ int stage_chain_relative(svo_ctx *ctx, const double *T, const int32_t *ok, int n
 // ------------------------------------------------------------------------------------------
 // workspace layout inside ctx->pnp_ws (n = max_batch items):
 //   [PnpRecord x n][mask bytes x n*cap][PnpState x n][PnpHyp x n*448][counts x n*448][subsets x n*2*448*5]
-//   [EPnP hand-over records x n*7*105*64 doubles]
+//   [EPnP hand-over records x n*7*105*64 doubles][cv::RNG(-1) states x kRngStream]
 static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 static size_t ws_off_mask(int n_items) { return al256(sizeof(PnpRecord) * (size_t)n_items); }
 static size_t ws_off_state(const svo_config &cfg, int n_items) { return al256(ws_off_mask(n_items) + (size_t)n_items * cfg.max_keypoints); }
@@ -788,7 +933,8 @@ static size_t ws_off_hyp(const svo_config &cfg, int n_items) { return al256(ws_o
 static size_t ws_off_counts(const svo_config &cfg, int n_items) { return al256(ws_off_hyp(cfg, n_items) + sizeof(PnpHyp) * (size_t)n_items * kPhaseHyps); }
 static size_t ws_off_subsets(const svo_config &cfg, int n_items) { return al256(ws_off_counts(cfg, n_items) + sizeof(int) * (size_t)n_items * kPhaseHyps); }
 static size_t ws_off_hand(const svo_config &cfg, int n_items) { return al256(ws_off_subsets(cfg, n_items) + sizeof(int) * 2 * 5 * (size_t)n_items * kPhaseHyps); }
-static size_t ws_end(const svo_config &cfg, int n_items) { return al256(ws_off_hand(cfg, n_items) + sizeof(double) * (size_t)n_items * kPhaseBlocks * kEpnpHandDoubles * 64); }
+static size_t ws_off_stream(const svo_config &cfg, int n_items) { return al256(ws_off_hand(cfg, n_items) + sizeof(double) * (size_t)n_items * kPhaseBlocks * kEpnpHandDoubles * 64); }
+static size_t ws_end(const svo_config &cfg, int n_items) { return al256(ws_off_stream(cfg, n_items) + sizeof(uint64_t) * kRngStream); }
 
 // RANSAC inlier flags of batch item 0 (the online pair): max_keypoints bytes
 const uint8_t *pnp_inlier_mask(const svo_ctx *ctx) { return (const uint8_t *)ctx->pnp_ws + ws_off_mask(ctx->cfg.max_batch); }
@@ -806,6 +952,18 @@ int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
     return SVO_OK;
 }
 
+// the generator states every solve starts with (cv::RNG(-1): state = (uint32)state * 4164903690 + (state >> 32)), once per context
+int geom_workspace_init(svo_ctx *ctx)
+{
+    std::vector<uint64_t> st(kRngStream);
+    uint64_t x = ~0ull;
+    for (int i = 0; i < kRngStream; i++) { x = (uint64_t)(uint32_t)x * 4164903690u + (uint32_t)(x >> 32); st[i] = x; }
+    if (hipMemcpy((char *)ctx->pnp_ws + ws_off_stream(ctx->cfg, ctx->cfg.max_batch), st.data(), sizeof(uint64_t) * kRngStream,
+                  hipMemcpyHostToDevice) != hipSuccess)
+        return SVO_ERR_HIP;
+    return SVO_OK;
+}
+
 // The launch sequence of one solvePnPRansac for n_items items (see the kernel comments above).
 // max_pts bounds the points of any item (grid.z of the scoring kernel).
 static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pts, hipStream_t st, bool begun = false)
@@ -819,6 +977,7 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
     a.counts = (int *)(ws + ws_off_counts(cfg, B));
     a.subsets = (int *)(ws + ws_off_subsets(cfg, B));
     a.hand = (double *)(ws + ws_off_hand(cfg, B));
+    a.stream = (const uint64_t *)(ws + ws_off_stream(cfg, B));
     if (!begun) hipLaunchKernelGGL(pnp_begin_kernel, dim3(n_items), dim3(64), 0, st, a);
     const int niters = a.iterations > 1 ? a.iterations : 1;
     // 1024 points per scoring workgroup; a launch that leaves the chip mostly empty (the online path) takes
@@ -864,6 +1023,7 @@ void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const floa
     a.begin.subsets = (int *)(ws + ws_off_subsets(ctx->cfg, B));
     a.begin.iterations = ctx->cfg.iterations;
     a.begin.first_cap = pnp_first_cap(ctx->cfg);
+    a.begin.stream = (const uint64_t *)(ws + ws_off_stream(ctx->cfg, B));
     hipLaunchKernelGGL(triangulate_kernel, dim3(gx + 1, n_items), dim3(64), 0, ctx->stream, a);
 }
 

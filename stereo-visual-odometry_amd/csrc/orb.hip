@@ -883,11 +883,11 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
 // to the first one that reaches N are exactly those the serial loop performs.
 // So a WORKGROUP OF FOUR WAVES owns an (image, level) -- a lone wave issues one instruction every ~5 cycles whatever
 // it does, and the tree is ~10^5 instructions -- and a pass is
-//   (1) the 4-way partition of every processed node's keys, which also counts them per quadrant: ONE THREAD PER NODE
-//       for nodes of <= kQtSmall keys (the usual case from the third pass on: a level-0 tree has ~250 of them with a
-//       handful of keys each, and the serial kernel spent ~3 k cycles of dependent instructions on each), eight LDS
-//       accesses in flight per thread; a wave together, in registers and in place, on a larger node (consecutive
-//       nodes go to different waves: the first passes have 4 and 16 nodes);
+//   (1) the 4-way partition of every processed node's keys, which also counts them per quadrant, A LANE PER KEY: nodes
+//       of <= 8 / 16 / 32 / 64 keys share a wave's lanes 8 / 4 / 2 / 1 at a time (the usual case from the third pass on:
+//       a level-0 tree has ~250 nodes with a handful of keys each, and the serial kernel spent ~3 k cycles of dependent
+//       instructions on each), ranks from four ballots masked to the node's lanes, in place; a wave together, in
+//       registers and in place, on a larger node; the work items go round the four waves, the longest first;
 //   (2) prefix sums over the processing order (workgroup scans through the LDS): children created before each node,
 //       the cut-off (rounds of 256 nodes after the one that holds the cut-off are not even partitioned);
 //   (3) the new list, written beside the old one (two node tables): children's creation numbers in creation order
@@ -898,9 +898,13 @@ __global__ __launch_bounds__(64) void orb_distribute_kernel(OrbDistArgs a)
 // does not depend on their order.  Output and tie-breaks are those of orb_distribute_kernel (same keypoints byte
 // for byte: the parity tests compare every image's), which stays for configurations whose node tables do not
 // fit the LDS (and behind SVO_ORB_QT_SERIAL=1, to time one against the other).
-constexpr int kQtSmall = 32;
-constexpr int kQpThreads = 256;
-constexpr int kQpScanBuf = 260;             // ints per scan buffer: 256 values, the total, padding to 16 bytes
+#ifndef SVO_QP_WAVES
+#define SVO_QP_WAVES 8
+#endif
+constexpr int kQpWaves = SVO_QP_WAVES;
+constexpr int kQpThreads = 64 * kQpWaves;
+constexpr int kQpScanBuf = 8;               // ints per scan buffer: one total per wave
+static_assert(kQpWaves <= 8 && kQpThreads <= 1023, "scan buffers and the packed 10-bit class counters");
 struct QpNode { short ulx, uly, brx, bry; unsigned short beg, cnt, seq, pad; };      // 16 bytes
 struct QpLds {
     KeyArr keys;                            // kLdsKeys
@@ -913,7 +917,6 @@ struct QpLds {
     unsigned short *divided;                // per list position: 1 if divided in this pass
     int *sbuf;                              // two scan buffers
     int *sh;                                // a few workgroup-wide scalars
-    KeyArr tmp; int tmp_cap;                // scratch keys of the one-thread partitions: the memory of nxt and xa, dead then
 };
 __host__ __device__ inline size_t qplds_bytes(int node_cap)
 {
@@ -934,7 +937,6 @@ __device__ inline QpLds qplds_carve(uint8_t *smem, int node_cap)
     L.kpre = (unsigned short *)smem; smem += (size_t)node_cap * 2;
     L.divided = (unsigned short *)smem; smem += (size_t)node_cap * 2;
     L.resp = smem;
-    L.tmp.xy = (uint32_t *)L.nxt; L.tmp.id = (uint16_t *)L.xa; L.tmp_cap = 4 * node_cap;   // 16 + 8 bytes per node = 4 keys of 4 + 2
     return L;
 }
 
@@ -950,24 +952,23 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
     return v;
 }
-// exclusive prefix sum over the workgroup's 256 threads taken in the order `o` (a permutation of 0..255); every thread
-// gets the total.  Consecutive calls must alternate between the two buffers (a thread may still be reading the
-// previous call's result when another starts the next).
-__device__ __forceinline__ int blk_excl_scan(int v, int o, int *buf, int tid, int &total)
+// exclusive prefix sum over the workgroup's threads in thread order; every thread gets the total.  Each wave scans its own
+// lanes on the DPP network and only the wave totals go through the LDS: one barrier.  Consecutive calls must alternate
+// between the two buffers (a thread may still be reading the previous call's totals when another starts the next).
+__device__ __forceinline__ int blk_excl_scan(int v, int *buf, int lane, int wv, int &total)
 {
-    buf[o] = v;
+    const int incl = wave_incl_scan(v);
+    if (lane == 63) buf[wv] = incl;
     __syncthreads();
-    if (tid < 64) {
-        const int4 q = *(const int4 *)(buf + 4 * tid);
-        const int s = q.x + q.y + q.z + q.w;
-        const int incl = wave_incl_scan(s);
-        const int ex = incl - s;
-        *(int4 *)(buf + 4 * tid) = make_int4(ex, ex + q.x, ex + q.x + q.y, ex + q.x + q.y + q.z);
-        if (tid == 63) buf[256] = incl;
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kQpWaves; w++) {
+        const int t = buf[w];
+        all += t;
+        if (w < wv) before += t;
     }
-    __syncthreads();
-    total = rfl(buf[256]);
-    return buf[o];
+    total = rfl(all);
+    return before + incl - v;
 }
 
 // a wave together on one node: stable 4-way partition in place (keys held in registers between the reads and the
@@ -1034,7 +1035,7 @@ __device__ inline void qp_partition(const KeyArr keys, const KeyArr gscratch, in
 #define QT_AT(i)
 #endif
 
-__global__ __launch_bounds__(kQpThreads) void orb_distribute_par_kernel(OrbDistArgs a)
+__global__ __launch_bounds__(kQpThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void orb_distribute_par_kernel(OrbDistArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t qp_smem[];
     QpLds L = qplds_carve(qp_smem, a.node_cap);
@@ -1061,10 +1062,10 @@ __global__ __launch_bounds__(kQpThreads) void orb_distribute_par_kernel(OrbDistA
     auto wfence = [&]() { if (keys_global) __threadfence(); wave_lds_fence(); };
     auto sync = [&]() { if (keys_global) __threadfence(); __syncthreads(); };
     int sbsel = 0;
-    auto scan = [&](int v, int o, int &total) -> int {
+    auto scan = [&](int v, int &total) -> int {
         int *bf = L.sbuf + kQpScanBuf * sbsel;
         sbsel ^= 1;
-        return blk_excl_scan(v, o, bf, tid, total);
+        return blk_excl_scan(v, bf, lane, wv, total);
     };
     bool overflow = false;
 #ifdef SVO_QT_STAMP
@@ -1072,14 +1073,14 @@ __global__ __launch_bounds__(kQpThreads) void orb_distribute_par_kernel(OrbDistA
     QT_AT(11) qt_acc[11] = 0;
 #endif
 
-    // ---- root nodes: stable binning of the candidates by column strip.  Each wave takes a quarter of the candidate list;
-    // lane i keeps strip i's count in that quarter, then its fill position; two sweeps over the list (global memory,
+    // ---- root nodes: stable binning of the candidates by column strip.  Each wave takes its part of the candidate list;
+    // lane i keeps strip i's count in that part, then its fill position; two sweeps over the list (global memory,
     // eight loads in flight).  Empty roots are dropped, their creation numbers are not.
     const int nroot = min(min(nIni, 64), cap);
     int n = 0, seq = 0;
     {
-        const int quarter = ((nkeys + 255) / 256) * 64;
-        const int kbeg = wv * quarter, kend = min(nkeys, kbeg + quarter);
+        const int part = ((nkeys + kQpThreads - 1) / kQpThreads) * 64;
+        const int kbeg = min(nkeys, wv * part), kend = min(nkeys, kbeg + part);
         int mine_cnt = 0, fill = 0;
         auto strip_of = [&](float x) { return min((int)(x / hX), nIni - 1); };
         auto count_chunk = [&](bool valid, int s) {
@@ -1099,8 +1100,8 @@ __global__ __launch_bounds__(kQpThreads) void orb_distribute_par_kernel(OrbDistA
             if (valid && s < nroot) keys.set(dst, make_uint2((uint32_t)(int)c.x | ((uint32_t)(int)c.y << 16), (uint32_t)k));
             if (valid && !keys_global) L.resp[k] = (uint8_t)(int)c.z;
         };
-        // a quarter that fits the LDS key arrays is read once and held in registers between the two sweeps
-        constexpr int kRootChunks = (kLdsKeys + 255) / 256;
+        // a wave's part of a list that fits the LDS key arrays is read once and held in registers between the two sweeps
+        constexpr int kRootChunks = (kLdsKeys + kQpThreads - 1) / kQpThreads;
         float4 held[kRootChunks];
         int held_s[kRootChunks];
         if (!keys_global) {
@@ -1121,13 +1122,20 @@ __global__ __launch_bounds__(kQpThreads) void orb_distribute_par_kernel(OrbDistA
                     if (base + 64 * u < kend) count_chunk(base + 64 * u + lane < kend, strip_of(cx[u]));
             }
         }
-        int *rc = L.sbuf;                                                   // [4 waves][64 strips]
+        // [waves][64 strips], 2 KB at most: the second node table, the expansion list and the quadrant counts lie one after
+        // the other (qplds_carve) and nothing has been written to them yet -- 32 bytes per node, node_cap >= 64
+        int *rc = (int *)L.nxt;
         rc[wv * 64 + lane] = mine_cnt;
         __syncthreads();
-        const int t0 = rc[lane], t1 = rc[64 + lane], t2 = rc[128 + lane], t3 = rc[192 + lane];
-        const int tot = t0 + t1 + t2 + t3;
+        int tot = 0, mine_before = 0;
+#pragma unroll
+        for (int w = 0; w < kQpWaves; w++) {
+            const int t = rc[w * 64 + lane];
+            tot += t;
+            if (w < wv) mine_before += t;
+        }
         const int start = wave_incl_scan(tot) - tot;
-        fill = start + (wv > 0 ? t0 : 0) + (wv > 1 ? t1 : 0) + (wv > 2 ? t2 : 0);
+        fill = start + mine_before;
         if (!keys_global) {
 #pragma unroll
             for (int u = 0; u < kRootChunks; u++)
@@ -1162,69 +1170,73 @@ __global__ __launch_bounds__(kQpThreads) void orb_distribute_par_kernel(OrbDistA
         // (1) partition + keys per quadrant, (2) children before each processed node and the cut-off
         int carry = 0, ndiv = np, total_kids = 0;
         bool found = false;
-        const KeyArr tmp = L.tmp;
-        const int o = lane * 4 + wv;                                        // consecutive nodes on different waves
+        // [5 classes][min(threads, node_cap)] thread numbers of a round's nodes, in the table that is not the list (dead here; a
+        // round has at most node_cap nodes, so the five lists of 16-bit entries fit its 16 bytes per node)
+        unsigned short *lst = (unsigned short *)L.nxt;
+        const int lstride = min(kQpThreads, cap);
         for (int r0 = 0; r0 < np && !found; r0 += kQpThreads) {
-            const int r = r0 + o;
+            const int r = r0 + tid;
             const bool act = r < np;
-            int beg = 0, cnt = 0, midx = 0, midy = 0;
-            if (act) {
-                const QpNode nd = L.cur[L.proc[r]];
-                beg = nd.beg; cnt = nd.cnt;
-                midx = nd.ulx + ((nd.brx - nd.ulx + 1) >> 1); midy = nd.uly + ((nd.bry - nd.uly + 1) >> 1);   // ceil(d / 2)
-            }
+            const int mycnt = act ? (int)L.cur[L.proc[r]].cnt : 0;
             if (tid == 0) L.sh[0] = 0x7FFFFFFF;
-            const bool maybe_small = act && cnt <= kQtSmall;
-            int ttot;
-            const int toff = scan(maybe_small ? cnt : 0, o, ttot);
-            const bool small_one = maybe_small && toff + cnt <= L.tmp_cap;
-            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            if (small_one) {
-                for (int k0 = 0; k0 < cnt; k0 += 8) {                       // copy to the scratch, counting
-                    uint2 kk[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) kk[u] = keys.get(beg + min(k0 + u, cnt - 1));
-#pragma unroll
-                    for (int u = 0; u < 8; u++)
-                        if (k0 + u < cnt) {
-                            const int q = key_quadrant(kk[u], midx, midy);
-                            c0 += q == 0; c1 += q == 1; c2 += q == 2; c3 += q == 3;
-                            tmp.set(toff + k0 + u, kk[u]);
-                        }
-                }
-                int o0 = beg, o1 = beg + c0, o2 = o1 + c1, o3 = o2 + c2;
-                for (int k0 = 0; k0 < cnt; k0 += 8) {                       // back, each key to its quadrant's range
-                    uint2 kk[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) kk[u] = tmp.get(toff + min(k0 + u, cnt - 1));
-#pragma unroll
-                    for (int u = 0; u < 8; u++)
-                        if (k0 + u < cnt) {
-                            const int q = key_quadrant(kk[u], midx, midy);
-                            int od;
-                            if (q == 0) od = o0++; else if (q == 1) od = o1++; else if (q == 2) od = o2++; else od = o3++;
-                            keys.set(od, kk[u]);
-                        }
-                }
-            }
+            // the round's nodes by size class: <= 8, 16, 32, 64 keys share a wave's 64 lanes (8, 4, 2, 1 nodes at a time,
+            // a lane per key); larger ones take a wave each.  Two scans of packed 10-bit counters give the class lists.
+            const int cls = mycnt <= 8 ? 0 : mycnt <= 16 ? 1 : mycnt <= 32 ? 2 : mycnt <= 64 ? 3 : 4;
+            int totA, totB;
+            const int pa = scan(act && cls < 3 ? 1 << (10 * cls) : 0, totA);
+            const int pb = scan(act && cls >= 3 ? 1 << (10 * (cls - 3)) : 0, totB);
+            if (act) lst[cls * lstride + (cls < 3 ? (pa >> (10 * cls)) & 1023 : (pb >> (10 * (cls - 3))) & 1023)] = (unsigned short)tid;
+            const int nc0 = totA & 1023, nc1 = (totA >> 10) & 1023, nc2 = totA >> 20, nc3 = totB & 1023, nhuge = totB >> 10;
+            __syncthreads();
             QT_AT(1)
-            unsigned long long big = __ballot(act && !small_one);
-            while (big) {                                                   // this wave together on a larger node of its own
-                const int src = __ffsll((long long)big) - 1;
-                big &= big - 1;
-                int c[4];
-                qp_partition(keys, gt, __builtin_amdgcn_readlane(beg, src), __builtin_amdgcn_readlane(cnt, src),
-                             __builtin_amdgcn_readlane(midx, src), __builtin_amdgcn_readlane(midy, src), c, lane, wfence);
-                if (lane == src) { c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; }
+            // work items, the longest first: a large node each, then chunks of 1, 2, 4, 8 nodes; round-robin over the waves
+            const int g3 = nhuge + nc3, g2 = g3 + ((nc2 + 1) >> 1), g1 = g2 + ((nc1 + 3) >> 2), g0 = g1 + ((nc0 + 7) >> 3);
+            for (int g = wv; g < g0; g += kQpWaves) {
+                if (g < nhuge) {
+                    const int r2 = r0 + rfl((int)lst[4 * lstride + g]);
+                    const QpNode nd = L.cur[rfl((int)L.proc[r2])];
+                    const int ulx = rfl(nd.ulx), uly = rfl(nd.uly), brx = rfl(nd.brx), bry = rfl(nd.bry);
+                    int c[4];
+                    qp_partition(keys, gt, rfl(nd.beg), rfl(nd.cnt), ulx + ((brx - ulx + 1) >> 1), uly + ((bry - uly + 1) >> 1), c, lane, wfence);
+                    if (lane == 0) *(uint2 *)(L.qc + 4 * r2) = make_uint2((uint32_t)c[0] | ((uint32_t)c[1] << 16), (uint32_t)c[2] | ((uint32_t)c[3] << 16));
+                    continue;
+                }
+                const int c = g < g3 ? 3 : g < g2 ? 2 : g < g1 ? 1 : 0;
+                const int ch = g - (c == 3 ? nhuge : c == 2 ? g3 : c == 1 ? g2 : g1), ncl = c == 3 ? nc3 : c == 2 ? nc2 : c == 1 ? nc1 : nc0;
+                const int sh = 3 + c, S = 1 << sh;
+                const int slot = lane >> sh, k = lane & (S - 1);
+                const int idx = (ch << (3 - c)) + slot;
+                const bool has = idx < ncl;
+                int r2 = 0, beg = 0, cn = 0, midx = 0, midy = 0;
+                if (has) {
+                    r2 = r0 + lst[c * lstride + idx];
+                    const QpNode nd = L.cur[L.proc[r2]];
+                    beg = nd.beg; cn = nd.cnt;
+                    midx = nd.ulx + ((nd.brx - nd.ulx + 1) >> 1); midy = nd.uly + ((nd.bry - nd.uly + 1) >> 1);   // ceil(d / 2)
+                }
+                const bool valid = has && k < cn;
+                const uint2 key = valid ? keys.get(beg + k) : make_uint2(0, 0);
+                const int q = key_quadrant(key, midx, midy);
+                const unsigned long long m0 = __ballot(valid && q == 0), m1 = __ballot(valid && q == 1),
+                                         m2 = __ballot(valid && q == 2), m3 = __ballot(valid && q == 3);
+                const unsigned long long seg = c == 3 ? ~0ull : (((1ull << S) - 1ull) << (slot << sh));    // the lanes of this node
+                const int n0 = __popcll(m0 & seg), n1 = __popcll(m1 & seg), n2 = __popcll(m2 & seg), n3 = __popcll(m3 & seg);
+                const unsigned long long mq = q == 0 ? m0 : q == 1 ? m1 : q == 2 ? m2 : m3;
+                const int rank = __popcll(mq & seg & lt);                   // stable: keys of the same quadrant before this one
+                const int off = q == 0 ? 0 : q == 1 ? n0 : q == 2 ? n0 + n1 : n0 + n1 + n2;
+                if (valid) keys.set(beg + off + rank, key);                 // (in place: the wave has read every key of the chunk by now)
+                if (has && k == 0) *(uint2 *)(L.qc + 4 * r2) = make_uint2((uint32_t)n0 | ((uint32_t)n1 << 16), (uint32_t)n2 | ((uint32_t)n3 << 16));
             }
+            sync();
             QT_AT(2)
-            const int kids = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
-            int ktot;
-            const int pre = carry + scan(kids, o, ktot);
+            int kids = 0;
             if (act) {
-                *(uint2 *)(L.qc + 4 * r) = make_uint2((uint32_t)c0 | ((uint32_t)c1 << 16), (uint32_t)c2 | ((uint32_t)c3 << 16));
-                L.kpre[r] = (unsigned short)pre;
+                const uint2 qv = *(const uint2 *)(L.qc + 4 * r);
+                kids = ((qv.x & 0xFFFFu) != 0) + ((qv.x >> 16) != 0) + ((qv.y & 0xFFFFu) != 0) + ((qv.y >> 16) != 0);
             }
+            int ktot;
+            const int pre = carry + scan(kids, ktot);
+            if (act) L.kpre[r] = (unsigned short)pre;
             carry += ktot;
             total_kids = carry;
             if (limitN > 0) {
@@ -1274,7 +1286,7 @@ __global__ __launch_bounds__(kQpThreads) void orb_distribute_par_kernel(OrbDistA
             }
             // nodes to expand next, in creation order (the sort of the last phase is by (count, creation number))
             int xtot;
-            const int xpos = xcarry + scan(nx, tid, xtot);
+            const int xpos = xcarry + scan(nx, xtot);
             xcarry += xtot;
             if (act && nx) {
                 int before = 0, w = 0;
@@ -1299,13 +1311,12 @@ __global__ __launch_bounds__(kQpThreads) void orb_distribute_par_kernel(OrbDistA
             const int i = i0 + tid;
             const bool und = i < n && L.divided[i] == 0;
             int utot;
-            const int rank = ucarry + scan(und ? 1 : 0, tid, utot);
+            const int rank = ucarry + scan(und ? 1 : 0, utot);
             ucarry += utot;
             if (und) L.nxt[total_kids + rank] = L.cur[i];
         }
         sync();
         QpNode *sw = L.cur; L.cur = L.nxt; L.nxt = sw;
-        L.tmp.xy = (uint32_t *)L.nxt;                   // (the scratch keys follow the table that is not the list)
         n = n_new; seq += total_kids; n_exp = xcarry;
         QT_AT(5)
 #ifdef SVO_QT_STAMP
@@ -1323,7 +1334,7 @@ __global__ __launch_bounds__(kQpThreads) void orb_distribute_par_kernel(OrbDistA
             const int i = i0 + tid;
             const bool ex = i < n && L.cur[i].cnt > 1;
             int ptot;
-            const int r = np + scan(ex ? 1 : 0, tid, ptot);
+            const int r = np + scan(ex ? 1 : 0, ptot);
             np += ptot;
             if (ex) L.proc[r] = (unsigned short)i;
         }

@@ -13,6 +13,7 @@ using namespace svo;
 namespace svo {
 // geometry.hip / pipeline.hip
 int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes);
+int geom_workspace_init(svo_ctx *ctx);
 int stage_triangulate(svo_ctx *ctx, const double P1[12], const double P2[12], const svo_pt2f *x1,
                       const svo_pt2f *x2, int n, svo_pt3f *out, int mem);
 int stage_pnp_ransac(svo_ctx *ctx, const svo_pt3f *obj, const svo_pt2f *img, int n, const double K[9],
@@ -184,6 +185,7 @@ extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
     CK(hipMalloc(&ctx->X3, sizeof(float) * 3 * (size_t)cap * B));
     if (geom_workspace_bytes(*cfg, B, &ctx->pnp_ws_bytes) != SVO_OK) return fail(SVO_ERR_ARG);
     CK(hipMalloc(&ctx->pnp_ws, ctx->pnp_ws_bytes));
+    if (geom_workspace_init(ctx) != SVO_OK) return fail(SVO_ERR_HIP);
     CK(hipMalloc(&ctx->d_results, sizeof(svo_step_result) * (size_t)B));
     CK(hipMalloc(&ctx->bslots, (size_t)2 * n_img * ctx->geom.slot_bytes));
     CK(hipMalloc(&ctx->kp_n_snap, sizeof(int) * (size_t)(3 * n_img)));

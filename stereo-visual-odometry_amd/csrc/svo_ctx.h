@@ -108,6 +108,7 @@ struct svo_ctx {
 namespace svo {
 // geometry.hip
 int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes);
+int geom_workspace_init(svo_ctx *ctx);
 void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const float2 *x1, const float2 *x2,
                               const int *n_pts, int n_fixed);
 void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n_pts, int n_fixed, hipStream_t st);
