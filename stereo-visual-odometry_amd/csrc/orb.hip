@@ -148,11 +148,13 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(OrbGeom g, uint8_t *slo
 
 // ---- per-cell FAST ---------------------------------------------------------------------------
 constexpr int kCellMax = 66;                 // wCell = ceil(width / floor(width / 30)) < 60, +6 overlap
-constexpr int kCellPitch = 72;               // LDS row pitch of a cell: kCellPitch + 3 bytes of dword-alignment slack, multiple of 4
+constexpr int kCellGroup = 4;                // cells of a cell row per workgroup, at most
+constexpr int kCellPitch = 136;              // LDS row pitch of a workgroup's window: up to 4 cells of 31 + 6 overlap + 3 bytes of dword-alignment slack, multiple of 4
 constexpr int kCellCap = 256;                // candidates kept per cell
-// threads per cell (measured: 64 -> 3.53 ms per 256 pairs, 128 -> 2.86, 256 -> 2.76: the loops' nearly empty last
-// passes cost less than the occupancy smaller workgroups lose)
+// threads per workgroup (measured with one cell per workgroup: 64 -> 3.53 ms per 256 pairs, 128 -> 2.86, 256 -> 2.76: the
+// loops' nearly empty last passes cost less than the occupancy smaller workgroups lose)
 constexpr int kCellThreads = 256;
+static_assert(kCellPitch * kCellMax < (1 << 14), "a window position and a 2-bit cell number share 16 bits");
 
 // FAST cornerness V = largest t for which the pixel is a FAST-9/16 corner (0 when < 1):
 // corner at threshold t <=> V >= t, and cornerScore == V.
@@ -182,50 +184,66 @@ __device__ __forceinline__ int fast_cornerness(const uint8_t *c, int P)
     return V > 0 ? V : 0;
 }
 
-// One workgroup per cell; one-dimensional grid of cells_total x n_img blocks, image by XCD (xcd_image_block).
+// One workgroup per GROUP of up to four consecutive cells of a cell row; one-dimensional grid of blks_total x n_img
+// blocks, image by XCD (xcd_image_block).  The reference runs FAST on every cell's own window (the cell + 3 pixels on
+// each side), so neighbouring windows overlap by 6 pixels and every window is a separate little image: its corners lie
+// 3 pixels inside it and its non-maximum suppression sees nothing outside those.  The windows of a group are taken as ONE
+// window -- the test and the cornerness of a pixel do not depend on the window it is seen from -- in which a pixel
+// belongs to the cell whose interior holds it, and the suppression ignores neighbours that belong to another cell.
+// Per cell the fixed work (staging, barriers, list bookkeeping, nearly empty last passes of the loops) is a quarter
+// of the one-cell-per-workgroup kernel's, and the overlap columns are tested once instead of twice.
 __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, const uint8_t *slots, int64_t slot_stride,
                                                            int iniTh, int minTh, float4 *cell_cand, int *cell_cnt,
                                                            int64_t cand_img_stride, int64_t cnt_img_stride, int n_img)
 {
-    int b, cell_all;                                                      // image, cell index over all levels
-    xcd_image_block(blockIdx.x, g.cells_total, n_img, b, cell_all);
-    const int l = level_of_block(g.cell_off, g.nlevels, cell_all);
-    // dynamic LDS: two byte planes (pixels, cornerness) + the position lists (three planes' worth), kCellMax
-    // columns x (hCell + 6) rows of THIS level (a static 66 x 66 worst case would cost 21.8 KB and starve the
-    // kernel of workgroups while the previous batch's pose solver holds most of the CU's LDS)
+    int b, blk_all;                                                       // image, workgroup index over all levels
+    xcd_image_block(blockIdx.x, g.blks_total, n_img, b, blk_all);
+    const int l = level_of_block(g.blk_off, g.nlevels, blk_all);
+    // dynamic LDS: two byte planes (pixels, cornerness) + the position lists (three planes' worth), kCellPitch
+    // columns x (hCell + 6) rows of THIS level
     extern __shared__ __attribute__((aligned(16))) uint8_t cf_smem[];
     const int plane = (kCellPitch * (g.hCell[l] + 6) + 15) & ~15;
     uint8_t *raw = cf_smem, *V = cf_smem + plane;
     uint16_t *list = (uint16_t *)(cf_smem + 2 * plane);      // survivors of the test, then candidates (compacted in place)
-    uint16_t *klist = list + plane;                          // keypoints after the NMS, in any order (at most a quarter of the
-                                                             // cell's pixels: a fifth plane of bytes holds plane / 2 of them)
-    __shared__ int s_any, s_nlist, s_ncand, s_nkept;
-    const int cell = cell_all - g.cell_off[l];
+    uint16_t *klist = list + plane;                          // keypoints after the NMS, in any order: position | cell << 14 (at most a
+                                                             // quarter of the window's pixels: a fifth plane of bytes holds plane / 2 of them)
+    __shared__ int s_any[kCellGroup], s_nkept[kCellGroup], s_nlist, s_ncand, s_nk;
+    const int blk = blk_all - g.blk_off[l];
     const int W = g.w[l], H = g.h[l], pitch = g.pitch[l];
     const int minBX = 16, minBY = 16, maxBX = W - 16, maxBY = H - 16;
-    const int nCols = g.nCols[l], wCell = g.wCell[l], hCell = g.hCell[l];
-    const int ci = cell / nCols, cj = cell - ci * nCols;
-    const float iniY = (float)(minBY + ci * hCell), iniX = (float)(minBX + cj * wCell);
-    float maxY = iniY + hCell + 6, maxX = iniX + wCell + 6;
-    int *cnt = cell_cnt + (int64_t)b * cnt_img_stride + g.cell_off[l] + cell;
+    const int nCols = g.nCols[l], wCell = g.wCell[l], hCell = g.hCell[l], gcols = g.gcols[l], G = g.gcell[l];
+    const int ci = blk / gcols, cg = blk - ci * gcols, cj0 = cg * G;
+    const int ngroup = min(G, nCols - cj0);                               // cells of this group
+    const float iniY = (float)(minBY + ci * hCell), iniX = (float)(minBX + cj0 * wCell);
+    float maxY = iniY + hCell + 6;
+    int *cnt = cell_cnt + (int64_t)b * cnt_img_stride + g.cell_off[l] + ci * nCols + cj0;
     const int tid = threadIdx.x;
-    bool skip = iniY >= maxBY - 3 || iniX >= maxBX - 6;
     if (maxY > maxBY) maxY = (float)maxBY;
-    if (maxX > maxBX) maxX = (float)maxBX;
-    const int x0 = (int)iniX, y0 = (int)iniY, cw = (int)maxX - x0, ch = (int)maxY - y0;
-    if (skip || cw < 7 || ch < 7) { if (tid == 0) *cnt = 0; return; }
+    const int x0 = (int)iniX, y0 = (int)iniY, ch = (int)maxY - y0;
+    // the cells that take part: not skipped by the reference (iniX >= maxBorderX - 6) and with a window of at least 7
+    // columns (FAST finds nothing in a narrower image); they are the first ncl of the group.  cw = width of their common window.
+    int ncl = 0, cw = 0;
+    for (int c = 0; c < ngroup; c++) {
+        const int ix = x0 + c * wCell;
+        const int wc = min(ix + wCell + 6, maxBX) - ix;
+        if (ix >= maxBX - 6 || wc < 7) break;
+        ncl = c + 1; cw = c * wCell + wc;
+    }
+    if (iniY >= maxBY - 3 || ch < 7 || ncl == 0) { if (tid < ngroup) cnt[tid] = 0; return; }
     // (row, column) of a linear index without an integer division (a runtime divisor costs ~25 vector
     // instructions): (i + 0.5) / n is never within 1e-3 of an integer for the i, n that occur here,
     // far above the float error, so truncating (i + 0.5) * (1 / n) is exact
     const int lowTh = min(iniTh, minTh);
     const uint8_t *img = slots + (int64_t)b * slot_stride + g.origin[l];
-    if (tid == 0) { s_any = 0; s_nlist = 0; s_ncand = 0; s_nkept = 0; }
+    if (tid < kCellGroup) { s_any[tid] = 0; s_nkept[tid] = 0; }
+    if (tid == 0) { s_nlist = 0; s_ncand = 0; s_nk = 0; }
     // V must read 0 wherever the NMS looks and no cornerness is computed.  The rows of the tested pixels are
     // zeroed by the test loop itself (one dword store beside its five reads); the row above and the row
     // below them here (a whole-plane clear cost five passes of the workgroup)
     uint32_t *Vd = (uint32_t *)V;                            // aligned dword view, like rawd
-    if (tid < 2 * (kCellPitch / 4)) Vd[(tid < kCellPitch / 4 ? 2 : ch - 3) * (kCellPitch / 4) + tid % (kCellPitch / 4)] = 0;
-    // the cell as aligned dwords (rows of the level are 4-byte aligned; the cell's first column
+    constexpr int RD = kCellPitch / 4;
+    if (tid < 2 * RD) Vd[(tid < RD ? 2 : ch - 3) * RD + tid % RD] = 0;
+    // the window as aligned dwords (rows of the level are 4-byte aligned; the window's first column
     // sits `ox` bytes into its first dword, so every LDS row is shifted by ox: rawc = raw + ox)
     const int ox = x0 & 3, nd = (ox + cw + 3) >> 2;
     const float inv_nd = 1.0f / (float)nd;
@@ -236,9 +254,11 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
             ((uint32_t *)(raw + y * kCellPitch))[c] = *(const uint32_t *)(src + (int64_t)y * pitch + 4 * c);
         }
     }
-    const uint32_t *rawd = (const uint32_t *)raw;           // aligned dword view, kCellPitch / 4 dwords per row
+    const uint32_t *rawd = (const uint32_t *)raw;           // aligned dword view, RD dwords per row
     raw += ox;
-    V += ox;                                                 // the same shift: position p of the cell is raw[p] and V[p]
+    V += ox;                                                 // the same shift: position p of the window is raw[p] and V[p]
+    // the cell of a window column (its interior is [3 + c wCell, 3 + (c + 1) wCell), the last one ends at cw - 3)
+    auto cell_of = [&](int x) { const int xi = x - 3; return (xi >= wCell) + (xi >= 2 * wCell) + (xi >= 3 * wCell); };
     __syncthreads();
     // Cornerness only matters where it can reach the threshold in force: a corner at threshold t needs one
     // pixel of each opposite pair (0,8), (4,12) beyond t, so positions failing that 4-pixel test at t keep
@@ -246,25 +266,24 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
     // The reference runs FAST at iniTh and, only if the cell stays empty, again at minTh.  Cornerness is
     // therefore computed in TWO PHASES: first for the survivors of the test at iniTh (on textured images
     // nearly every pixel survives the test at minTh = 7, and the arc min/max of every pixel was three
-    // quarters of this kernel); the pixels with iniTh > V >= minTh only matter when the cell has no
+    // quarters of this kernel); the pixels with iniTh > V >= minTh only matter when a cell has no
     // keypoint at iniTh (no corner, or strict NMS emptied it), and only then are they computed.
     // The test runs on FOUR pixels per thread (one aligned LDS dword of row y and its neighbours
     // three rows up / down and three columns left / right: five dword reads instead of twenty byte
     // reads), in packed 16-bit arithmetic on the even and the odd bytes:
     //   alive <=> max( min(v - min(p0,p8), v - min(p4,p12)),  min(max(p0,p8) - v, max(p4,p12) - v) ) > t
-    auto survivors_and_cornerness = [&](const int th) -> int {
+    auto survivors_and_cornerness = [&](const int th) {
         {
             typedef short s16x2 __attribute__((ext_vector_type(2)));
             const int rows = ch - 6, ngroups = nd * rows;
             const s16x2 T1 = {(short)(th + 1), (short)(th + 1)};
-            constexpr int RD = kCellPitch / 4;
             for (int i0 = 0; i0 < ngroups; i0 += kCellThreads) {
                 const int i = i0 + tid;
                 uint32_t m4 = 0;
                 int y = 0, xb = 0;
                 if (i < ngroups) {
                     const int yy = (int)(((float)i + 0.5f) * inv_nd), gq = i - yy * nd;
-                    y = yy + 3; xb = 4 * gq - ox;                            // cell x of the dword's first byte
+                    y = yy + 3; xb = 4 * gq - ox;                            // window x of the dword's first byte
                     const uint32_t *r = rawd + y * RD + gq;
                     const uint32_t C = r[0], U = r[-3 * RD], D = r[3 * RD], Lf = gq > 0 ? r[-1] : 0u, Rt = r[1];
                     Vd[y * RD + gq] = 0;                                     // (see the clear of the two outer rows above)
@@ -305,10 +324,9 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
             }
         }
         __syncthreads();
-        // cornerness of the survivors; the positions that reach minTh are compacted again IN PLACE (a
+        // cornerness of the survivors; the positions that reach the threshold are compacted again IN PLACE (a
         // write index never passes the block of kCellThreads entries being read), so the NMS passes below only
-        // visit possible keypoints instead of every pixel of the cell
-        int any = 0;
+        // visit possible keypoints instead of every pixel of the window
         const int nlist = s_nlist;
         for (int i0 = 0; i0 < nlist; i0 += kCellThreads) {
             const int i = i0 + tid;
@@ -317,7 +335,10 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
                 pos = list[i];
                 v = fast_cornerness(&raw[pos], kCellPitch);
                 V[pos] = (uint8_t)v;
-                any |= v >= iniTh;
+                if (v >= iniTh) {                                            // "FAST at iniTh finds something in this cell"
+                    const int y = (int)(((float)pos + 0.5f) * (1.0f / (float)kCellPitch));
+                    s_any[cell_of(pos - y * kCellPitch)] = 1;
+                }
             }
             __syncthreads();
             const bool cand = v >= th && v > 0;
@@ -330,19 +351,24 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
                 if (cand) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
             }
         }
-        return any;
     };
-    // phase 1 at the higher of the two thresholds the cell can end up with, phase 2 (all pixels that can
-    // reach the lower one) only when the first NMS pass leaves the cell empty
+    // phase 1 at the higher of the two thresholds a cell can end up with, phase 2 (all pixels that can
+    // reach the lower one) only when the first NMS pass leaves a cell empty
     const int th1 = iniTh > minTh ? iniTh : lowTh;
     int th_done = th1;
-    if (survivors_and_cornerness(th1)) s_any = 1;
+    survivors_and_cornerness(th1);
     __syncthreads();
     int ncand = s_ncand;
-    int thr = s_any ? iniTh : minTh;
+    int thr[kCellGroup];
+    bool open[kCellGroup];                                   // cells still without keypoints
+#pragma unroll
+    for (int c = 0; c < kCellGroup; c++) { thr[c] = s_any[c] ? iniTh : minTh; open[c] = c < ncl; }
     for (int pass = 0; pass < 2; pass++) {
-        if (thr < th_done) {
-            // the pixels with th_done > V >= thr are needed now: V of every survivor of the weaker test
+        int low = 0x7FFFFFFF;
+#pragma unroll
+        for (int c = 0; c < kCellGroup; c++) if (open[c]) low = min(low, thr[c]);
+        if (low < th_done) {
+            // the pixels with th_done > V >= minTh are needed now: V of every survivor of the weaker test
             // (those of phase 1 come out the same again), candidate list rebuilt
             __syncthreads();
             if (tid == 0) { s_nlist = 0; s_ncand = 0; }
@@ -352,19 +378,26 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
             __syncthreads();
             ncand = s_ncand;
         }
-        // strict 3x3 NMS over the candidates; the keypoints go to klist through one LDS atomic per wave and pass
+        // strict 3x3 NMS over the candidates of the open cells, among the pixels of the SAME cell; the keypoints go to
+        // klist through one LDS atomic per wave and pass
         for (int i0 = 0; i0 < ncand; i0 += kCellThreads) {
             const int i = i0 + tid;
-            int pos = 0;
+            int pos = 0, c = 0;
             bool k = false;
             if (i < ncand) {
                 pos = list[i];
                 const uint8_t *p = &V[pos];
                 const int s = p[0];
-                if (s >= thr) {
-#define SC(o) (p[o] >= thr ? (int)p[o] : 0)
-                    k = s > SC(-1) && s > SC(1) && s > SC(-kCellPitch - 1) && s > SC(-kCellPitch) && s > SC(-kCellPitch + 1) &&
-                        s > SC(kCellPitch - 1) && s > SC(kCellPitch) && s > SC(kCellPitch + 1);
+                const int y = (int)(((float)pos + 0.5f) * (1.0f / (float)kCellPitch)), x = pos - y * kCellPitch;
+                c = cell_of(x);
+                const int t = c == 0 ? thr[0] : c == 1 ? thr[1] : c == 2 ? thr[2] : thr[3];
+                const bool op = c == 0 ? open[0] : c == 1 ? open[1] : c == 2 ? open[2] : open[3];
+                if (op && s >= t) {
+                    const bool lok = x - 3 != c * wCell, rok = x - 3 != (c + 1) * wCell - 1;     // neighbours in the same cell
+#define SC(o) (p[o] >= t ? (int)p[o] : 0)
+                    k = s > SC(-kCellPitch) && s > SC(kCellPitch) &&
+                        (!lok || (s > SC(-1) && s > SC(-kCellPitch - 1) && s > SC(kCellPitch - 1))) &&
+                        (!rok || (s > SC(1) && s > SC(-kCellPitch + 1) && s > SC(kCellPitch + 1)));
 #undef SC
                 }
             }
@@ -372,33 +405,43 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
             if (m) {
                 const int lane = tid & 63;
                 int base = 0;
-                if (lane == 0) base = atomicAdd(&s_nkept, __popcll(m));
+                if (lane == 0) base = atomicAdd(&s_nk, __popcll(m));
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (k) klist[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+                if (k) { klist[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(pos | (c << 14)); atomicAdd(&s_nkept[c], 1); }
             }
         }
         __syncthreads();
         // "if (vKeysCell.empty()) FAST(..., minThFAST)": strict NMS can empty a cell whose corners tie
-        if (s_nkept > 0 || thr == minTh) break;
-        thr = minTh;
+        bool again = false;
+#pragma unroll
+        for (int c = 0; c < kCellGroup; c++) {
+            if (!open[c]) continue;
+            if (s_nkept[c] > 0 || thr[c] == minTh) open[c] = false;
+            else { thr[c] = minTh; again = true; }
+        }
+        if (!again) break;
     }
-    // ordered (row-major) emission: a cell keeps a handful of keypoints (positions y * pitch + x, so their
-    // numeric order IS the row-major order), and a keypoint's slot is the number of keypoints with a smaller
-    // position -- counted by its thread over the list (LDS broadcast reads) instead of scanning a keep plane
-    // of the whole cell (two passes of the workgroup with three ballots and three barriers each)
+    // ordered (row-major) emission: a cell keeps a handful of keypoints (entries cell << 14 | y * pitch + x, so their
+    // numeric order IS the cell order, then the row-major order), and a keypoint's slot is the number of keypoints with a
+    // smaller entry minus those of the cells before its own -- counted by its thread over the list (LDS broadcast reads)
     {
-        float4 *out = cell_cand + (int64_t)b * cand_img_stride + ((int64_t)g.cell_off[l] + cell) * kCellCap;
-        const int nk = s_nkept;
+        const int nk = s_nk;
+        int nkc[kCellGroup], before[kCellGroup];
+#pragma unroll
+        for (int c = 0, run = 0; c < kCellGroup; c++) { nkc[c] = s_nkept[c]; before[c] = run; run += nkc[c]; }
         for (int i = tid; i < nk; i += kCellThreads) {
-            const int pos = klist[i];
+            const int e = klist[i], c = e >> 14, pos = e & 0x3FFF;
             int rank = 0;
-            for (int j = 0; j < nk; j++) rank += klist[j] < pos;
+            for (int j = 0; j < nk; j++) rank += klist[j] < e;
+            rank -= c == 0 ? before[0] : c == 1 ? before[1] : c == 2 ? before[2] : before[3];
             if (rank < kCellCap) {
                 const int y = (int)(((float)pos + 0.5f) * (1.0f / (float)kCellPitch)), x = pos - y * kCellPitch;
-                out[rank] = make_float4((float)x + (float)(cj * wCell), (float)y + (float)(ci * hCell), (float)V[pos], 0.f);
+                float4 *out = cell_cand + (int64_t)b * cand_img_stride + ((int64_t)g.cell_off[l] + ci * nCols + cj0 + c) * kCellCap;
+                out[rank] = make_float4((float)(x - c * wCell) + (float)((cj0 + c) * wCell), (float)y + (float)(ci * hCell), (float)V[pos], 0.f);
             }
         }
-        if (tid == 0) *cnt = nk;             // may exceed kCellCap: flagged by orb_gather_kernel
+        // (a count may exceed kCellCap: flagged by orb_gather_kernel)
+        if (tid < ngroup) cnt[tid] = tid == 0 ? nkc[0] : tid == 1 ? nkc[1] : tid == 2 ? nkc[2] : nkc[3];
     }
 }
 
@@ -1915,7 +1958,7 @@ int orb_make_geom(const svo_config &cfg, OrbGeom *g)
         for (int i = 0; i < 7; i++) { float f = (float)(t[i] * s); g->gk[i] = (int)lrintf(f * 256.f); }
     }
     int64_t off = 0, boff = 0;
-    int coff = 0;
+    int coff = 0, boff_cells = 0;
     for (int l = 0; l < nlevels; l++) {
         g->w[l] = (int)lrintf((float)cfg.width * inv_scale[l]);
         g->h[l] = (int)lrintf((float)cfg.height * inv_scale[l]);
@@ -1937,12 +1980,18 @@ int orb_make_geom(const svo_config &cfg, OrbGeom *g)
             if (g->wCell[l] + 6 > kCellMax || g->hCell[l] + 6 > kCellMax) return SVO_ERR_ARG;
             g->ncell[l] = nCols * nRows;
             if (g->ncell[l] > 1024) return SVO_ERR_ARG;
+            int gc = (kCellPitch - 3 - 6) / g->wCell[l];                     // cells whose common window fits an LDS row
+            gc = gc < 1 ? 1 : gc > kCellGroup ? kCellGroup : gc;
+            g->gcell[l] = gc; g->gcols[l] = (nCols + gc - 1) / gc;
         }
+        g->blk_off[l] = boff_cells;
+        boff_cells += g->ncell[l] > 0 ? g->gcols[l] * g->nRows[l] : 0;
         coff += g->ncell[l];
     }
     g->slot_bytes = off;
     g->blur_total = boff;
     g->cells_total = coff;
+    g->blks_total = boff_cells;
     {
         int yb = 0;
         for (int l = 0; l < nlevels; l++) {
@@ -2111,8 +2160,8 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     {
         int hmax = 0;
         for (int l = 0; l < L; l++) if (g.ncell[l] > 0 && g.hCell[l] > hmax) hmax = g.hCell[l];
-        if (g.cells_total > 0)
-            hipLaunchKernelGGL(orb_cellfast_kernel, dim3(g.cells_total * n_img), dim3(kCellThreads), (size_t)5 * ((kCellPitch * (hmax + 6) + 15) & ~15), st,
+        if (g.blks_total > 0)
+            hipLaunchKernelGGL(orb_cellfast_kernel, dim3(g.blks_total * n_img), dim3(kCellThreads), (size_t)5 * ((kCellPitch * (hmax + 6) + 15) & ~15), st,
                                g, slots, g.slot_bytes, ctx->cfg.orb_ini_th, ctx->cfg.orb_min_th, cell_cand, cell_cnt,
                                (int64_t)g.cells_total * kCellCap, (int64_t)g.cells_total, n_img);
     }

@@ -34,6 +34,8 @@ struct OrbGeom {
     int gk[7];                           // integer 7-tap Gaussian, sigma 2, scale 256
     int nCols[kOrbMaxLevels], nRows[kOrbMaxLevels], wCell[kOrbMaxLevels], hCell[kOrbMaxLevels];
     int ncell[kOrbMaxLevels], cell_off[kOrbMaxLevels], cells_total;
+    // the cell-FAST launch: a workgroup takes gcell[l] consecutive cells of a cell row (gcols[l] workgroups per row)
+    int gcell[kOrbMaxLevels], gcols[kOrbMaxLevels], blk_off[kOrbMaxLevels], blks_total;
     int xtab_off[kOrbMaxLevels], ytab_off[kOrbMaxLevels], xtab_total, ytab_total;   // resize tables (levels >= 1)
     // the blur launch covers ALL levels: first block (y) of level l
     int blur_blk[kOrbMaxLevels + 1];
