@@ -162,25 +162,26 @@ __device__ __forceinline__ int fast_cornerness(const uint8_t *c, int P)
 {
     const int v = c[0];
     int d[16];
-    d[0] = v - c[3 * P];       d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];   d[3] = v - c[P + 3];
-    d[4] = v - c[3];           d[5] = v - c[-P + 3];      d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];
-    d[8] = v - c[-3 * P];      d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-P - 3];
-    d[12] = v - c[-3];         d[13] = v - c[P - 3];      d[14] = v - c[2 * P - 2];  d[15] = v - c[3 * P - 1];
-    // min / max over every 9-arc d[i..i+8] as three-input ops: triples, then triples of triples
+    d[0] = c[3 * P];       d[1] = c[3 * P + 1];   d[2] = c[2 * P + 2];   d[3] = c[P + 3];
+    d[4] = c[3];           d[5] = c[-P + 3];      d[6] = c[-2 * P + 2];  d[7] = c[-3 * P + 1];
+    d[8] = c[-3 * P];      d[9] = c[-3 * P - 1];  d[10] = c[-2 * P - 2]; d[11] = c[-P - 3];
+    d[12] = c[-3];         d[13] = c[P - 3];      d[14] = c[2 * P - 2];  d[15] = c[3 * P - 1];
+    // The cornerness is max over the 9-arcs of min(v - p) and of min(p - v): on the ring values themselves that is
+    // v - (smallest arc maximum) and (largest arc minimum) - v -- no sixteen differences.  Min / max over every 9-arc
+    // d[i..i+8] as three-input ops: triples, then triples of triples.
     int m3[16], x3[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         m3[i] = min(min(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
         x3[i] = max(max(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
     }
-    int best = -255, worst = 255;
+    int max_of_min = 0, min_of_max = 255;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        best = max(best, min(min(m3[i], m3[(i + 3) & 15]), m3[(i + 6) & 15]));
-        worst = min(worst, max(max(x3[i], x3[(i + 3) & 15]), x3[(i + 6) & 15]));
+        max_of_min = max(max_of_min, min(min(m3[i], m3[(i + 3) & 15]), m3[(i + 6) & 15]));
+        min_of_max = min(min_of_max, max(max(x3[i], x3[(i + 3) & 15]), x3[(i + 6) & 15]));
     }
-    const int bestn = -worst;
-    const int V = max(best, bestn) - 1;
+    const int V = max(v - min_of_max, max_of_min - v) - 1;
     return V > 0 ? V : 0;
 }
 
@@ -272,21 +273,34 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
     // three rows up / down and three columns left / right: five dword reads instead of twenty byte
     // reads), in packed 16-bit arithmetic on the even and the odd bytes:
     //   alive <=> max( min(v - min(p0,p8), v - min(p4,p12)),  min(max(p0,p8) - v, max(p4,p12) - v) ) > t
+    // the test loop's thread -> (column group, row) map: nd column groups x tR rows per step
+    const int tR = kCellThreads / nd;
+    const int tRow = (int)(((float)tid + 0.5f) * inv_nd), tq = tid - tRow * nd;
+    const int tXb = 4 * tq - ox;                                             // window x of the column group's first byte
+    uint32_t tInside;                                                        // its pixels inside [3, cw - 3)
+    {
+        const int lo = max(0, 3 - tXb), hi = min(4, cw - 3 - tXb);
+        tInside = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+    }
     auto survivors_and_cornerness = [&](const int th) {
         {
             typedef short s16x2 __attribute__((ext_vector_type(2)));
-            const int rows = ch - 6, ngroups = nd * rows;
+            const int rows = ch - 6;
             const s16x2 T1 = {(short)(th + 1), (short)(th + 1)};
-            for (int i0 = 0; i0 < ngroups; i0 += kCellThreads) {
-                const int i = i0 + tid;
-                uint32_t m4 = 0;
-                int y = 0, xb = 0;
-                if (i < ngroups) {
-                    const int yy = (int)(((float)i + 0.5f) * inv_nd), gq = i - yy * nd;
-                    y = yy + 3; xb = 4 * gq - ox;                            // window x of the dword's first byte
-                    const uint32_t *r = rawd + y * RD + gq;
-                    const uint32_t C = r[0], U = r[-3 * RD], D = r[3 * RD], Lf = gq > 0 ? r[-1] : 0u, Rt = r[1];
-                    Vd[y * RD + gq] = 0;                                     // (see the clear of the two outer rows above)
+            // a thread keeps ONE column group (four pixels) and walks down the rows, R rows of the window per step: the
+            // column's position, its in-window mask and its left neighbour are set up once
+            const int lane = tid & 63;
+            // the survivors of a thread's column group: four bits per step, compacted ONCE after the walk (a prefix sum and an
+            // LDS atomic per step were 40 % of this loop)
+            unsigned long long alive = 0;
+            int step = 0;
+            for (int yb = 0; yb < rows; yb += tR, step++) {
+                const int yy = yb + tRow;
+                const int y = yy + 3;
+                if (tRow < tR && yy < rows) {
+                    const uint32_t *r = rawd + y * RD + tq;
+                    const uint32_t C = r[0], U = r[-3 * RD], D = r[3 * RD], Lf = tq > 0 ? r[-1] : 0u, Rt = r[1];
+                    Vd[y * RD + tq] = 0;                                     // (see the clear of the two outer rows above)
                     const uint32_t Lv = __builtin_amdgcn_alignbyte(C, Lf, 1);    // x - 3 neighbours of the four pixels
                     const uint32_t Rv = __builtin_amdgcn_alignbyte(Rt, C, 3);    // x + 3 neighbours
                     uint32_t sgn[2];
@@ -296,30 +310,33 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
                         const s16x2 v = half(C), u = half(U), d = half(D), l = half(Lv), rr = half(Rv);
                         const s16x2 mnA = __builtin_elementwise_min(u, d), mxA = __builtin_elementwise_max(u, d);
                         const s16x2 mnB = __builtin_elementwise_min(l, rr), mxB = __builtin_elementwise_max(l, rr);
-                        const s16x2 dark = __builtin_elementwise_min(v - mnA, v - mnB);
-                        const s16x2 bright = __builtin_elementwise_min(mxA - v, mxB - v);
+                        const s16x2 dark = v - __builtin_elementwise_max(mnA, mnB);      // == min(v - mnA, v - mnB)
+                        const s16x2 bright = __builtin_elementwise_min(mxA, mxB) - v;    // == min(mxA - v, mxB - v)
                         sgn[hb] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(dark, bright) - T1);   // sign set <=> not alive
                     }
                     const uint32_t dead = ((sgn[0] >> 15) & 1u) | ((sgn[1] >> 14) & 2u) | ((sgn[0] >> 29) & 4u) | ((sgn[1] >> 28) & 8u);
-                    // pixels inside [3, cw - 3)
-                    const int lo = max(0, 3 - xb), hi = min(4, cw - 3 - xb);
-                    const uint32_t inside = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
-                    m4 = ~dead & inside;
+                    alive |= (unsigned long long)(~dead & tInside) << (4 * step);
                 }
-                // survivors -> list (any order): one LDS atomic per wave and step
-                const int lane = tid & 63;
-                const unsigned long long lt = (1ull << lane) - 1ull;
-                const unsigned long long b0 = __ballot(m4 & 1u), b1 = __ballot(m4 & 2u), b2 = __ballot(m4 & 4u), b3 = __ballot(m4 & 8u);
-                const int c0 = __popcll(b0), c1 = __popcll(b1), c2 = __popcll(b2), c3 = __popcll(b3);
-                if (c0 + c1 + c2 + c3) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&s_nlist, c0 + c1 + c2 + c3);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    const int pos = y * kCellPitch + xb;
-                    if (m4 & 1u) list[base + __popcll(b0 & lt)] = (uint16_t)pos;
-                    if (m4 & 2u) list[base + c0 + __popcll(b1 & lt)] = (uint16_t)(pos + 1);
-                    if (m4 & 4u) list[base + c0 + c1 + __popcll(b2 & lt)] = (uint16_t)(pos + 2);
-                    if (m4 & 8u) list[base + c0 + c1 + c2 + __popcll(b3 & lt)] = (uint16_t)(pos + 3);
+            }
+            // survivors -> list (any order): a prefix sum of the lanes' counts and one LDS atomic per wave; a lane's entries
+            // are written without branches (a dead pixel's store goes to a scratch entry past the keypoint list)
+            const int mine = __popcll(alive);
+            const int incl = wave_incl_scan(mine);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            if (total) {
+                int base = 0;
+                if (lane == 63) base = atomicAdd(&s_nlist, total);
+                int at = __builtin_amdgcn_readlane(base, 63) + incl - mine;
+                uint16_t *scratch = klist + plane / 2;
+                for (int st = 0; st < step; st++) {
+                    const uint32_t m4 = (uint32_t)(alive >> (4 * st)) & 15u;
+                    const int pos = (3 + tRow + st * tR) * kCellPitch + tXb;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const bool on = (m4 >> q) & 1u;
+                        *(on ? list + at : scratch) = (uint16_t)(pos + q);
+                        at += on;
+                    }
                 }
             }
         }
@@ -451,6 +468,7 @@ __global__ __launch_bounds__(256) void orb_gather_kernel(OrbGeom g, const float4
                                                          float4 *lvl_cand, int *lvl_cnt, int cand_cap, int *overflow)
 {
     __shared__ int offs[1024];
+    __shared__ unsigned short cn[1024];
     __shared__ int total;
     const int l = blockIdx.x, b = blockIdx.y;
     const int ncell = g.ncell[l];
@@ -483,7 +501,7 @@ __global__ __launch_bounds__(256) void orb_gather_kernel(OrbGeom g, const float4
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int c = tid * 4 + q;
-            if (c < ncell) offs[c] = run;
+            if (c < ncell) { offs[c] = run; cn[c] = (unsigned short)v[q]; }
             run += v[q];
         }
         if (tid == 255) total = run;                       // ncell <= 1024 == 4 * 256: the last thread ends the scan
@@ -494,10 +512,11 @@ __global__ __launch_bounds__(256) void orb_gather_kernel(OrbGeom g, const float4
     if (threadIdx.x == 0 && total > cand_cap) atomicOr(overflow + b, 2);
     const float4 *src = cell_cand + (int64_t)b * cand_img_stride + (int64_t)g.cell_off[l] * kCellCap;
     float4 *dst = lvl_cand + ((int64_t)b * g.nlevels + l) * cand_cap;
-    // a cell holds a few dozen candidates at most: 16 lanes per cell (a whole wave per cell copied 20 of 64 lanes)
-    for (int c = threadIdx.x >> 4; c < ncell; c += 16) {
-        const int n = min(cnt[c], kCellCap), o = offs[c];
-        for (int k = threadIdx.x & 15; k < n; k += 16)
+    // a cell holds a handful of candidates: 8 lanes per cell, 32 cells per pass, counts and offsets from the LDS (with 16
+    // lanes and the count read from global memory a level-0 list was 28 passes of two dependent loads: the launch's time)
+    for (int c = threadIdx.x >> 3; c < ncell; c += 32) {
+        const int n = cn[c], o = offs[c];
+        for (int k = threadIdx.x & 7; k < n; k += 8)
             if (o + k < cand_cap) dst[o + k] = src[(int64_t)c * kCellCap + k];
     }
     if (threadIdx.x == 0) lvl_cnt[b * g.nlevels + l] = min(total, cand_cap);
@@ -983,18 +1002,6 @@ __device__ inline QpLds qplds_carve(uint8_t *smem, int node_cap)
     return L;
 }
 
-// inclusive prefix sum over the wave's lanes on the DPP network (row shifts inside the rows of 16, then the two row
-// broadcasts: the sequence of LLVM's AMDGPUAtomicOptimizer for gfx9) -- six adds, no LDS round trips
-__device__ __forceinline__ int wave_incl_scan(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
-    return v;
-}
 // exclusive prefix sum over the workgroup's threads in thread order; every thread gets the total.  Each wave scans its own
 // lanes on the DPP network and only the wave totals go through the LDS: one barrier.  Consecutive calls must alternate
 // between the two buffers (a thread may still be reading the previous call's totals when another starts the next).
@@ -2161,7 +2168,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
         int hmax = 0;
         for (int l = 0; l < L; l++) if (g.ncell[l] > 0 && g.hCell[l] > hmax) hmax = g.hCell[l];
         if (g.blks_total > 0)
-            hipLaunchKernelGGL(orb_cellfast_kernel, dim3(g.blks_total * n_img), dim3(kCellThreads), (size_t)5 * ((kCellPitch * (hmax + 6) + 15) & ~15), st,
+            hipLaunchKernelGGL(orb_cellfast_kernel, dim3(g.blks_total * n_img), dim3(kCellThreads), (size_t)5 * ((kCellPitch * (hmax + 6) + 15) & ~15) + 16, st,
                                g, slots, g.slot_bytes, ctx->cfg.orb_ini_th, ctx->cfg.orb_min_th, cell_cand, cell_cnt,
                                (int64_t)g.cells_total * kCellCap, (int64_t)g.cells_total, n_img);
     }

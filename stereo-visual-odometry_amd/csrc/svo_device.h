@@ -41,6 +41,18 @@ struct OrbGeom {
     int blur_blk[kOrbMaxLevels + 1];
 };
 
+// inclusive prefix sum over the wave's lanes on the DPP network (row shifts inside the rows of 16, then the two row
+// broadcasts: the sequence of LLVM's AMDGPUAtomicOptimizer for gfx9) -- six adds, no LDS round trips
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
 __host__ __device__ inline int refl101(int i, int n)
 {
     if (n == 1) return 0;
