@@ -24,7 +24,11 @@ namespace svo {
 
 // ------------------------------------------------------------------------------------------
 struct PnpState;
-struct PnpBeginArgs { PnpState *state; int *counts; int *subsets; int iterations, first_cap; const uint64_t *stream; };
+// the keypoint counts (and capacity flags) of the frames of a pair, frozen for the pose stage's gates while the next batch's
+// front end overwrites the live ones: snap[p] = n(previous), snap[n_pairs + p] = n(current), snap[2 n_pairs + p] = OR of the
+// flags of the pair's image slots (ORB mode: per = 2 slots per frame).  Written by the pair's begin workgroup.
+struct SnapArgs { const int *n, *ovf; int fp0, fc0, fstep, per, n_pairs; int *snap; };
+struct PnpBeginArgs { PnpState *state; int *counts; int *subsets; int iterations, first_cap; const uint64_t *stream; SnapArgs snap; };
 __device__ void pnp_begin_item(const PnpBeginArgs &a, int n, int b, int lane);
 
 struct TriArgs {
@@ -287,6 +291,13 @@ __device__ void pnp_begin_item(const PnpBeginArgs &a, int n, int b, int lane)
 {
     PnpState *st = a.state + b;
     int *counts = a.counts + (int64_t)b * kPhaseHyps;
+    if (a.snap.snap && lane == 0) {
+        const SnapArgs &q = a.snap;
+        const int sp = q.per * (q.fp0 + b * q.fstep), sc = q.per * (q.fc0 + b * q.fstep);
+        q.snap[b] = q.n[sp];
+        q.snap[q.n_pairs + b] = q.n[sc];
+        if (q.ovf) q.snap[2 * q.n_pairs + b] = q.per == 2 ? (q.ovf[sp] | q.ovf[sp + 1] | q.ovf[sc] | q.ovf[sc + 1]) : (q.ovf[sp] | q.ovf[sc]);
+    }
     for (int i = lane; i < kPhaseHyps; i += 64) counts[i] = 0;
     const int niters = a.iterations > 1 ? a.iterations : 1;
     uint64_t rng = ~0ull;
@@ -308,7 +319,7 @@ __device__ void pnp_begin_item(const PnpBeginArgs &a, int n, int b, int lane)
 }
 __global__ __launch_bounds__(64) void pnp_begin_kernel(PnpArgs a)
 {
-    const PnpBeginArgs ba{a.state, a.counts, a.subsets, a.iterations, a.first_cap, a.stream};
+    const PnpBeginArgs ba{a.state, a.counts, a.subsets, a.iterations, a.first_cap, a.stream, SnapArgs{}};
     pnp_begin_item(ba, a.n_pts ? a.n_pts[blockIdx.x] : a.n_fixed, blockIdx.x, threadIdx.x);
 }
 
@@ -760,10 +771,8 @@ struct FinalizeArgs {
     svo_step_result *res;
 };
 
-__global__ void finalize_kernel(FinalizeArgs a)
+__device__ inline void finalize_pair(const FinalizeArgs &a, int p)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= a.n_pairs) return;
     svo_step_result r;
     const PnpRecord &q = a.pnp[p];
     r.n_prev_kps = a.n_prev[p]; r.n_cur_kps = a.n_cur[p];
@@ -833,20 +842,31 @@ __device__ __forceinline__ double quad_bcast_f64(double v)
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), K * 0x55, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
-__global__ __launch_bounds__(64) void chain_kernel(svo_step_result *res, int n_pairs, Pose16 pose0, const double *seed_dev)
+// The gates of every pair, then the chain, in ONE launch of one workgroup (the pose stage ends with it: two launches were
+// 10 us of a lone pair's 750): 256 threads finalize the pairs, the first wave multiplies the chain through.
+constexpr int kFinThreads = 256;
+__global__ __launch_bounds__(kFinThreads) void finalize_chain_kernel(FinalizeArgs a, Pose16 pose0, const double *seed_dev)
 {
     __shared__ double sT[64 * 16];
     __shared__ int sOk[64];
-    const int lane = threadIdx.x, i = (lane >> 2) & 3, j = lane & 3;
+    for (int p = threadIdx.x; p < a.n_pairs; p += kFinThreads) finalize_pair(a, p);
+    __threadfence_block();
+    svo_step_result *res = a.res;
+    const int n_pairs = a.n_pairs;
+    const int lane = threadIdx.x & 63, i = (lane >> 2) & 3, j = lane & 3;
+    const bool first = threadIdx.x < 64;
     double P = seed_dev ? seed_dev[i * 4 + j] : pose0.m[i * 4 + j];     // device seed: the previous batch's last pose
     for (int base = 0; base < n_pairs; base += 64) {
         // the records of 64 pairs are fetched together (one dependent global load per pair made the
         // serial product cost a memory round trip per step)
         const int cnt = min(64, n_pairs - base);
         __syncthreads();
-        for (int e = lane; e < cnt * 16; e += 64) sT[e] = res[base + (e >> 4)].T_rel_inv[e & 15];
-        if (lane < cnt) sOk[lane] = res[base + lane].ok;
+        if (first) {
+            for (int e = lane; e < cnt * 16; e += 64) sT[e] = res[base + (e >> 4)].T_rel_inv[e & 15];
+            if (lane < cnt) sOk[lane] = res[base + lane].ok;
+        }
         __syncthreads();
+        if (!first) continue;
         for (int p = 0; p < cnt; p++) {
             const double p0 = quad_bcast_f64<0>(P), p1 = quad_bcast_f64<1>(P), p2 = quad_bcast_f64<2>(P), p3 = quad_bcast_f64<3>(P);
             if (sOk[p]) {
@@ -1003,7 +1023,7 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
 }
 
 void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const float2 *x1, const float2 *x2,
-                              const int *n_pts, int n_fixed)
+                              const int *n_pts, int n_fixed, const SnapSpec *snap)
 {
     TriArgs a{};
     memcpy(a.P1, ctx->cfg.P1, sizeof(a.P1));
@@ -1024,6 +1044,7 @@ void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const floa
     a.begin.iterations = ctx->cfg.iterations;
     a.begin.first_cap = pnp_first_cap(ctx->cfg);
     a.begin.stream = (const uint64_t *)(ws + ws_off_stream(ctx->cfg, B));
+    if (snap) a.begin.snap = SnapArgs{snap->n, snap->ovf, snap->fp0, snap->fc0, snap->fstep, snap->per, n_items, ctx->kp_n_snap};
     hipLaunchKernelGGL(triangulate_kernel, dim3(gx + 1, n_items), dim3(64), 0, ctx->stream, a);
 }
 
@@ -1050,10 +1071,9 @@ void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const i
     f.n_pairs = n_pairs; f.mode = ctx->cfg.track_mode; f.num_features_tracking = ctx->cfg.num_features_tracking;
     f.inlier_rate = ctx->cfg.inlier_rate; f.min_move2 = ctx->cfg.min_move2; f.max_move2 = ctx->cfg.max_move2;
     f.res = ctx->d_results;
-    hipLaunchKernelGGL(finalize_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, f);
     Pose16 p0;
     for (int i = 0; i < 16; i++) p0.m[i] = pose0_host ? pose0_host[i] : ((i % 5 == 0) ? 1.0 : 0.0);
-    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, st, ctx->d_results, n_pairs, p0, ctx->seed_dev);
+    hipLaunchKernelGGL(finalize_chain_kernel, dim3(1), dim3(kFinThreads), 0, st, f, p0, ctx->seed_dev);
 }
 
 // ---- stage API ------------------------------------------------------------------------------

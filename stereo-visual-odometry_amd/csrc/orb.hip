@@ -2202,26 +2202,6 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     return SVO_OK;
 }
 
-// Keypoint counts and capacity flags of the images a batch of pairs uses, frozen for the pose stage
-// (the next batch's extraction overwrites orb_n / orb_overflow while the side stream still needs them):
-// snap[p] = n(last.left), snap[n_pairs + p] = n(cur.left), snap[2 n_pairs + p] = OR of the flags of
-// last.left, last.right, cur.left, cur.right.
-__global__ void orb_snapshot_kernel(const int *n, const int *ovf, int n_pairs, int fp0, int fc0, int fstep, int *snap)
-{
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    const int sp = 2 * (fp0 + p * fstep), sc = 2 * (fc0 + p * fstep);
-    snap[p] = n[sp];
-    snap[n_pairs + p] = n[sc];
-    snap[2 * n_pairs + p] = ovf[sp] | ovf[sp + 1] | ovf[sc] | ovf[sc + 1];
-}
-
-void orb_snapshot_counts(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipStream_t st)
-{
-    hipLaunchKernelGGL(orb_snapshot_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, (const int *)ctx->orb_n,
-                       (const int *)ctx->orb_overflow, n_pairs, fp0, fc0, fstep, ctx->kp_n_snap);
-}
-
 void orb_launch_match_fixed(svo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, hipStream_t st)
 {
     hipLaunchKernelGGL(orb_match_kernel<4>, dim3((nq + 127) / 128, 1), dim3(256), 0, st, q, (const int *)nullptr, nq, (int64_t)0, t,

@@ -84,9 +84,10 @@ static int run_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, con
         }
         orb_match_pairs(ctx, n_pairs, fp0, fc0, fstep, ctx->stream);
         mark(ctx, kTMatch);
-        launch_triangulate_batch(ctx, n_pairs, cap, ctx->cmp[0], ctx->cmp[1], ctx->m_out, 0);
-        // n_prev / n_cur = left keypoint counts of the two frames (feature slots 2f) + capacity flags
-        orb_snapshot_counts(ctx, n_pairs, fp0, fc0, fstep, ctx->stream);
+        // + n_prev / n_cur = left keypoint counts of the two frames (feature slots 2f) and the capacity flags, frozen for the
+        // pose stage by the pairs' begin workgroups
+        const SnapSpec snap{(const int *)ctx->orb_n, (const int *)ctx->orb_overflow, fp0, fc0, fstep, 2};
+        launch_triangulate_batch(ctx, n_pairs, cap, ctx->cmp[0], ctx->cmp[1], ctx->m_out, 0, &snap);
         mark(ctx, kTTri);
         return run_back(ctx, n_pairs, pose0_host, results_dev);
     }
@@ -122,17 +123,11 @@ static int run_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, con
     c.m_out = ctx->m_out;
     launch_compact(c, n_pairs, ctx->stream);
     mark(ctx, kTCompact);
-    // triangulatePoints(P1, P2, t1_left, t1_right) (:292-294)
-    launch_triangulate_batch(ctx, n_pairs, cap, ctx->cmp[0], ctx->cmp[1], ctx->m_out, 0);
-    // keypoint counts of the frames involved, frozen for the pose stage (FAST of the next batch
-    // overwrites kp_n): snap[p] = n_prev of pair p, snap[n_pairs + p] = n_cur of pair p
-    if (fstep == 1) {
-        SVO_HIP(hipMemcpyAsync(ctx->kp_n_snap, ctx->kp_n + fp0, sizeof(int) * n_pairs, hipMemcpyDeviceToDevice, ctx->stream));
-        SVO_HIP(hipMemcpyAsync(ctx->kp_n_snap + n_pairs, ctx->kp_n + fc0, sizeof(int) * n_pairs, hipMemcpyDeviceToDevice, ctx->stream));
-    } else {
-        SVO_HIP(hipMemcpyAsync(ctx->kp_n_snap, ctx->kp_n + fp0, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
-        SVO_HIP(hipMemcpyAsync(ctx->kp_n_snap + 1, ctx->kp_n + fc0, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
-    }
+    // triangulatePoints(P1, P2, t1_left, t1_right) (:292-294); the pairs' begin workgroups also freeze the keypoint counts
+    // of the frames involved for the pose stage (FAST of the next batch overwrites kp_n): snap[p] = n_prev of pair p,
+    // snap[n_pairs + p] = n_cur of pair p
+    const SnapSpec snap{ctx->kp_n, nullptr, fp0, fc0, fstep, 1};
+    launch_triangulate_batch(ctx, n_pairs, cap, ctx->cmp[0], ctx->cmp[1], ctx->m_out, 0, &snap);
     mark(ctx, kTTri);
     return run_back(ctx, n_pairs, pose0_host, results_dev);
 }

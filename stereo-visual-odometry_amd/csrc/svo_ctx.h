@@ -109,8 +109,10 @@ namespace svo {
 // geometry.hip
 int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes);
 int geom_workspace_init(svo_ctx *ctx);
+// snap: the frames' keypoint counts / capacity flags to freeze into ctx->kp_n_snap beside the triangulation (null: none)
+struct SnapSpec { const int *n, *ovf; int fp0, fc0, fstep, per; };
 void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const float2 *x1, const float2 *x2,
-                              const int *n_pts, int n_fixed);
+                              const int *n_pts, int n_fixed, const SnapSpec *snap = nullptr);
 void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n_pts, int n_fixed, hipStream_t st);
 // orb.hip
 int orb_alloc(svo_ctx *ctx);
@@ -122,7 +124,6 @@ int stage_host_image(svo_ctx *ctx, const uint8_t *img, int pitch, int stage_idx,
 int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int pitch, int64_t img_stride, int slot0,
                       int n_img, hipStream_t st);
 int orb_match_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipStream_t st);
-void orb_snapshot_counts(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipStream_t st);
 void orb_launch_match_fixed(svo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, hipStream_t st);
 void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur, const int *ovf,
                            const double *pose0_host, hipStream_t st);      // ctx->seed_dev != null: seed read on the device
