@@ -191,6 +191,34 @@ def test_orb_extract_other_configurations(pkg, oracle, tc, synth, cfg):
     ctx.close()
 
 
+def test_orb_extract_more_candidates_than_the_lds_key_arrays(pkg, oracle, tc, synth):
+    """cv::FAST is uncapped: a busy image gives a level more candidates than the quadtree kernel keeps in LDS (3456);
+    the tree then partitions its keys in global scratch.  Noise on a rendered frame until level 0 has more than that
+    (and less than the capacity of 4 x nFeatures), then bit-exact keypoints and descriptors."""
+    seq = synth.StereoSequence(width=1241, height=376, n_frames=1, seed=17, supersample=1)
+    base = seq.render(0)[0].numpy().astype(np.int32)
+    rng = np.random.default_rng(5)
+    noise = rng.integers(-64, 65, base.shape)
+    ctx = pkg.Context(1241, 376, device=0, track_mode=pkg.MODE_ORB)
+    picked = None
+    for amp in (0.15, 0.25, 0.35, 0.5, 0.7, 1.0):
+        img = np.clip(base + (noise * amp).astype(np.int32), 0, 255).astype(np.uint8)
+        try:
+            kps, desc, per = ctx.orb_extract(img)
+        except RuntimeError:
+            break                                   # past the candidate capacity: the context refuses loudly
+        n0 = len(ctx.orb_read_candidates(0, cap=16384))
+        if n0 > 3456:
+            picked = (img, kps, desc, per, n0)
+            break
+    assert picked is not None, "no noise level put level 0 between 3456 candidates and the capacity"
+    img, kps, desc, per, n0 = picked
+    rk, rd, rper = oracle.orb_extract(img)
+    assert per.tolist() == rper.tolist()
+    assert kps.tobytes() == rk.tobytes() and desc.tobytes() == rd.tobytes()
+    ctx.close()
+
+
 @pytest.mark.parametrize("nq,nt", [(1, 1), (15, 257), (16, 256), (17, 255), (700, 64), (33, 1000)])
 def test_match_hamming_shapes_and_ties(pkg, oracle, tc, nq, nt):
     """Row counts around the matcher's tile sizes (16 queries per workgroup, 256 train rows per

@@ -125,6 +125,23 @@ def test_pnp_ransac_many_rounds_and_failure(ctx, oracle, tc):
     assert res["ok"] == 0 and res["n_inliers"] == 0 and np.array_equal(res["R"], np.eye(3))
 
 
+@pytest.mark.parametrize("n,n_out,iterations", [(6, 3, 500), (7, 4, 500), (12, 9, 500), (40, 33, 500), (300, 255, 500),
+                                                (300, 255, 130), (25, 21, 700)])
+def test_pnp_ransac_orb_mode_first_phase_is_the_whole_search(pkg, oracle, tc, n, n_out, iterations):
+    """An ORB-mode context draws the subsets of the whole iterationsCount (<= 512) up front, the 64 lanes together, from
+    the constant cv::RNG(-1) stream; with a handful of points nearly every subset redraws indices and the 4096-draw
+    stretch runs out (6 points: ~8.7 draws per subset), so the serial generator takes over mid-phase; 700 iterations
+    need a second phase drawn by it.  Few inliers: the search never stops early.  Everything must equal the oracle's
+    serial loop: iteration count, winner, mask, pose."""
+    c = pkg.Context(416, 128, device=0, track_mode=pkg.MODE_ORB, min_move2=0.0, max_move2=1e9)
+    X, x, r, t = _planted(n, 40 + n, n_out, noise=0.02)
+    ref = oracle.pnp_ransac(X, x, K, iterations=iterations)
+    got = c.pnp_ransac(X, x, K, iterations=iterations)
+    assert ref["ransac_iters"] > min(iterations, 64) or n <= 7
+    _check_pnp(got, ref)
+    c.close()
+
+
 def _check_step(g, r, first=False):
     assert int(g["ok"]) == r["ok"] and int(g["fail_stage"]) == r["fail_stage"]
     assert int(g["n_cur_kps"]) == r["n_cur_kps"]
