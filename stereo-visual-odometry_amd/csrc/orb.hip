@@ -1468,6 +1468,7 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(OrbGeom g, const uint8_t 
     if (x0 >= w || y0 >= h) return;
     const uint8_t *lvl = slots + (int64_t)b * slot_stride + g.origin[l];
     uint8_t *dst = blur + (int64_t)b * blur_img_stride + g.blur_off[l] + x0;
+    const int bp = g.bpitch[l];
     // BORDER_REFLECT_101 is applied HERE (ORBextractor.cpp:1034-1035 blurs the un-bordered clone of the level):
     // rows by reflecting the row index, columns only in the threads whose 12-byte window leaves the row -- the
     // first thread of a row and the last one or two.  No kernel writes a frame around the ORB levels any more
@@ -1499,7 +1500,6 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(OrbGeom g, const uint8_t 
         selA[k] = sa; selB[k] = sb;
     }
     const bool wave_edge = __builtin_amdgcn_ballot_w64(edge) != 0;       // (uniform: decides the code path of the whole wave)
-    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
     auto rowsum = [&](const uint32_t (&d)[3], uint32_t (&out)[4]) {      // d: columns x0-4 .. x0+7 of one row
 #pragma unroll
         for (int o = 0; o < 4; o++) {                               // taps of column x0+o: bytes o+1 .. o+7
@@ -1551,11 +1551,7 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(OrbGeom g, const uint8_t 
                 v >>= 16;
                 v4 |= (v > 255u ? 255u : v) << (8 * o);
             }
-            if (yy < rows) {
-                uint8_t *q = dst + (int64_t)(y0 + yy) * w;
-                if (x0 + 4 <= w) *(u32_unaligned *)q = v4;          // the tight blurred rows are w bytes apart: any alignment
-                else for (int o = 0; x0 + o < w; o++) q[o] = (uint8_t)(v4 >> (8 * o));
-            }
+            if (yy < rows) *(uint32_t *)(dst + (int64_t)(y0 + yy) * bp) = v4;     // rows are padded to whole dwords: one aligned store
         }
     }
 }
@@ -1624,6 +1620,10 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
         a.n_out[b] = min(total, a.out_cap);
         if (total > a.out_cap) atomicOr(a.overflow + b, 4);          // more keypoints than max_keypoints
     }
+    __shared__ int4 s_lv[kOrbMaxLevels];                                 // origin, pitch, blurred pitch, blurred offset of a level
+    if (threadIdx.x < kOrbMaxLevels)
+        s_lv[threadIdx.x] = make_int4((int)a.g.origin[threadIdx.x], a.g.pitch[threadIdx.x], a.g.bpitch[threadIdx.x], (int)a.g.blur_off[threadIdx.x]);
+    __syncthreads();
     const bool valid = gidx < total && gidx < a.out_cap;
     if (__ballot(valid) == 0ull) return;
     const int gq = valid ? gidx : 0;                                  // an idle half shadows keypoint 0, stores nothing
@@ -1641,52 +1641,78 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     const float4 cand = a.lvl_cand[(int64_t)inst * a.cand_cap + a.sel[(int64_t)inst * a.sel_cap + (gq - base)]];
     const float x = cand.x + 16.f, y = cand.y + 16.f;                // += minBorderX / minBorderY
     const int ix = __float2int_rn(x), iy = __float2int_rn(y);
-    const int pitch = a.g.pitch[l], w = a.g.w[l];
+    // the level's geometry from a small LDS table (the level differs from lane half to lane half: indexing the
+    // kernel-argument arrays with it is a chain of selects per value, ~50 instructions)
+    const int4 lv = s_lv[l];
+    const int pitch = lv.y, bp = lv.z;
     // Both gathers (749-pixel circular patch of the level, <= 39x39 footprint of the rotated pattern
     // in the blurred level) go through LDS: a half-wave fetches its two windows as aligned dwords with
     // all loads in flight at once, then reads single bytes from LDS.
     __shared__ uint32_t s_raw[8][31 * 9], s_blr[8][39 * 11];
     const int hw = (threadIdx.x >> 6) * 2 + half;
     uint32_t *raw = s_raw[hw], *blr = s_blr[hw];
-    const uint8_t *lvl = a.slots + (int64_t)b * a.slot_stride + a.g.origin[l];     // 4-byte aligned rows
+    // (addresses = a base that is uniform over the workgroup + a 32-bit offset per lane: an image's slot is a few MB)
+    const uint8_t *img_base = a.slots + (int64_t)b * a.slot_stride;                // 4-byte aligned rows
     const int rx0 = (ix - 15) & ~3, roff = (ix - 15) - rx0;
+    // a lane keeps ONE dword column of the window and walks down the rows (27 of the 32 lanes: 9 columns x 3 rows per
+    // step): the address and the LDS index advance by a constant, no division or multiplication per load
+    {
+        const int c = sl % 9, rr = sl / 9;
+        uint32_t off = (uint32_t)lv.x + (uint32_t)((iy - 15 + rr) * pitch + rx0 + 4 * c);
+        int li = rr * 9 + c;
+        uint32_t v[11];                                              // (all the loads in flight before the first LDS store)
 #pragma unroll
-    for (int t = 0; t < 9; t++) {
-        const int i = sl + 32 * t;
-        if (i < 31 * 9) {
-            const int r = i / 9, c = i - r * 9;
-            raw[i] = *(const uint32_t *)(lvl + (int64_t)(iy - 15 + r) * pitch + rx0 + 4 * c);
+        for (int t = 0; t < 11; t++) {
+            v[t] = sl < 27 && rr + 3 * t < 31 ? *(const uint32_t *)(img_base + off) : 0u;
+            off += 3u * (uint32_t)pitch;
+        }
+#pragma unroll
+        for (int t = 0; t < 11; t++) {
+            if (sl < 27 && rr + 3 * t < 31) raw[li] = v[t];
+            li += 27;
         }
     }
-    const uint8_t *bimg = a.blur + (int64_t)b * a.blur_img_stride + a.g.blur_off[l];
-    const int64_t bsize = (int64_t)w * a.g.h[l];
-    // rows of the tight blurred image are not aligned: align each row's start down, keep its offset
+    const uint8_t *blur_base = a.blur + (int64_t)b * a.blur_img_stride;          // 4-byte aligned rows, bp apart
+    const int bx0 = (ix - 19) & ~3, boff = (ix - 19) - bx0;          // (the 39 x 39 footprint lies inside the level: >= 19 pixels from its edges)
+    {
+        const int c = sl % 11, rr = sl / 11;                          // 22 lanes: 11 columns x 2 rows per step
+        uint32_t off = (uint32_t)lv.w + (uint32_t)((iy - 19 + rr) * bp + bx0 + 4 * c);
+        int li = rr * 11 + c;
+        uint32_t v[20];
 #pragma unroll
-    for (int t = 0; t < 14; t++) {
-        const int i = sl + 32 * t;
-        if (i < 39 * 11) {
-            const int r = i / 11, c = i - r * 11;
-            const int64_t o = (int64_t)(iy - 19 + r) * w + (ix - 19);        // byte offset of the row's first pixel
-            const int64_t oa = ((o + ((uintptr_t)bimg & 3)) & ~(int64_t)3) - ((uintptr_t)bimg & 3) + 4 * c;
-            uint32_t v = 0;
-            if (oa >= 0 && oa + 4 <= bsize) v = *(const uint32_t *)(bimg + oa);
-            else for (int q = 0; q < 4; q++) if (oa + q >= 0 && oa + q < bsize) v |= (uint32_t)bimg[oa + q] << (8 * q);
-            blr[i] = v;
+        for (int t = 0; t < 20; t++) {
+            v[t] = sl < 22 && rr + 2 * t < 39 ? *(const uint32_t *)(blur_base + off) : 0u;
+            off += 2u * (uint32_t)bp;
+        }
+#pragma unroll
+        for (int t = 0; t < 20; t++) {
+            if (sl < 22 && rr + 2 * t < 39) blr[li] = v[t];
+            li += 22;
         }
     }
     wave_lds_fence();
-    // IC_Angle: m10 = sum u * I, m01 = sum v * I over the circular patch (rows v = -15..15)
+    // IC_Angle: m10 = sum u * I, m01 = sum v * I over the circular patch (rows v = -15..15).  A lane takes a row: its 31
+    // bytes as eight dwords shifted to start at u = -15, the pixels outside |u| <= umax[|v|] masked off, then four
+    // bytes per instruction: v_sad_u8 against 0 adds them up, v_dot4_u32_u8 against (j, j+1, j+2, j+3) gives
+    // sum (u + 15) * I (exact integers: sum u * I = that - 15 sum I)
     int m10 = 0, m01 = 0;
     if (sl < 31) {
         const int v = sl - 15, d = a.g.umax[v < 0 ? -v : v];
-        const uint8_t *row = (const uint8_t *)(raw + sl * 9) + roff + 15;
-        int s = 0, su = 0;
+        const uint32_t *rw = raw + sl * 9;
+        uint32_t dw[9];
 #pragma unroll
-        for (int u = -15; u <= 15; ++u) {
-            const int val = (u >= -d && u <= d) ? (int)row[u] : 0;
-            s += val; su += u * val;
+        for (int k = 0; k < 9; k++) dw[k] = rw[k];
+        const uint32_t bits = (2u << (15 + d)) - (1u << (15 - d));           // bit j set <=> column u = j - 15 is inside the patch
+        uint32_t s = 0, sw = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t e = __builtin_amdgcn_alignbit(dw[k + 1], dw[k], 8 * roff);          // bytes j = 4k .. 4k + 3
+            const uint32_t px = e & ((((bits >> (4 * k)) & 15u) * 0x00204081u & 0x01010101u) * 0xFFu);
+            const uint32_t wj = (uint32_t)(4 * k) * 0x01010101u + 0x03020100u;
+            s = __builtin_amdgcn_sad_u8(px, 0u, s);
+            sw = __builtin_amdgcn_udot4(px, wj, sw, false);
         }
-        m10 = su; m01 = v * s;
+        m10 = (int)sw - 15 * (int)s; m01 = v * (int)s;
     }
     m10 = half_sum_i32(m10); m01 = half_sum_i32(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
@@ -1698,12 +1724,7 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     const float ca = (float)cd, sb = (float)sd;
     {
         const signed char *pat = c_pattern + sl * 32;
-        const int balign = (int)((uintptr_t)bimg & 3);
-        auto sample = [&](int dyy, int dxx) -> int {
-            const int64_t o = (int64_t)(iy + dyy) * w + (ix - 19);            // row start in the tight image
-            const int off = (int)((o + balign) & 3);                             // its offset inside the staged dwords
-            return ((const uint8_t *)(blr + (dyy + 19) * 11))[off + dxx + 19];
-        };
+        auto sample = [&](int dyy, int dxx) -> int { return ((const uint8_t *)(blr + (dyy + 19) * 11))[boff + dxx + 19]; };
         int val = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -1975,7 +1996,8 @@ int orb_make_geom(const svo_config &cfg, OrbGeom *g)
         off += (int64_t)g->pitch[l] * (g->h[l] + 2 * kPad);
         off = (off + 255) / 256 * 256;
         g->blur_off[l] = boff;
-        boff += (int64_t)g->w[l] * g->h[l];
+        g->bpitch[l] = (g->w[l] + 3) & ~3;
+        boff += (int64_t)g->bpitch[l] * g->h[l];
         // cell grid of ComputeKeyPointsOctTree (:729-741)
         const int maxBX = g->w[l] - 16, maxBY = g->h[l] - 16;
         const float width = (float)(maxBX - 16), height = (float)(maxBY - 16);
@@ -1996,7 +2018,7 @@ int orb_make_geom(const svo_config &cfg, OrbGeom *g)
         coff += g->ncell[l];
     }
     g->slot_bytes = off;
-    g->blur_total = boff;
+    g->blur_total = boff;                       // (a multiple of 4: every image's levels start 4-byte aligned)
     g->cells_total = coff;
     g->blks_total = boff_cells;
     {
@@ -2088,7 +2110,7 @@ int orb_alloc(svo_ctx *ctx)
         if (!yt.empty()) SVO_HIP(hipMemcpy(ctx->orb_ytab, yt.data(), sizeof(int4) * yt.size(), hipMemcpyHostToDevice));
     }
     SVO_HIP(hipMalloc(&ctx->orb_slots, (size_t)g.slot_bytes * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_blur, (size_t)g.blur_total * n_img));
+    SVO_HIP(hipMalloc(&ctx->orb_blur, (size_t)g.blur_total * n_img + 64));     // + the descriptor kernel's last dword past a row end
     SVO_HIP(hipMalloc(&ctx->orb_cell_cand, sizeof(float4) * (size_t)g.cells_total * kCellCap * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_cell_cnt, sizeof(int) * (size_t)g.cells_total * n_img));
     SVO_HIP(hipMalloc(&ctx->orb_lvl_cand, sizeof(float4) * (size_t)kCandCap * L * n_img));

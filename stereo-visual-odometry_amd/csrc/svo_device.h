@@ -26,7 +26,8 @@ struct OrbGeom {
     int nlevels;
     int w[kOrbMaxLevels], h[kOrbMaxLevels], pitch[kOrbMaxLevels];
     int64_t origin[kOrbMaxLevels];       // byte offset of pixel (0,0) of level l inside the slot
-    int64_t blur_off[kOrbMaxLevels];     // offset of level l in the tight blurred / row-sum images
+    int64_t blur_off[kOrbMaxLevels];     // offset of level l in the blurred images (rows bpitch[l] bytes apart, 4-byte aligned)
+    int bpitch[kOrbMaxLevels];
     int64_t slot_bytes, blur_total;
     float scale[kOrbMaxLevels];          // mvScaleFactor
     int quota[kOrbMaxLevels];            // mnFeaturesPerLevel
