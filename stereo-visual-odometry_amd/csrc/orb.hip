@@ -2098,7 +2098,8 @@ int orb_alloc(svo_ctx *ctx)
             SVO_HIP(hipFuncSetAttribute((const void *)orb_distribute_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)qplds_bytes(ctx->orb_node_cap)));
     }
-    ctx->orb_cand_cap = 4 * ctx->cfg.max_keypoints;      // FAST candidates kept per (image, level)
+    // FAST candidates kept per (image, level); one less than 2^16 at most: a quadtree node's key count is a 16-bit field
+    ctx->orb_cand_cap = 4 * ctx->cfg.max_keypoints < 65535 ? 4 * ctx->cfg.max_keypoints : 65535;
     const int kCandCap = ctx->orb_cand_cap;
     SVO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), svo_bit_pattern_31, 1024));
     {
