@@ -172,7 +172,10 @@ def test_orb_mode_failure_stages(pkg, oracle, tc, synth):
 
 @pytest.mark.parametrize("cfg", [dict(nlevels=1, scale_factor=1.2, nfeatures=800, ini_th=20, min_th=7),
                                  dict(nlevels=5, scale_factor=1.5, nfeatures=1200, ini_th=30, min_th=10),
-                                 dict(nlevels=8, scale_factor=1.1, nfeatures=300, ini_th=12, min_th=12)])
+                                 dict(nlevels=8, scale_factor=1.1, nfeatures=300, ini_th=12, min_th=12),
+                                 # a per-level quota whose node tables do not fit the node-parallel quadtree's LDS: the serial
+                                 # wave-per-tree kernel takes over
+                                 dict(nlevels=1, scale_factor=1.2, nfeatures=3000, ini_th=9, min_th=5)])
 def test_orb_extract_other_configurations(pkg, oracle, tc, synth, cfg):
     """ORBextractor with non-default YAML values (nLevels, fScaleFactor, nFeatures, FAST thresholds):
     resize tables, quotas, cell grid and quadtree all follow the configuration; bit-exact."""
