@@ -61,11 +61,29 @@ __global__ __launch_bounds__(256) void pyr_border_kernel(PyrArgs a, int l)
         uint8_t *dst = lvl + (int64_t)py * pitch;
         for (int px = ((int)threadIdx.x << 2) - kPad; px < w + kPad; px += 1024) {
             uint32_t v = 0;
+            if (px >= 0 && px + 4 <= w) v = *(const uint32_t *)(src + px);     // above / below the interior: an aligned dword of the mirrored row
+            else {
 #pragma unroll
-            for (int q = 0; q < 4; q++) v |= (uint32_t)src[refl101(min(px + q, w + kPad - 1), w)] << (8 * q);
+                for (int q = 0; q < 4; q++) v |= (uint32_t)src[refl101(min(px + q, w + kPad - 1), w)] << (8 * q);
+            }
             if (px + 4 <= w + kPad) *(uint32_t *)(dst + px) = v;
             else for (int q = 0; px + q < w + kPad; q++) dst[px + q] = (uint8_t)(v >> (8 * q));
         }
+    } else if (w >= 2 * kPad) {
+        // the 2 x 32 side bytes of sixteen interior rows, a DWORD per thread (sixteen per row: 64 one-byte loads and
+        // stores per row made this launch four times slower than its bytes): the four frame bytes px .. px + 3 are the
+        // interior bytes at the mirrored columns in reverse order -- one unaligned load, one byte swap, one store
+        static_assert(kBorderRows == 16 && kPad == 32, "256 threads = 16 rows x 16 dwords");
+        typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+        const int k = threadIdx.x & 15, r = threadIdx.x >> 4;
+        const int py = (gidx - 2 * kPad) * kBorderRows + r;
+        if (py >= h) return;
+        uint8_t *row = lvl + (int64_t)py * pitch;
+        // left: px = -32 + 4 k mirrors columns 32 - 4 k .. 29 - 4 k; right: px = w + 4 (k - 8) mirrors w - 2 - 4 (k - 8) .. - 3
+        const int px = k < 8 ? -kPad + 4 * k : w + 4 * (k - 8);
+        const int c0 = k < 8 ? kPad - 3 - 4 * k : w - 5 - 4 * (k - 8);
+        const uint32_t v = *(const u32_unaligned *)(row + c0);
+        *(u32_unaligned *)(row + px) = __builtin_amdgcn_perm(0u, v, 0x00010203u);
     } else {
         const int t = threadIdx.x & 63;
         const int px = t < kPad ? t - kPad : w + (t - kPad);
