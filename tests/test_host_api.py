@@ -119,6 +119,37 @@ def test_yaml_surface_and_image_readers(host_built, tmp_path):
     assert "image4 ok=0" in out
 
 
+def test_png_reader_stream_shapes(host_built, tmp_path):
+    """The PNG reader on the stream shapes deflate has: stored blocks (level 0), fixed and dynamic Huffman blocks, long
+    matches (flat image), literals only (noise), every row filter (PIL picks them per row for the gradient / photo-like
+    images), one and many IDAT chunks, widths that are not multiples of anything: same pixels as PIL."""
+    from PIL import Image
+    rng = np.random.default_rng(8)
+    yy, xx = np.mgrid[0:173, 0:419]
+    imgs = {
+        "noise": rng.integers(0, 256, (173, 419), dtype=np.uint8),
+        "flat": np.full((64, 1241), 93, np.uint8),
+        "grad": ((xx * 3 + yy * 5) % 256).astype(np.uint8),
+        "photo": np.clip(128 + 60 * np.sin(xx / 17.0) * np.cos(yy / 11.0) + rng.normal(0, 4, xx.shape), 0, 255).astype(np.uint8),
+        "tiny": rng.integers(0, 256, (1, 1), dtype=np.uint8),
+        "thin": rng.integers(0, 4, (300, 3), dtype=np.uint8) * 60,
+    }
+    files, want = [], []
+    for name, im in imgs.items():
+        for lvl in (0, 1, 6, 9):
+            fn = tmp_path / f"{name}_{lvl}.png"
+            Image.fromarray(im).save(fn, compress_level=lvl)
+            files.append(str(fn)); want.append(im)
+    big = np.clip(120 + 50 * np.sin(np.arange(376)[:, None] / 23.0) + rng.normal(0, 6, (376, 1241)), 0, 255).astype(np.uint8)
+    Image.fromarray(big).save(tmp_path / "big.png", compress_level=3)           # several 64 KB IDAT chunks
+    files.append(str(tmp_path / "big.png")); want.append(big)
+    _write_yaml(tmp_path / "cfg.yaml", "/data/kitti/00")
+    out = subprocess.check_output([os.path.join(host_built, "host_selftest"), str(tmp_path / "cfg.yaml")] + files,
+                                  stderr=subprocess.DEVNULL).decode()
+    for i, im in enumerate(want):
+        assert f"image{i + 1} ok=1 rows={im.shape[0]} cols={im.shape[1]} hash={_hash(im)}" in out, files[i]
+
+
 def test_usage_error_returns_nonzero(host_built):
     r = subprocess.run([os.path.join(host_built, "run_kitti_stereo")], stderr=subprocess.DEVNULL)
     assert r.returncode == 2
