@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 5
+#define SVO_ABI_VERSION 6
 
 /* status codes */
 #define SVO_OK                 0
@@ -79,10 +79,22 @@ typedef struct {
     float   orb_scale_factor;       /* fScaleFactor 1.2 */
     int32_t orb_nlevels;            /* nLevels 8 */
     int32_t orb_ini_th, orb_min_th; /* fIniThFAST 20, fMinThFAST 7 */
+    /* ABI v6.  Order of the five float sums A11, A12, A22, b1, b2 inside cv::calcOpticalFlowPyrLK
+       (src/tracking.cpp:593-618), the one place where upstream's result depends on the build's SIMD width:
+       SVO_LK_ACCUM_EXACT (default): exact integer sums converted to float once -- upstream's acctype = int64
+           variant, independent of any order (canonical choice C0);
+       SVO_LK_ACCUM_SSE2: float accumulation in the lane order of upstream's CV_SSE2 block, i.e. what an x86
+           OpenCV 3 build computes (four lanes over x = 0..19 + scalar tail for A, _mm_madd_epi16 pairs over
+           x = 0..15 + scalar tail for b).  Bit-identical to oracle/lk.c's accumulation mode 2; about 2x the
+           LK kernel time.  YAML key `lk_accum: exact | sse2`. */
+    int32_t lk_accum;
+    int32_t _reserved;
 } svo_config;
 
 #define SVO_MODE_LK  0
 #define SVO_MODE_ORB 1
+#define SVO_LK_ACCUM_EXACT 0
+#define SVO_LK_ACCUM_SSE2  1
 
 typedef struct {                    /* solvePnPRansac + Rodrigues outcome */
     double rvec[3], tvec[3], R[9];

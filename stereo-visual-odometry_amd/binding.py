@@ -27,10 +27,12 @@ class Config(C.Structure):
                 ("min_move2", C.c_double), ("max_move2", C.c_double),
                 ("P1", C.c_double * 12), ("P2", C.c_double * 12),
                 ("track_mode", C.c_int32), ("orb_nfeatures", C.c_int32), ("orb_scale_factor", C.c_float),
-                ("orb_nlevels", C.c_int32), ("orb_ini_th", C.c_int32), ("orb_min_th", C.c_int32)]
+                ("orb_nlevels", C.c_int32), ("orb_ini_th", C.c_int32), ("orb_min_th", C.c_int32),
+                ("lk_accum", C.c_int32), ("_reserved", C.c_int32)]
 
 
 MODE_LK, MODE_ORB = 0, 1
+LK_ACCUM_EXACT, LK_ACCUM_SSE2 = 0, 1          # svo_config.lk_accum
 
 
 class PnPResult(C.Structure):
@@ -134,6 +136,14 @@ def _ptr(a):
     return C.c_void_p(a.data_ptr()), (MEM_DEVICE if a.is_cuda else MEM_HOST)
 
 
+def _torch_ready(t):
+    """The library runs on the context's own stream: outputs this binding has just allocated with torch (their
+    zero fill is a kernel on TORCH's current stream) and inputs torch has just produced must be complete before
+    a library kernel touches them.  Only the stage wrappers that allocate call this; track_batch does not."""
+    import torch
+    torch.cuda.current_stream(t.device).synchronize()
+
+
 class Context:
     """One svo_ctx: owns every device buffer of the hot path on one GPU."""
 
@@ -234,6 +244,7 @@ class Context:
             n = pts.shape[0]
             out = torch.zeros((n, 2), dtype=torch.float32, device=pts.device)
             st = torch.zeros(n, dtype=torch.uint8, device=pts.device)
+            _torch_ready(st)
         pi, mem = _ptr(pts)
         po, _ = _ptr(out)
         ps, _ = _ptr(st)
@@ -252,6 +263,7 @@ class Context:
             import torch
             n = t1_left.shape[0]
             outs = [torch.zeros((max(n, 1), 2), dtype=torch.float32, device=t1_left.device) for _ in range(4)]
+            _torch_ready(outs[0])
         pi, mem = _ptr(t1_left)
         m = C.c_int(0)
         self._check(self.lib.svo_circular_match(self.h, *[int(s) for s in slots], pi, n,
@@ -268,6 +280,7 @@ class Context:
         else:
             import torch
             out = torch.zeros((x1.shape[0], 3), dtype=torch.float32, device=x1.device)
+            _torch_ready(out)
         p1, mem = _ptr(x1)
         p2, _ = _ptr(x2)
         self._check(self.lib.svo_triangulate(self.h, C.c_void_p(P1.ctypes.data), C.c_void_p(P2.ctypes.data),
@@ -285,6 +298,7 @@ class Context:
         else:
             import torch
             mask = torch.zeros(max(obj.shape[0], 1), dtype=torch.uint8, device=obj.device)
+            _torch_ready(mask)
         n = obj.shape[0]
         res = PnPResult()
         po, mem = _ptr(obj)
@@ -336,6 +350,7 @@ class Context:
             import torch
             idx = torch.zeros(max(len(query), 1), dtype=torch.int32, device=query.device)
             dist = torch.zeros(max(len(query), 1), dtype=torch.float32, device=query.device)
+            _torch_ready(dist)
         pq, mem = _ptr(query)
         self._check(self.lib.svo_match_hamming(self.h, pq, len(query), _ptr(train)[0], len(train), _ptr(idx)[0],
                                                _ptr(dist)[0], mem))
@@ -454,6 +469,7 @@ class Context:
             okc = ok.to(torch.int32).contiguous()
             assert T.is_cuda and okc.is_cuda and T.dtype == torch.float64
             out = torch.zeros_like(T)
+            _torch_ready(out)
             tp, op_, up, mem = C.c_void_p(T.data_ptr()), C.c_void_p(okc.data_ptr()), C.c_void_p(out.data_ptr()), MEM_DEVICE
         self._check(self.lib.svo_chain_relative(self.h, tp, op_, int(T.shape[0]), p0, up, mem))
         return out                      # device tensors: complete in stream order on the context's stream

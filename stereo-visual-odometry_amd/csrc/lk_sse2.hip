@@ -1,0 +1,520 @@
+// lk_sse2.hip -- the pyramidal LK tracker of lk.hip with the five sums A11, A12, A22, b1, b2 accumulated in
+// FLOAT, in the order of upstream's x86 build (svo_config.lk_accum = SVO_LK_ACCUM_SSE2).
+//
+// Why: the reference's four cv::calcOpticalFlowPyrLK calls (src/tracking.cpp:593-618) run an OpenCV 3 whose
+// accumulators are float (acctype = itemtype = float outside the Tegra build) and whose CV_SSE2 block fixes the
+// order of the additions: oracle/lk.c restates that order (orc_lk_set_accum(2)), and lk.hip's exact integer sums
+// (canonical choice C0) differ from it in the last bits of 12 % of the track coordinates --
+// enough to move RANSAC's inlier set on one pair in seven.  This kernel reproduces the x86 order bit for bit:
+//   A (per level):   four float lanes q = x & 3 over x = 0..19, rows in order:  qA[q] += fx * fy   (105 terms a lane)
+//                    + a scalar tail x = 20:  iA += (float)(ix * iy)  (21 terms);   A = tail + (((q0 + q1) + q2) + q3)
+//   b (per iteration): _mm_madd_epi16 pairs (k, k + 4) of every group of eight pixels, x = 0..15:
+//                    qb0 = [bx(0,4) by(0,4) bx(1,5) by(1,5)], qb1 = [bx(2,6) by(2,6) bx(3,7) by(3,7)], each lane
+//                    += (float)(int32 pair sum) over rows and the two groups (42 terms a lane);  scalar tail x = 16..20:
+//                    ib += (float)(diff * I_x) in raster order (105 terms);  bb = qb0 + qb1;  b1 = tail1 + (bb0 + bb2),
+//                    b2 = tail2 + (bb1 + bb3).
+// A float sum in a fixed order is a SERIAL chain: it cannot be reduced over the lanes.  What can be shared is the
+// instruction stream: the wave still tracks four points ("slots", lk.hip), the 63 pixel lanes of a slot produce the
+// TERMS in parallel (exact int32 products / pair sums, converted once), write them to LDS in chain order, and then
+// every chain of all four slots runs in its own lane -- 4 x (8 + 2) chains for b, 4 x (12 + 3) for A -- through ONE
+// loop of 105 dependent v_add_f32 fed by ds_read_b128.  Pixel ownership follows the SSE groups: lane (row, seg)
+// owns window row `row`, columns 8 seg .. 8 seg + 7 (seg 2: the five tail columns 16..20), so a madd pair (k, k + 4)
+// is ONE v_dot2_i32_i16 of packed (diff_k, diff_k+4) x (Ix_k, Ix_k+4) inside a lane.
+// Everything else -- tiles as row-pair column words, packed Scharr on the fly, weights, control flow, the circular
+// chain of four calls, the keep predicate -- is lk.hip's, and so are the fixed-point pixel values (integers: exact).
+//
+// One wave per workgroup (no barrier anywhere): 22 KB of LDS per wave (13 KB tiles + 9 KB chain staging), seven
+// waves per CU.  Costs about twice the exact kernel per iteration.
+#include "lk_common.h"
+
+namespace svo {
+
+// b staging of one slot (dwords): 8 lane chains S[c][t], c = 2 k + (x|y), t = 2 row + group (42 terms, stride 44),
+// then 2 tail chains T[x|y][t], t = 5 row + i (105 terms, stride 108).  The A staging (per level, before the
+// iterations) reuses the area: patch words (Ix | Iy << 16) W[q][t], t = 5 row + (x >> 2) (105 words, stride 108),
+// then the 21 tail words (x = 20).
+constexpr int kSStride = 44, kTStride = 108, kTBase = 8 * kSStride, kStageDw = kTBase + 2 * kTStride;   // 568
+constexpr int kAqStride = 108, kAtBase = 4 * kAqStride;                                                 // 432 + 21 <= 568
+constexpr int kLdsDwSse2 = kLdsDwPerWave + kSlots * kStageDw;                                           // 5520 dwords
+constexpr int kDumpB = 43, kDumpA = 105;     // entries no chain adds: padding of S chain 0 / of every W[q]
+static_assert(kStageDw % 4 == 0 && kSStride % 4 == 0 && kTStride % 4 == 0 && kTBase % 4 == 0 && kLdsDwPerWave % 4 == 0,
+              "chain reads are 16-byte loads");
+
+typedef uint32_t __attribute__((address_space(3))) lds_u32;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(3))) lds_cf32x4;
+typedef const u32x4 __attribute__((address_space(3))) lds_cu32x4;
+
+// per-lane constants: the pixel role (row, seg) and the chain role (c = lane & 15 of row `slot`)
+struct Sse2Lane {
+    int row, seg;
+    uint32_t onmask;        // all ones in the 63 pixel lanes
+    uint32_t pmask;         // mask of the patch pairs m = 1..3: seg 2 owns pixels 0..4 only (high halves = pixels 5..7 vanish)
+    bool seg2;
+    uint32_t qoff;          // byte offset of the lane's first I-tile word inside a slot tile
+    uint32_t joff;          // ... of its first J-tile word
+    uint32_t wb[10];        // b term j of slot 0 goes to LDS byte address wb[j]
+    uint32_t wa_lo, wa_hi[4];   // patch word i < 4 goes to wa_lo + (i * kAqStride) * 4, word 4 + i to wa_hi[i]
+    uint32_t cb, ca;        // chain read addresses (b, A) of this lane's chain, the lane's slot included
+    uint32_t selA;          // v_perm selector that puts the two factors of this lane's A sum side by side
+    bool b_tail, a_tail;
+};
+
+__device__ __forceinline__ void lds_store(uint32_t byte_addr, uint32_t v) { *(lds_u32 *)(size_t)byte_addr = v; }
+
+__device__ __forceinline__ Sse2Lane make_lane(int lane, uint32_t lds_base)
+{
+    Sse2Lane L;
+    L.row = min(lane / 3, kWin - 1); L.seg = lane - (lane / 3) * 3;
+    const bool on = lane < 63;
+    L.onmask = on ? ~0u : 0u;
+    L.seg2 = L.seg == 2;
+    L.pmask = L.seg2 ? 0x0000FFFFu : ~0u;
+    L.qoff = (uint32_t)((L.seg * 8 * kQColDw + L.row) * 4);
+    L.joff = (uint32_t)((L.seg * 8 * kJColDw + L.row) * 4);
+    const uint32_t stage0 = lds_base + kLdsDwPerWave * 4;
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+        int e = kDumpB;
+        if (on && !L.seg2 && j < 8) e = j * kSStride + 2 * L.row + L.seg;
+        if (on && L.seg2) e = kTBase + (j & 1) * kTStride + 5 * L.row + (j >> 1);
+        L.wb[j] = stage0 + (uint32_t)e * 4;
+    }
+    // patch words: pixel i (x = 8 seg + i) -> W[x & 3][5 row + (x >> 2)];  x = 20 -> tail word `row`;  x > 20: nowhere
+    L.wa_lo = stage0 + (uint32_t)(on ? 5 * L.row + 2 * L.seg : kDumpA) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int e = kDumpA;
+        if (on && !L.seg2) e = i * kAqStride + 5 * L.row + 2 * L.seg + 1;
+        if (on && L.seg2 && i == 0) e = kAtBase + L.row;
+        L.wa_hi[i] = stage0 + (uint32_t)e * 4;
+    }
+    const int c = lane & 15;
+    const uint32_t stage_s = stage0 + (uint32_t)((lane >> 4) * kStageDw) * 4;
+    L.b_tail = c == 8 || c == 9;
+    L.cb = stage_s + (uint32_t)(c < 8 ? c * kSStride : (L.b_tail ? kTBase + (c - 8) * kTStride : 0)) * 4;
+    L.a_tail = c >= 12;
+    L.ca = stage_s + (uint32_t)(c < 12 ? (c & 3) * kAqStride : kAtBase) * 4;
+    const int type = c < 12 ? c >> 2 : (c - 12) % 3;          // 0: Ix Ix, 1: Ix Iy, 2: Iy Iy
+    L.selA = type == 0 ? 0x01000100u : (type == 1 ? 0x03020100u : 0x03020302u);
+    return L;
+}
+
+// value of lane `j` of this lane's row of 16
+__device__ __forceinline__ float row_lane(float v, int lane, int j)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 48) + j) * 4, __float_as_int(v)));
+}
+
+// ---- phase A for one slot: the lane's 8 patch pixels from the staged I tile (cf. patch_slot in lk.hip) ------------
+// Tile bytes j = 0..10 of the lane = image columns ipx - 1 + 8 seg + j.  Outputs: the patch packed as madd pairs
+// (pixel m | pixel m + 4 << 16, m = 0..3) -- I with 5 fractional bits, Ix, Iy -- and the 8 patch words Ix | Iy << 16
+// of the A chains.  Pixels right of column 20 (seg 2, i > 4) are computed from whatever lies beside the tile and
+// masked out of the pairs; their patch words go to a dump entry.
+template <bool EDGE>
+__device__ __forceinline__ void patch_slot8(uint32_t tile_addr, const Sse2Lane &L, uint32_t Wau, uint32_t Wbu, int ipx,
+                                            int ipy, int w, int h, uint32_t (&IvP)[4], uint32_t (&IxP)[4],
+                                            uint32_t (&IyP)[4], uint32_t (&Aw)[8])
+{
+    const uint32_t Wa = Wau & L.onmask, Wb = Wbu & L.onmask;
+    uint32_t Q01[11], Q12[11], Q23[11];
+    {
+        lds_cu32 *q0 = (lds_cu32 *)(size_t)(tile_addr + L.qoff);
+#pragma unroll
+        for (int j = 0; j < 11; j++) { Q01[j] = q0[j * kQColDw]; Q12[j] = q0[j * kQColDw + 1]; Q23[j] = q0[j * kQColDw + 2]; }
+    }
+    uint32_t T0[11], T1[11];
+    const u16x2 k12 = {12, 12}, k40 = {40, 40};
+#pragma unroll
+    for (int j = 0; j < 11; j++) {
+        T0[j] = as_u32((as_u16x2(Q01[j]) + as_u16x2(Q23[j])) * k12 + as_u16x2(Q12[j]) * k40);       // 4 t0
+        T1[j] = as_u32(as_u16x2(Q23[j]) - as_u16x2(Q01[j]));                                          // t1
+    }
+    uint32_t DX[9], DY[9];
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        DX[c] = as_u32(as_u16x2(T0[c + 2]) - as_u16x2(T0[c]));                                        // 4 dx
+        DY[c] = as_u32((as_u16x2(T1[c]) + as_u16x2(T1[c + 2])) * k12 + as_u16x2(T1[c + 1]) * k40);    // 4 dy
+    }
+    if (EDGE) {                                  // the derivative image's border is BORDER_CONSTANT 0
+        const int gyA = ipy + L.row, gyB = gyA + 1;
+        const uint32_t rows = ((gyA >= 0 && gyA < h) ? 0x0000FFFFu : 0u) | ((gyB >= 0 && gyB < h) ? 0xFFFF0000u : 0u);
+#pragma unroll
+        for (int c = 0; c < 9; c++) {
+            const int gx = ipx + L.seg * 8 + c;
+            const uint32_t mk = (gx >= 0 && gx < w) ? rows : 0u;
+            DX[c] &= mk; DY[c] &= mk;
+        }
+    }
+    int iv[8], ix[8], iy[8];                     // ix, iy: value << 16 | rounding residue
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        iv[k] = dot2(Q12[k + 2], Wb, dot2_k(Q12[k + 1], Wa, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+        ix[k] = dot2(DX[k + 1], Wb, dot2_k(DX[k], Wa, 1 << (W_BITS + 1)));
+        iy[k] = dot2(DY[k + 1], Wb, dot2_k(DY[k], Wa, 1 << (W_BITS + 1)));
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        IvP[m] = perm_b32((uint32_t)iv[m + 4], (uint32_t)iv[m], 0x05040100u);
+        IxP[m] = perm_b32((uint32_t)ix[m + 4], (uint32_t)ix[m], 0x07060302u);      // the two high halves
+        IyP[m] = perm_b32((uint32_t)iy[m + 4], (uint32_t)iy[m], 0x07060302u);
+        if (m > 0) { IxP[m] &= L.pmask; IyP[m] &= L.pmask; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) Aw[i] = perm_b32((uint32_t)iy[i], (uint32_t)ix[i], 0x07060302u);   // Ix | Iy << 16
+}
+
+// ---- one iteration's pixel work for one slot: the lane's ten b terms as floats -----------------------------------
+// seg 0, 1:  v[2 k + xy] = (float)(diff_k I_k + diff_k+4 I_k+4)  -- the int32 lanes of _mm_madd_epi16, converted as
+//            _mm_cvtepi32_ps does (round to nearest even);  v[8], v[9] unused
+// seg 2:     v[2 i + xy] = (float)(diff_i I_i) for the tail pixels i = 0..3 (x = 16..19), v[8 + xy] for i = 4 (x = 20)
+__device__ __forceinline__ void mismatch_slot8(const uint32_t (&C)[9], uint32_t Wa, uint32_t Wb, const uint32_t (&IvP)[4],
+                                               const uint32_t (&IxP)[4], const uint32_t (&IyP)[4], int vround, bool seg2,
+                                               float (&v)[10])
+{
+    int d[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = dot2(C[k + 1], Wb, dot2_sv(C[k], Wa, vround));
+    uint32_t df[4];                              // diff = J - I of pixels (m, m + 4): the J samples are the high halves of d
+    int tx[4], ty[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        df[m] = as_u32(as_u16x2(perm_b32((uint32_t)d[m + 4], (uint32_t)d[m], 0x07060302u)) - as_u16x2(IvP[m]));
+        tx[m] = dot2_0(df[m], IxP[m]);
+        ty[m] = dot2_0(df[m], IyP[m]);
+    }
+    const uint32_t d0 = df[0] & 0xFFFFu;         // pixel 0 alone (seg 2: x = 16), pixel 4 = pair - pixel 0 (x = 20)
+    const int lx = dot2_0(d0, IxP[0]), ly = dot2_0(d0, IyP[0]);
+    v[0] = (float)(seg2 ? lx : tx[0]); v[1] = (float)(seg2 ? ly : ty[0]);
+#pragma unroll
+    for (int m = 1; m < 4; m++) { v[2 * m] = (float)tx[m]; v[2 * m + 1] = (float)ty[m]; }
+    v[8] = (float)(tx[0] - lx); v[9] = (float)(ty[0] - ly);
+}
+
+// ---- the serial sums: every chain lane adds its chain's terms in order -------------------------------------------
+// b: lanes c = 0..7 of a row run the 42-term lane chains, c = 8, 9 the 105-term tails (the other lanes add garbage)
+__device__ __forceinline__ float chain_b(const Sse2Lane &L)
+{
+    lds_cf32x4 *p = (lds_cf32x4 *)(size_t)L.cb;
+    float acc = 0.f, acc42 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 27; t++) {
+        const f32x4 q = p[t];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int idx = 4 * t + e;
+            if (idx == 42) acc42 = acc;
+            if (idx < 105) acc += q[e];
+        }
+    }
+    return L.b_tail ? acc : acc42;
+}
+// A: lanes c = 0..11 = (sum type c >> 2, SSE lane c & 3) 105 terms, c = 12..14 the 21-term tails.  A term is the
+// product of two 16-bit patch values: exact in float (< 2^24), so _mm_mul_ps(fx, fy) and (float)(ix * iy) coincide.
+__device__ __forceinline__ float chain_a(const Sse2Lane &L)
+{
+    lds_cu32x4 *p = (lds_cu32x4 *)(size_t)L.ca;
+    float acc = 0.f, acc21 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 27; t++) {
+        const u32x4 q = p[t];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int idx = 4 * t + e;
+            if (idx == 21) acc21 = acc;
+            if (idx < 105) {
+                const uint32_t f = perm_b32(q[e], q[e], L.selA);
+                acc += (float)(int)(short)(f & 0xFFFFu) * (float)((int)f >> 16);
+            }
+        }
+    }
+    return L.a_tail ? acc21 : acc;
+}
+
+// One cv::calcOpticalFlowPyrLK call for the wave's four points (cf. lk_call4 in lk.hip; control values are per
+// lane = per slot lane >> 4).
+__device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *slotI, const uint8_t *slotJ, float2 prevPt,
+                                              float2 &outPt, int &status, bool live, uint32_t *lds, int lane,
+                                              const Sse2Lane &L)
+{
+    const float half = 10.f;                     // (winSize - 1) * 0.5
+    const float FLT_SCALE = 1.f / (1 << 20);
+    uint32_t IvP[kSlots][4], IxP[kSlots][4], IyP[kSlots][4];
+    int q_pr[3], q_dc4[3], jq_dst[3];            // staging item lane + 64 t = row pair * 7 + dword column
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int i = lane + 64 * t;
+        q_pr[t] = i / 7; q_dc4[t] = 4 * (i - q_pr[t] * 7); jq_dst[t] = q_dc4[t] * kJColDw + q_pr[t];
+    }
+    const uint32_t lds_base = (uint32_t)(size_t)(lds_cu32 *)lds;
+    int vround = 1 << (W_BITS - 5 - 1 + 7);
+    asm volatile("" : "+v"(vround));
+    status = 1;
+    float nx = 0.f, ny = 0.f;
+    uint32_t rI[kSlots][3][2];
+    auto request_I = [&](int level) {
+        const int w = g.w[level], h = g.h[level], pitch = g.pitch[level];
+        const float lscale = 1.f / (float)(1 << level);
+        const int ipx = cv_floor(prevPt.x * lscale - half), ipy = cv_floor(prevPt.y * lscale - half);
+        const unsigned long long m = __ballot(live && !window_oob(ipx, ipy, w, h));
+        const int x0 = (ipx - 1) & ~3;
+        uint32_t src[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) src[t] = (uint32_t)(q_pr[t] * pitch + q_dc4[t]);
+#pragma unroll
+        for (int s = 0; s < kSlots; s++) {
+            if (!((m >> (16 * s)) & 1ull)) continue;
+            const int x0s = __builtin_amdgcn_readlane(x0, 16 * s), ipys = __builtin_amdgcn_readlane(ipy, 16 * s);
+            tile_loads(rI[s], slotI, slotI + pitch, (uint32_t)(g.origin[level] + (ipys - 1) * pitch + x0s), src, lane, kQPairs * 7);
+        }
+    };
+    request_I(g.nlevels - 1);
+    for (int level = g.nlevels - 1; level >= 0; --level) {
+        const int w = g.w[level], h = g.h[level], pitch = g.pitch[level];
+        const float lscale = 1.f / (float)(1 << level);
+        float px = prevPt.x * lscale, py = prevPt.y * lscale;
+        if (level == g.nlevels - 1) { nx = px; ny = py; }
+        else { nx = nx * 2.f; ny = ny * 2.f; }
+        px -= half; py -= half;
+        const int ipx = cv_floor(px), ipy = cv_floor(py);
+        const bool oob = window_oob(ipx, ipy, w, h);
+        if (live && oob && level == 0) status = 0;
+        bool lvl_on = live && !oob;
+        const PackedWeights wt = bilinear_weights(px - (float)ipx, py - (float)ipy);
+        const uint32_t WIa = wt.Wa, WIb = wt.Wb;
+        const int x0 = (ipx - 1) & ~3;
+        const int offI = (ipx - 1) - x0;
+        float qx = nx - half, qy = ny - half;       // nextPt - halfWin
+        int tx0 = -(1 << 20), ty0 = 0;              // no J tile staged
+        {
+            const int inx = cv_floor(qx), iny = cv_floor(qy);
+            if (lvl_on && !window_oob(inx, iny, w, h)) { tx0 = inx - kJMargin; ty0 = iny - kJMargin; }
+        }
+        const unsigned long long m_on = __ballot(lvl_on), m_j = __ballot(tx0 != -(1 << 20));
+        uint32_t q_src[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) q_src[t] = (uint32_t)(q_pr[t] * pitch + q_dc4[t]);
+        uint32_t rJ[kSlots][3][2];
+        // ---- I tiles as row-pair column words (the J tiles take their place afterwards)
+#pragma unroll
+        for (int s = 0; s < kSlots; s++) {
+            if (!((m_on >> (16 * s)) & 1ull)) continue;
+            uint32_t *qt = lds + s * kQTileDw;
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                if (lane + 64 * t < kQPairs * 7) {
+                    const uint32_t top = rI[s][t][0], bot = rI[s][t][1];
+                    uint32_t *d = qt + jq_dst[t];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) d[c * kQColDw] = perm_b32(bot, top, 0x0c040c00u + 0x00010001u * c);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < kSlots; s++) {
+            if (!((m_j >> (16 * s)) & 1ull)) continue;
+            const int tx0s = __builtin_amdgcn_readlane(tx0, 16 * s), ty0s = __builtin_amdgcn_readlane(ty0, 16 * s);
+            tile_loads(rJ[s], slotJ, slotJ + pitch, (uint32_t)(g.origin[level] + ty0s * pitch + tx0s), q_src, lane, kJPairs * 7);
+        }
+        wave_lds_fence();
+        // ---- patches; their words Ix | Iy << 16 go to the chain staging in the order of the A chains
+#pragma unroll
+        for (int s = 0; s < kSlots; s++) {
+            if (!((m_on >> (16 * s)) & 1ull)) continue;
+            const uint32_t qaddr = lds_base + (uint32_t)((s * kQTileDw + __builtin_amdgcn_readlane(offI, 16 * s) * kQColDw) * 4);
+            const uint32_t W01s = __builtin_amdgcn_readlane(WIa, 16 * s), W23s = __builtin_amdgcn_readlane(WIb, 16 * s);
+            const int ipxs = __builtin_amdgcn_readlane(ipx, 16 * s), ipys = __builtin_amdgcn_readlane(ipy, 16 * s);
+            uint32_t Aw[8];
+            if (__builtin_expect(ipxs < 0 || ipxs + kWin >= w || ipys < 0 || ipys + kWin >= h, 0))
+                patch_slot8<true>(qaddr, L, W01s, W23s, ipxs, ipys, w, h, IvP[s], IxP[s], IyP[s], Aw);
+            else
+                patch_slot8<false>(qaddr, L, W01s, W23s, ipxs, ipys, w, h, IvP[s], IxP[s], IyP[s], Aw);
+            const uint32_t so = (uint32_t)(s * kStageDw * 4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                lds_store(L.wa_lo + so + (uint32_t)(i * kAqStride * 4), Aw[i]);
+                lds_store(L.wa_hi[i] + so, Aw[4 + i]);
+            }
+        }
+        wave_lds_fence();                        // the patch words are complete; the J tiles reuse the I tiles' LDS
+#pragma unroll
+        for (int s = 0; s < kSlots; s++) {
+            if (!((m_j >> (16 * s)) & 1ull)) continue;
+            tile_store_j(lds + s * kJTileDw, rJ[s], jq_dst, lane);
+        }
+        float A11, A12, A22, D;
+        {
+            const float r = chain_a(L);
+            float q[15];
+#pragma unroll
+            for (int j = 0; j < 15; j++) q[j] = row_lane(r, lane, j);
+            // iA += A_buf[0] + A_buf[1] + A_buf[2] + A_buf[3] after the scalar tail went into iA
+            A11 = (q[12] + (((q[0] + q[1]) + q[2]) + q[3])) * FLT_SCALE;
+            A12 = (q[13] + (((q[4] + q[5]) + q[6]) + q[7])) * FLT_SCALE;
+            A22 = (q[14] + (((q[8] + q[9]) + q[10]) + q[11])) * FLT_SCALE;
+        }
+        wave_lds_fence();                        // the iterations' b terms overwrite the patch words
+        D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
+                             (float)(2 * kWin * kWin);
+        const bool degenerate = minEig < 0.001f || D < 1.1920929e-07f;
+        if (lvl_on && degenerate && level == 0) status = 0;
+        lvl_on = lvl_on && !degenerate;
+        D = 1.f / D;
+
+        if (level > 0) request_I(level - 1);
+        float pdx = 0.f, pdy = 0.f;
+        bool it_on = lvl_on;
+        for (int j = 0; j < kLkMaxIter; j++) {
+            if (!__any(it_on)) break;
+            const int inx = cv_floor(qx), iny = cv_floor(qy);
+            if (it_on && window_oob(inx, iny, w, h)) {
+                if (level == 0) status = 0;
+                it_on = false;
+            }
+            const PackedWeights wj = bilinear_weights(qx - (float)inx, qy - (float)iny);
+            const uint32_t Wa = wj.Wa, Wb = wj.Wb;
+            int cx = inx - tx0, cy = iny - ty0;
+            const bool restage = it_on && ((unsigned)cx > (unsigned)(2 * kJMargin) || (unsigned)cy > (unsigned)(2 * kJMargin));
+            if (restage) { tx0 = inx - kJMargin; ty0 = iny - kJMargin; cx = kJMargin; cy = kJMargin; }
+            const int joff = ((int)__umul24((unsigned)cx, kJColDw) + cy + (lane >> 4) * kJTileDw) * 4;
+            const unsigned long long m_it = __ballot(it_on), m_rs = __ballot(restage);
+            if (__builtin_expect(m_rs != 0, 0)) {     // a window drifted out of its tile
+#pragma unroll
+                for (int s = 0; s < kSlots; s++) {
+                    if (!((m_rs >> (16 * s)) & 1ull)) continue;
+                    const int tx0s = __builtin_amdgcn_readlane(tx0, 16 * s), ty0s = __builtin_amdgcn_readlane(ty0, 16 * s);
+                    uint32_t r[3][2];
+                    tile_loads(r, slotJ, slotJ + pitch, (uint32_t)(g.origin[level] + ty0s * pitch + tx0s), q_src, lane, kJPairs * 7);
+                    tile_store_j(lds + s * kJTileDw, r, jq_dst, lane);
+                }
+                wave_lds_fence();
+            }
+#pragma unroll
+            for (int s = 0; s < kSlots; s++) {
+                if (!((m_it >> (16 * s)) & 1ull)) continue;
+                const int joffs = __builtin_amdgcn_readlane(joff, 16 * s);
+                const uint32_t Was = __builtin_amdgcn_readlane(Wa, 16 * s), Wbs = __builtin_amdgcn_readlane(Wb, 16 * s);
+                lds_cu32 *pj = (lds_cu32 *)(size_t)(lds_base + (uint32_t)joffs + L.joff);
+                uint32_t C[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) C[k] = pj[k * kJColDw];
+                float v[10];
+                mismatch_slot8(C, Was, Wbs, IvP[s], IxP[s], IyP[s], vround, L.seg2, v);
+                const uint32_t so = (uint32_t)(s * kStageDw * 4);
+#pragma unroll
+                for (int t = 0; t < 10; t++) lds_store(L.wb[t] + so, __float_as_uint(v[t]));
+            }
+            wave_lds_fence();
+            float b1f, b2f;
+            {
+                const float r = chain_b(L);
+                // bbuf = qb0 + qb1; ib1 += bbuf[0] + bbuf[2]; ib2 += bbuf[1] + bbuf[3]  (the tails are already in ib)
+                const float bb0 = row_lane(r, lane, 0) + row_lane(r, lane, 4), bb1 = row_lane(r, lane, 1) + row_lane(r, lane, 5),
+                            bb2 = row_lane(r, lane, 2) + row_lane(r, lane, 6), bb3 = row_lane(r, lane, 3) + row_lane(r, lane, 7);
+                b1f = (row_lane(r, lane, 8) + (bb0 + bb2)) * FLT_SCALE;
+                b2f = (row_lane(r, lane, 9) + (bb1 + bb3)) * FLT_SCALE;
+            }
+            wave_lds_fence();                    // the next iteration's terms overwrite these
+            const float dlx = (A12 * b2f - A22 * b1f) * D;
+            const float dly = (A12 * b1f - A11 * b2f) * D;
+            const float dd = dlx * dlx + dly * dly;
+            bool conv = dd <= 0.9999e-4f;
+            if (__builtin_expect(__any(it_on && !conv && dd < 1.0001e-4f), 0)) {
+                asm volatile("" ::: "memory");
+                conv = (double)dlx * (double)dlx + (double)dly * (double)dly <= 0.01 * 0.01;
+            }
+            if (it_on) {
+                qx += dlx; qy += dly;
+                nx = qx + half; ny = qy + half;
+                if (conv) it_on = false;
+                else if (j > 0 && fabsf(dlx + pdx) <= 0.01f && fabsf(dly + pdy) <= 0.01f) {
+                    nx -= dlx * 0.5f; ny -= dly * 0.5f;
+                    it_on = false;
+                }
+                pdx = dlx; pdy = dly;
+            }
+        }
+        if (live && status && level == 0) {
+            int fx = cv_floor(nx - half), fy = cv_floor(ny - half);
+            if (window_oob(fx, fy, w, h)) status = 0;
+        }
+    }
+    outPt = make_float2(nx, ny);
+}
+
+// Grid: ONE wave per workgroup, a.gx WAVES per batch item walking the item's points in strides of a.gx * 4 slots;
+// the same XCD-aware item mapping as lk_kernel (consecutive workgroup ids go round the 8 XCDs).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lk_sse2_kernel(LkArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsDwSse2];
+    const int n_aware = (a.batch & ~7) * a.gx;
+    int b, wv;
+    if ((int)blockIdx.x < n_aware) {
+        const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+        b = (slot_id / a.gx) * 8 + xcd; wv = slot_id % a.gx;
+    } else {
+        const int r = blockIdx.x - n_aware;
+        b = (a.batch & ~7) + r / a.gx; wv = r % a.gx;
+    }
+    const int lane = threadIdx.x & 63;
+    const int slot = lane >> 4;
+    int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
+    n = min(n, a.cap);
+    const Sse2Lane L = make_lane(lane, (uint32_t)(size_t)(lds_cu32 *)lds);
+    int spw = kSlots;
+    if (a.spread) spw = min(kSlots, max(1, (n + a.gx - 1) / a.gx));
+    for (int first = wv * spw; first < n; first += a.gx * spw) {
+        const int idx = first + slot;
+        const bool valid = slot < spw && idx < n;
+        const bool writer = valid && lane == 16 * slot;
+        const int64_t po = (int64_t)b * a.pts_stride + (valid ? idx : first);
+        const float2 p0 = a.pts_in[po];
+        float2 cur = p0, nxt;
+        bool outside = p0.x < 0 || p0.y < 0, bad = false, noepi = false;
+        bool live = valid;
+        float prev_y = p0.y;
+#pragma nounroll
+        for (int c = 0; c < a.ncalls; c++) {
+            const uint8_t *sI = a.prev[c] + (int64_t)b * a.slot_stride;
+            const uint8_t *sJ = a.next[c] + (int64_t)b * a.slot_stride;
+            int st;
+            lk_call4_sse2(a.g, sI, sJ, cur, nxt, st, live, lds, lane, L);
+            if (writer && live) {
+                a.pts_out[c][po] = nxt;
+                a.status[c][po] = (uint8_t)st;
+            }
+            // Tracking::deleteBadmatchFeatures terms, as in lk_kernel (src/tracking.cpp:619-660)
+            if (live) {
+                outside = outside || nxt.x < 0 || nxt.y < 0;
+                bad = bad || st == 0;
+                if (c == 0 || c == 2) noepi = noepi || (double)fabsf(prev_y - nxt.y) > a.match_err;
+                prev_y = nxt.y;
+                cur = nxt;
+            }
+            if (a.ncalls == 4 && (outside || bad || noepi)) live = false;
+            if (!__any(live)) break;
+        }
+        if (a.ncalls == 4 && writer) a.keep[po] = !(outside || bad || noepi);
+        wave_lds_fence();
+    }
+}
+
+void launch_lk_sse2(const LkArgs &a0, int batch, int max_pts, hipStream_t st)
+{
+    if (max_pts <= 0 || batch <= 0) return;
+    const int waves = (max_pts + kSlots - 1) / kSlots;      // one pass over the capacity
+    LkArgs a = a0;
+    a.gx = waves < 768 ? waves : 768;
+    a.spread = 0;
+    if (batch < 4) {                             // latency shape: seven single-wave workgroups per CU are resident
+        const int room = 1792 / batch;
+        a.gx = max_pts < room ? max_pts : room;
+        a.spread = 1;
+    }
+    a.batch = batch;
+    hipLaunchKernelGGL(lk_sse2_kernel, dim3(batch * a.gx), dim3(64), 0, st, a);
+}
+
+}  // namespace svo

@@ -109,6 +109,7 @@ static int run_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, con
     for (int i = 0; i < 4; i++) { a.pts_out[i] = ctx->pts_out[i]; a.status[i] = ctx->status[i]; }
     a.keep = ctx->keep;
     a.match_err = ctx->cfg.feature_match_error; a.match_err_f = (float)ctx->cfg.feature_match_error;
+    a.accum = ctx->cfg.lk_accum;
     launch_lk(a, n_pairs, cap, ctx->stream);
     mark(ctx, kTLk);
     // the previous batch's pose stage (overlap mode) still reads the compacted lists / 3-D points

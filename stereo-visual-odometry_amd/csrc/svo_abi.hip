@@ -91,6 +91,7 @@ extern "C" void svo_default_config(svo_config *cfg, int width, int height)
     cfg->orb_nlevels = 8;                   // :91
     cfg->orb_ini_th = 20;                   // :90
     cfg->orb_min_th = 7;                    // :89
+    cfg->lk_accum = SVO_LK_ACCUM_EXACT;     // the canonical recipe; SVO_LK_ACCUM_SSE2 = an x86 OpenCV build's float order
 }
 
 static void free_all(svo_ctx *c)
@@ -129,6 +130,10 @@ extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
     if (cfg->width < 32 || cfg->height < 32 || cfg->max_keypoints < 64 || cfg->max_batch < 1 ||
         cfg->num_slots < 4 || cfg->width > 16384 || cfg->height > 16384)
         return SVO_ERR_ARG;
+    if (cfg->lk_accum != SVO_LK_ACCUM_EXACT && cfg->lk_accum != SVO_LK_ACCUM_SSE2) {
+        fprintf(stderr, "svo_create: lk_accum = %d is neither SVO_LK_ACCUM_EXACT nor SVO_LK_ACCUM_SSE2\n", cfg->lk_accum);
+        return SVO_ERR_ARG;
+    }
     if (cfg->num_features_tracking < 5) {
         // with fewer than 5 tracks required, a pair with exactly 4 would reach cv::solvePnPRansac's
         // npoints == 4 branch (P3P kernel), which this library does not implement: refuse the
@@ -413,6 +418,7 @@ static void fill_lk_common(svo_ctx *ctx, LkArgs &a, int n)
     a.n_pts = nullptr; a.n_fixed = n; a.cap = n;
     a.match_err = ctx->cfg.feature_match_error;
     a.match_err_f = (float)ctx->cfg.feature_match_error;
+    a.accum = ctx->cfg.lk_accum;
 }
 
 extern "C" int svo_lk_track(svo_ctx *ctx, int slot_prev, int slot_next, const svo_pt2f *prev_pts, int n,
