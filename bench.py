@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--mode", choices=["lk", "orb"], default="lk",
                     help="lk = BASELINE config #2 (FAST+LK, the quoted metric); orb = config #3 (ORB extractor + "
                          "descriptor match path, the reference's shipped default track_mode)")
+    ap.add_argument("--lk-accum", choices=["exact", "sse2"], default="exact",
+                    help="order of the float sums inside the LK tracker (svo_config.lk_accum): exact = the canonical integer sums, "
+                         "sse2 = an x86 OpenCV 3 build's lane order (bit-identical to oracle/lk.c mode 2)")
     ap.add_argument("--shard", choices=["sequences", "pairs"], default="sequences")
     ap.add_argument("--config5", action="store_true", help="KITTI 00-07 sequence lengths dealt to the ranks (see the docstring)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
@@ -129,7 +132,7 @@ def launch_ranks(args):
 def kernel_source_hash():
     """sha256 over the sources lk_kernel is built from: profile-derived numbers are only valid for them."""
     h = hashlib.sha256()
-    for f in ("lk.hip", "svo_device.h", "svo_kernels.h"):
+    for f in ("lk.hip", "lk_common.h", "svo_device.h", "svo_kernels.h"):
         with open(os.path.join(entry.PKG_DIR, "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -303,6 +306,8 @@ def main():
     mode_kw = {}
     if args.mode == "orb":       # config/default.yaml:75,87-93: ORB_stereof2f_pnp, minmove 0.05, maxmove 10
         mode_kw = dict(track_mode=pkg.MODE_ORB, min_move2=0.05 ** 2, max_move2=10.0 ** 2)
+    if args.lk_accum == "sse2":
+        mode_kw["lk_accum"] = pkg.LK_ACCUM_SSE2
     ctx = pkg.Context(W, H, device=local_rank, max_batch=B, P1=P1, P2=P2, **mode_kw)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)            # launches, events and the RCCL gather share one stream

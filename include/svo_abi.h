@@ -88,7 +88,11 @@ typedef struct {
            x = 0..15 + scalar tail for b).  Bit-identical to oracle/lk.c's accumulation mode 2; about 2x the
            LK kernel time.  YAML key `lk_accum: exact | sse2`. */
     int32_t lk_accum;
-    int32_t _reserved;
+    /* ABI v6.  LK mode, fused entry points only (svo_add_frame / svo_track_*): 0 = track every cv::FAST corner, as
+       the reference does (src/tracking.cpp:94-113); N > 0 = keep the N highest-response corners of every left image
+       (ties: raster order first; the kept corners stay in raster order) -- BASELINE config #4's "2000 features per
+       frame".  n_prev_kps / n_cur_kps then report the kept counts.  YAML key `fast_keep_strongest`. */
+    int32_t fast_keep_strongest;
 } svo_config;
 
 #define SVO_MODE_LK  0
@@ -114,6 +118,7 @@ typedef struct {                    /* one Tracking::AddFrame step (LK mode) */
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
 int         svo_abi_version(void);
+int         svo_config_bytes(void);      /* sizeof(svo_config) of this build (ABI v6): a binding checks its own struct against it */
 void        svo_default_config(svo_config *cfg, int width, int height);   /* default.yaml + KITTI rig */
 int         svo_device_count(int *n);   /* HIP devices visible to this process (ABI v5): the multi-sequence runner deals
                                            sequences to them; SVO_ERR_HIP with *n = 0 when the runtime finds none */
@@ -253,6 +258,10 @@ int svo_collect_results(svo_ctx *ctx, svo_step_result *results, int n_pairs);
 int svo_get_frame_keypoints(svo_ctx *ctx, int side, svo_keypoint *kps, uint8_t *descriptors, int cap, int *n_out);
 int svo_get_last_tracks(svo_ctx *ctx, svo_pt2f *t1_left, svo_pt2f *t1_right, svo_pt2f *t2_right,
                         svo_pt2f *t2_left, uint8_t *inlier, int cap, int *n_out);
+/* ABI v6: the same for pair `pair` (0-based) of the most recent svo_track_batch / svo_track_uploaded(_async) launch --
+ * valid until the next launch on this context; waits for that batch's pose stage. */
+int svo_get_batch_tracks(svo_ctx *ctx, int pair, svo_pt2f *t1_left, svo_pt2f *t1_right, svo_pt2f *t2_right,
+                         svo_pt2f *t2_left, uint8_t *inlier, int cap, int *n_out);
 
 /* Serial prefix product of n inverse relative motions (svo_step_result.T_rel_inv, row-major 4x4),
  * skipping pairs with ok == 0:  poses_out[p] = pose0 * prod_{q <= p, ok[q]} T[q]  -- the

@@ -28,7 +28,7 @@ class Config(C.Structure):
                 ("P1", C.c_double * 12), ("P2", C.c_double * 12),
                 ("track_mode", C.c_int32), ("orb_nfeatures", C.c_int32), ("orb_scale_factor", C.c_float),
                 ("orb_nlevels", C.c_int32), ("orb_ini_th", C.c_int32), ("orb_min_th", C.c_int32),
-                ("lk_accum", C.c_int32), ("_reserved", C.c_int32)]
+                ("lk_accum", C.c_int32), ("fast_keep_strongest", C.c_int32)]
 
 
 MODE_LK, MODE_ORB = 0, 1
@@ -80,6 +80,9 @@ def load_library():
         raise SvoError(f"{path} is missing: run __graft_entry__.build() (hipcc) first; "
                        "this package has no CPU fallback")
     lib = C.CDLL(path)
+    if lib.svo_config_bytes() != C.sizeof(Config):
+        raise SvoError(f"{path}: svo_config is {lib.svo_config_bytes()} bytes, this binding's Config {C.sizeof(Config)} "
+                       "(stale build? run __graft_entry__.build())")
     lib.svo_last_error.restype = C.c_char_p
     lib.svo_last_error.argtypes = [C.c_void_p]
     lib.svo_create.argtypes = [C.POINTER(Config), C.c_int, C.POINTER(C.c_void_p)]
@@ -91,6 +94,7 @@ def load_library():
                                     C.c_void_p, C.c_void_p, C.c_int]
     lib.svo_get_frame_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     lib.svo_get_last_tracks.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int, C.POINTER(C.c_int)]
+    lib.svo_get_batch_tracks.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.POINTER(C.c_int)]
     lib.svo_chain_relative.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     lib.svo_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
     lib.svo_host_free.argtypes = [C.c_void_p, C.c_void_p]
@@ -482,6 +486,15 @@ class Context:
         self._check(self.lib.svo_get_frame_keypoints(self.h, int(side), C.c_void_p(kps.ctypes.data),
                                                      C.c_void_p(desc.ctypes.data) if with_descriptors else None, cap, C.byref(n)))
         return (kps[:n.value].copy(), desc[:n.value].copy()) if with_descriptors else kps[:n.value].copy()
+
+    def batch_tracks(self, pair, cap=65536):
+        """(t1_left, t1_right, t2_right, t2_left, inlier) of pair `pair` of the last track_batch launch."""
+        pts = [np.zeros((cap, 2), np.float32) for _ in range(4)]
+        inl = np.zeros(cap, np.uint8)
+        n = C.c_int(0)
+        self._check(self.lib.svo_get_batch_tracks(self.h, int(pair), *[C.c_void_p(p.ctypes.data) for p in pts],
+                                                  C.c_void_p(inl.ctypes.data), cap, C.byref(n)))
+        return [p[:n.value].copy() for p in pts] + [inl[:n.value].copy()]
 
     def last_tracks(self, cap=65536):
         """(t1_left, t1_right, t2_right, t2_left, inlier) of the pair last tracked by add_frame."""

@@ -271,6 +271,71 @@ __global__ __launch_bounds__(256) void fast_emit_kernel(FastArgs a)
     }
 }
 
+// svo_config.fast_keep_strongest (BASELINE config #4: "exactly N features per frame"): keeps the `keep` highest-response
+// corners of every image -- ties by raster order, i.e. np.argsort(-response, kind="stable")[:keep] -- IN PLACE and in
+// raster order.  Responses are the integer FAST scores (1..255): a 256-bin histogram gives the cut-off score t, every
+// corner above t stays and so do the first (keep - #above) corners AT t.  One workgroup per image walks the list in
+// chunks of 1024 (a chunk is read before anything is written, and the write positions never overtake the reads).
+__global__ __launch_bounds__(1024) void fast_keep_strongest_kernel(FastArgs a, int keep)
+{
+    __shared__ int hist[256];
+    __shared__ int wave_eq[16], wave_kp[16];
+    __shared__ int s_t, s_need_eq, s_eq_base, s_out_base;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = a.n_out[b];
+    if (n <= keep || n > a.cap) return;          // nothing to drop / over capacity: the pair fails as SVO_FAIL_CAPACITY anyway
+    float2 *xy = a.kp_xy + (int64_t)b * a.kp_stride;
+    float *resp = a.kp_resp + (int64_t)b * a.kp_stride;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[min(255, max(0, (int)resp[i]))], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int above = 0, t = 255;
+        for (; t > 0; t--) {                     // largest t with #(response >= t) >= keep
+            if (above + hist[t] >= keep) break;
+            above += hist[t];
+        }
+        s_t = t; s_need_eq = keep - above; s_eq_base = 0; s_out_base = 0;
+    }
+    __syncthreads();
+    const int t = s_t, need_eq = s_need_eq;
+    for (int start = 0; start < n; start += 1024) {
+        const int i = start + tid;
+        const bool in = i < n;
+        const float2 p = in ? xy[i] : make_float2(0.f, 0.f);
+        const float r = in ? resp[i] : 0.f;
+        const int ri = (int)r;
+        const bool eq = in && ri == t;
+        const unsigned long long me = __ballot(eq);
+        if (lane == 0) wave_eq[wv] = __popcll(me);
+        __syncthreads();
+        int eq_pre = s_eq_base, eq_tot = 0;
+        for (int q = 0; q < 16; q++) { const int c = wave_eq[q]; if (q < wv) eq_pre += c; eq_tot += c; }
+        const int eq_rank = eq_pre + __popcll(me & ((1ull << lane) - 1ull));
+        const bool kp = in && (ri > t || (eq && eq_rank < need_eq));
+        const unsigned long long mk = __ballot(kp);
+        if (lane == 0) wave_kp[wv] = __popcll(mk);
+        __syncthreads();
+        int kp_pre = s_out_base, kp_tot = 0;
+        for (int q = 0; q < 16; q++) { const int c = wave_kp[q]; if (q < wv) kp_pre += c; kp_tot += c; }
+        if (kp) {
+            const int dst = kp_pre + __popcll(mk & ((1ull << lane) - 1ull));
+            xy[dst] = p; resp[dst] = r;
+        }
+        __syncthreads();
+        if (tid == 0) { s_eq_base += eq_tot; s_out_base += kp_tot; }
+        __syncthreads();
+    }
+    if (tid == 0) a.n_out[b] = keep;
+}
+
+void launch_fast_keep_strongest(const FastArgs &a, int batch, int keep, hipStream_t st)
+{
+    if (keep <= 0 || batch <= 0 || !a.nms) return;
+    hipLaunchKernelGGL(fast_keep_strongest_kernel, dim3(batch), dim3(1024), 0, st, a, keep);
+}
+
 void launch_fast(const FastArgs &a, int batch, hipStream_t st)
 {
     (void)hipMemsetAsync(a.rowcount, 0, sizeof(int) * (size_t)a.rowcount_stride * batch, st);

@@ -61,6 +61,7 @@ static int ingest_frames(svo_ctx *ctx, const uint8_t *L, const uint8_t *R, int p
     a.kp_stride = ctx->cfg.max_keypoints;
     a.n_out = ctx->kp_n + f0; a.cap = ctx->cfg.max_keypoints;
     launch_fast(a, n_new, ctx->stream);
+    launch_fast_keep_strongest(a, n_new, ctx->cfg.fast_keep_strongest, ctx->stream);
     mark(ctx, kTFast);
     return SVO_OK;
 }
@@ -171,6 +172,7 @@ int pipeline_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t
     SVO_ARG(results_mem == SVO_MEM_HOST || results_mem == SVO_MEM_DEVICE, "bad results_mem");
     SVO_HIP(hipSetDevice(ctx->device));
     const int n_pairs = n_frames - 1;
+    ctx->last_batch_pairs = n_pairs;
     mark(ctx, kT0);
     int rc = ingest_frames(ctx, left_frames, right_frames, pitch, frame_stride, 0, n_frames);
     if (rc) return rc;

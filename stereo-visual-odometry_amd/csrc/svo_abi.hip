@@ -53,6 +53,7 @@ static void make_geom(int w, int h, PyrGeom *g)
 
 extern "C" int svo_wait_results(svo_ctx *ctx);
 extern "C" int svo_abi_version(void) { return SVO_ABI_VERSION; }
+extern "C" int svo_config_bytes(void) { return (int)sizeof(svo_config); }
 
 extern "C" int svo_device_count(int *n)
 {
@@ -91,6 +92,7 @@ extern "C" void svo_default_config(svo_config *cfg, int width, int height)
     cfg->orb_nlevels = 8;                   // :91
     cfg->orb_ini_th = 20;                   // :90
     cfg->orb_min_th = 7;                    // :89
+    cfg->fast_keep_strongest = 0;           // every cv::FAST corner, as the reference tracks them
     cfg->lk_accum = SVO_LK_ACCUM_EXACT;     // the canonical recipe; SVO_LK_ACCUM_SSE2 = an x86 OpenCV build's float order
 }
 
@@ -134,6 +136,7 @@ extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
         fprintf(stderr, "svo_create: lk_accum = %d is neither SVO_LK_ACCUM_EXACT nor SVO_LK_ACCUM_SSE2\n", cfg->lk_accum);
         return SVO_ERR_ARG;
     }
+    if (cfg->fast_keep_strongest < 0) return SVO_ERR_ARG;
     if (cfg->num_features_tracking < 5) {
         // with fewer than 5 tracks required, a pair with exactly 4 would reach cv::solvePnPRansac's
         // npoints == 4 branch (P3P kernel), which this library does not implement: refuse the
@@ -879,6 +882,36 @@ extern "C" int svo_get_frame_keypoints(svo_ctx *ctx, int side, svo_keypoint *kps
         }
     }
     *n_out = n;
+    return SVO_OK;
+}
+
+// The same read-back for pair `pair` of the most recent svo_track_batch / svo_track_uploaded launch (ABI v6): what a
+// caller needs to audit a batch against another implementation -- bench.py's self-check does.
+extern "C" int svo_get_batch_tracks(svo_ctx *ctx, int pair, svo_pt2f *t1_left, svo_pt2f *t1_right, svo_pt2f *t2_right,
+                                    svo_pt2f *t2_left, uint8_t *inlier, int cap, int *n_out)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(n_out && cap >= 0, "null output");
+    SVO_ARG(pair >= 0 && pair < ctx->last_batch_pairs, "pair is not part of the last batch launch");
+    SVO_HIP(hipSetDevice(ctx->device));
+    if (svo_wait_results(ctx) != SVO_OK) return SVO_ERR_HIP;
+    int *h_n = (int *)ctx->h_pinned;
+    SVO_HIP(hipMemcpyAsync(h_n, ctx->m_out + pair, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    const int n = *h_n;
+    SVO_ARG(n >= 0 && n <= ctx->cfg.max_keypoints, "corrupt track count");
+    SVO_ARG(n <= cap, "track capacity too small");
+    *n_out = n;
+    if (n == 0) return SVO_OK;
+    const size_t o = (size_t)pair * ctx->cfg.max_keypoints;
+    svo_pt2f *dst[4] = {t1_left, t1_right, t2_right, t2_left};
+    for (int k = 0; k < 4; k++) {
+        if (!dst[k]) continue;
+        if (k == 2 && ctx->cfg.track_mode == SVO_MODE_ORB) { memset(dst[k], 0, sizeof(svo_pt2f) * (size_t)n); continue; }
+        SVO_HIP(hipMemcpyAsync(dst[k], ctx->cmp[k] + o, sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (inlier) SVO_HIP(hipMemcpyAsync(inlier, pnp_inlier_mask(ctx) + o, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
     return SVO_OK;
 }
 

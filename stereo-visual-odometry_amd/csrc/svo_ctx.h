@@ -42,6 +42,7 @@ struct svo_ctx {
     // ---- online state (svo_add_frame)
     int online_frames = 0;            // frames fed since reset
     int online_cur = 0;               // which half of the 2-frame ring holds the latest frame
+    int last_batch_pairs = 0;         // pairs of the most recent batch launch (svo_get_batch_tracks)
     int online_tracked = 0;           // tracks of the last svo_add_frame pair (0 when it stopped before matching)
     double pose[16];
     // ---- ORB path (allocated on first use: orb_alloc)

@@ -17,6 +17,8 @@ struct FastArgs {
     int cap;
 };
 void launch_fast(const FastArgs &a, int batch, hipStream_t st);
+// svo_config.fast_keep_strongest: in-place selection of the `keep` highest-response corners per image, raster order kept
+void launch_fast_keep_strongest(const FastArgs &a, int batch, int keep, hipStream_t st);
 
 // ---- LK pyramid (pyramid.hip) ---------------------------------------------------------------
 struct PyrArgs {

@@ -17,6 +17,14 @@ Tracking::Tracking(System *system, Parameter::Ptr parameter, Sensors::Ptr sensor
     // needs from it is read NOW, so several System objects -- one per sequence -- can be built one after
     // the other and then run side by side
     max_keypoints_key_ = Config::Has("max_keypoints") ? Config::Get<int>("max_keypoints") : 0;
+    // order of the float sums inside cv::calcOpticalFlowPyrLK (include/svo_abi.h): `exact` is independent of the
+    // build, `sse2` reproduces an x86 OpenCV 3 bit for bit at about twice the LK kernel time
+    fast_keep_strongest_ = Config::Has("fast_keep_strongest") ? Config::Get<int>("fast_keep_strongest") : 0;
+    if (Config::Has("lk_accum")) {
+        const std::string v = Config::Get<std::string>("lk_accum");
+        if (v == "sse2") lk_accum_ = SVO_LK_ACCUM_SSE2;
+        else if (v != "exact") LZB_LOG("WARNING", "lk_accum: '%s' is neither 'exact' nor 'sse2'; using 'exact'", v.c_str());
+    }
 }
 
 Tracking::~Tracking()
@@ -93,6 +101,8 @@ bool Tracking::EnsureContext(int width, int height, int max_batch)
     cfg.confidence = confidence_;
     cfg.feature_match_error = feature_match_error_;
     cfg.inlier_rate = inlier_rate_;
+    cfg.lk_accum = lk_accum_;
+    cfg.fast_keep_strongest = fast_keep_strongest_ > 0 ? fast_keep_strongest_ : 0;
     if (track_mode_ == "ORB_stereof2f_pnp") {
         // the shipped default (config/default.yaml:75): ORBextractor(nFeatures, fScaleFactor, nLevels,
         // fIniThFAST, fMinThFAST) (src/tracking.cpp:20) and the configured minmove / maxmove gate (:215)

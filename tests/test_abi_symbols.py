@@ -43,6 +43,9 @@ def test_default_config_matches_reference_yaml(pkg):
     # ORBextractor arguments, config/default.yaml:89-93
     assert (cfg.orb_nfeatures, cfg.orb_nlevels, cfg.orb_ini_th, cfg.orb_min_th) == (2000, 8, 20, 7)
     assert abs(cfg.orb_scale_factor - 1.2) < 1e-7 and cfg.track_mode == 0
+    # ABI v6 additions default to the reference's behaviour: every FAST corner, the canonical (order-free) LK sums
+    assert cfg.lk_accum == b.LK_ACCUM_EXACT and cfg.fast_keep_strongest == 0
+    assert b.load_library().svo_config_bytes() == ctypes.sizeof(b.Config)
 
 
 def test_create_fails_loudly_without_gpu(pkg):

@@ -114,6 +114,41 @@ def test_lk_sse2_100_pairs_batched_and_online(pkg, oracle, tc, s0_100):
     _check_online(pkg, seq, frames[:41], ref[:40], lk_accum=pkg.LK_ACCUM_SSE2)
 
 
+def test_lk_sse2_through_run_kitti_stereo(pkg, oracle, s0_100, tmp_path):
+    """YAML `lk_accum: sse2` through the drop-in binary (per-frame loop and batched runner): the pose file
+    follows the oracle's x86-order chain, and differs from the `exact` run's file."""
+    import os
+    import subprocess
+    from test_gpu_parity_sequence import HOST, _write_pgm
+    from test_host_api import _write_yaml
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    seq, frames = s0_100
+    frames = frames[:17]
+    with sse2_oracle(oracle):
+        ref = _oracle_lk_sequence(oracle, seq, frames)
+    for cam in (0, 1):
+        os.makedirs(tmp_path / f"image_{cam}")
+    for t, (L, R) in enumerate(frames):
+        _write_pgm(tmp_path / "image_0" / f"{t:06d}.pgm", L)
+        _write_pgm(tmp_path / "image_1" / f"{t:06d}.pgm", R)
+    _write_yaml(tmp_path / "exact.yaml", str(tmp_path), fx=seq.fx, fy=seq.fy, cx=seq.cx, cy=seq.cy)
+    txt = open(tmp_path / "exact.yaml", encoding="utf-8").read()
+    open(tmp_path / "sse2.yaml", "w", encoding="utf-8").write(txt + "lk_accum: sse2\n")
+    open(tmp_path / "sse2_batched.yaml", "w", encoding="utf-8").write(txt + "lk_accum: sse2\nbatch_size: 8\ndecode_threads: 4\n")
+    want = np.stack([np.eye(4)] + [pose for _, _, _, pose in ref])[:, :3]
+    files = {}
+    for cfg in ("exact.yaml", "sse2.yaml", "sse2_batched.yaml"):
+        out = tmp_path / (cfg + ".poses")
+        r = subprocess.run([os.path.join(HOST, "run_kitti_stereo"), str(tmp_path / cfg), str(out)], capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        files[cfg] = open(out, "rb").read()
+        if cfg != "exact.yaml":
+            poses = np.loadtxt(out).reshape(-1, 3, 4)
+            assert poses.shape == want.shape
+            assert max(relfro(poses[t], want[t]) for t in range(len(want))) <= 1e-6      # the file holds 10 significant digits
+    assert files["sse2.yaml"] == files["sse2_batched.yaml"] != files["exact.yaml"]
+
+
 def test_lk_sse2_second_seed_24_pairs(pkg, oracle, tc, synth):
     seq, frames = _render(synth, tc, 1241, 376, 25, 7)
     with sse2_oracle(oracle):
