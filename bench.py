@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--e2e-frames", type=int, default=1025, help="frames of the end-to-end leg (run_kitti_stereo from PGM and PNG "
                     "files on disk, process start included; 0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the m1 / online legs (value, roofline, cpu_baseline only)")
+    ap.add_argument("--no-self-check", action="store_true", help="skip the oracle comparison of 8 random pairs of the last step")
+    ap.add_argument("--no-legs", action="store_true", help="skip the lk_accum_sse2 / orb (config #3) / hd (config #4) legs")
+    ap.add_argument("--hd-batch", type=int, default=64, help="pairs per step of the hd leg (1920x1080, exactly 2000 corners)")
     ap.add_argument("--no-timing-marks", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the pose stage in stream order")
     ap.add_argument("--mode", choices=["lk", "orb"], default="lk",
@@ -149,6 +152,184 @@ def newest_profile(name, src_hash=None):
     return None
 
 
+def roofline_lk(stage_ms, pts_total, B):
+    """The LK launch of a mean step against the HBM roof (4257 algorithmic bytes per point per call,
+    4 fused calls per launch) and against the VALU issue roof it actually sits under; the profile-derived fields
+    (PMC traffic, instruction count) are valid only for the kernel source they were measured on."""
+    lk_ms = stage_ms["lk"]
+    src_hash = kernel_source_hash()
+    alg_bytes = pts_total * 4 * LK_BYTES_PER_POINT_CALL
+    achieved = alg_bytes / (lk_ms * 1e-3) / 1e9
+    traffic, valu = None, None
+    prof = newest_profile("lk", src_hash) if B == 256 else None
+    if prof:
+        traffic = prof.get("traffic_bytes")
+        n_valu = prof.get("valu_wave_instructions")
+        peak = prof.get("valu_peak_wave_instr_per_cycle_per_simd")
+        # shader clock of the profiled launch: GRBM_GUI_ACTIVE counts the cycles of all 8 XCDs over the launch
+        clk = prof.get("clock_ghz_measured") or CLOCK_GHZ
+        if n_valu and peak:
+            rate = n_valu / (lk_ms * 1e-3 * N_SIMD * clk * 1e9)
+            valu = {"achieved": round(rate, 4), "peak": peak, "unit": "wave-instructions/cycle/SIMD",
+                    "frac": round(rate / peak, 4), "clock_ghz": clk,
+                    "clock_source": ("GRBM_GUI_ACTIVE / 8 XCDs / launch time of the profiled run" if prof.get("clock_ghz_measured")
+                                     else "MI355X_MICROARCH.md peak clock (no GRBM pass in the profile)"),
+                    "profile": prof["_file"],
+                    "note": "peak = measured issue rate of v_dot2 / v_perm / v_pk_* / DPP / v_cndmask (4 cycles per "
+                            "wave-instruction); profiles/r02_valu_roof.txt"}
+    return {"bound": "hbm", "kernel": "lk_kernel (4-call circular chain, one launch per step)",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "frac_measured_traffic": (round(traffic / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
+            "launch_ms": round(lk_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+            "limiting_resource": "valu-issue", "valu": valu, "kernel_source_sha256_16": src_hash}
+
+
+def roofline_orb(stage_ms, B, w, h):
+    """ORB mode: the largest kernel group is the per-cell FAST over the 8-level pyramid (3.09 W H bytes
+    read per image; the candidate records are negligible)."""
+    cf_ms = stage_ms["orb_cellfast"]
+    alg_bytes = int(3.09 * w * h * 2 * (B + 1))
+    achieved = alg_bytes / (cf_ms * 1e-3) / 1e9
+    oprof = newest_profile("orb") if B == 256 else None
+    return {"bound": "hbm", "kernel": "orb_cellfast_kernel (one launch per step over all pyramid levels)",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": (oprof or {}).get("cellfast_traffic_bytes"), "profile": (oprof or {}).get("_file"),
+            "launch_ms": round(cf_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
+
+
+def run_leg(pkg, torch, dev, L, R, width, height, B, steps, warmup, ctx_kw):
+    """`steps` svo_track_batch calls of B pairs each on a FRESH context -- overlap on, records device-resident in two
+    buffers, the rendered chunks cycled -- timed like the main measurement (frames resident in HBM).  Returns the
+    context (its buffers still hold the last step: svo_get_batch_tracks), the elapsed seconds, the stage times, the last
+    step's records and the index of the first frame of the last step's chunk."""
+    NC = (L.shape[0] - 1) // B
+    ctx = pkg.Context(width, height, device=dev.index, max_batch=B, **ctx_kw)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_overlap(True)
+    bufs = [torch.zeros((B, pkg.STEP_DTYPE.itemsize), dtype=torch.uint8, device=dev) for _ in range(2)]
+
+    def one(k):
+        c = k % NC
+        ctx.track_batch(L[c * B:c * B + B + 1, :, :width], R[c * B:c * B + B + 1, :, :width], results=bufs[k & 1])
+
+    for k in range(warmup):
+        one(k)
+    ctx.sync()
+    torch.cuda.synchronize()
+    ctx.enable_timing(True)
+    ctx.get_timing()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        one(k)
+    ctx.sync()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    stage_ms = dict(ctx.get_timing())
+    ctx.enable_timing(False)
+    recs = np.frombuffer(bufs[(steps - 1) & 1].cpu().numpy().tobytes(), dtype=pkg.STEP_DTYPE)
+    return ctx, el, stage_ms, recs, ((steps - 1) % NC) * B
+
+
+def self_check(pkg, O, ctx, recs, L, R, width, f0, P1, P2, mode="lk", sse2=False, keep=0, n_check=8, seed=20261004):
+    """After the timing: `n_check` random pairs of the LAST step against the CPU oracle on the same frames -- fail_stage,
+    keypoint / track / inlier counts, RANSAC and LM iteration numbers, every matched track and the inlier mask byte for
+    byte, the relative motion to 1e-9.  A mismatch makes bench.py exit non-zero: a throughput number for wrong results
+    is not a number."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(seed)
+    pairs = sorted(int(x) for x in rng.choice(len(recs), size=min(n_check, len(recs)), replace=False))
+    need = sorted({f for p in pairs for f in (p, p + 1)})
+    fl = {f: L[f0 + f, :, :width].cpu().numpy() for f in need}
+    fr = {f: R[f0 + f, :, :width].cpu().numpy() for f in need}
+    K = np.asarray(P1, np.float64).reshape(3, 4)[:, :3].copy()
+
+    def one_lk(p):
+        prm = O.make_params(P1, P2)
+        kps = O.fast(fl[p])
+        n_all = len(kps)
+        if keep and n_all > keep:
+            kps = kps[np.sort(np.argsort(-kps["response"], kind="stable")[:keep])]
+        r, cur, _ = O.lk_track_step(prm, fl[p], fr[p], fl[p + 1], fr[p + 1], kps, np.eye(4), want_tracks=True, threads=1)
+        r["n_cur_kps"] = min(len(cur), keep) if keep else len(cur)
+        tr = r["tracks"]
+        pnp = O.pnp_ransac(O.triangulate(P1, P2, tr[0], tr[1]), tr[3], K) if r["n_tracked"] >= 5 else None
+        return r, [tr[0], tr[1], tr[2], tr[3]], pnp
+
+    def one_orb(p):
+        prm = O.make_params(P1, P2, min_t2=0.05 ** 2, max_t2=10.0 ** 2)
+        (kL, dL), (kR, dR), (k2, d2) = (O.orb_extract(im)[:2] for im in (fl[p], fr[p], fl[p + 1]))
+        r, _ = O.orb_track_step(prm, kL, dL, kR, dR, k2, d2, np.eye(4))
+        t2l, t1l, t1r = O.orb_robust_match(kL, dL, kR, dR, k2, d2)
+        pnp = O.pnp_ransac(O.triangulate(P1, P2, t1l, t1r), t2l, K) if len(t1l) >= 5 else None
+        return r, [t1l, t1r, None, t2l], pnp
+
+    old = O.set_lk_accum(O.LK_ACCUM_FLOAT_SSE if sse2 else O.LK_ACCUM_EXACT)
+    try:
+        with ThreadPoolExecutor(max_workers=min(len(pairs), usable_cores())) as ex:
+            refs = list(ex.map(one_orb if mode == "orb" else one_lk, pairs))
+    finally:
+        O.set_lk_accum(old)
+    bad = []
+    for p, (r, tr, pnp) in zip(pairs, refs):
+        g = recs[p]
+        for k in ("ok", "fail_stage", "n_prev_kps", "n_cur_kps", "n_tracked", "n_inliers"):
+            if int(g[k]) != int(r[k]):
+                bad.append(f"pair {p}: {k} {int(g[k])} != {int(r[k])}")
+        got = ctx.batch_tracks(p)
+        for k, name in enumerate(("t1_left", "t1_right", "t2_right", "t2_left")):
+            if tr[k] is not None and got[k].tobytes() != np.ascontiguousarray(tr[k]).tobytes():
+                bad.append(f"pair {p}: tracks {name} differ")
+        if pnp is not None:
+            for k in ("ransac_iters", "lm_iters"):
+                if int(g[k]) != int(pnp[k]):
+                    bad.append(f"pair {p}: {k} {int(g[k])} != {int(pnp[k])}")
+            if got[4].tobytes() != pnp["mask"].tobytes():
+                bad.append(f"pair {p}: RANSAC inlier mask differs")
+        if r["ok"]:
+            e = float(np.linalg.norm(g["T_rel_inv"].reshape(4, 4) - r["T_rel_inv"]) / np.linalg.norm(r["T_rel_inv"]))
+            if not e <= 1e-9:
+                bad.append(f"pair {p}: T_rel_inv off by {e:.2e}")
+    return {"pairs": len(pairs), "ok": not bad, "compared": "fail_stage, counts, ransac_iters, lm_iters, tracks + inlier mask "
+            "(bytes), T_rel_inv (1e-9) vs oracle/ on the same frames" + (", oracle in SSE2 accumulation order" if sse2 else ""),
+            "which_pairs_of_last_step": pairs, **({"mismatches": bad[:12]} if bad else {})}
+
+
+def cpu_orb(O, L, R, width, P1, P2, n1, n_all):
+    """config #3 on the CPU: ORBextractor on the left and right image of every frame, then the matcher + pose step;
+    1 thread frame by frame (the reference's order), then every image / every pair over the usable cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    prm = O.make_params(P1, P2, min_t2=0.05 ** 2, max_t2=10.0 ** 2)
+    cores = usable_cores()
+
+    def orb_run(n, workers):
+        fl = L[:n + 1, :, :width].cpu().numpy()
+        fr = R[:n + 1, :, :width].cpu().numpy()
+        c0 = time.perf_counter()
+        if workers == 1:
+            prev, pose = None, np.eye(4)
+            for t in range(n + 1):
+                cur = (O.orb_extract(fl[t])[:2], O.orb_extract(fr[t])[:2])
+                if prev is not None:
+                    _, pose = O.orb_track_step(prm, *prev[0], *prev[1], *cur[0], pose)
+                prev = cur
+        else:
+            with ThreadPoolExecutor(max_workers=workers) as ex:
+                feats = list(ex.map(lambda im: O.orb_extract(im)[:2], [im for t in range(n + 1) for im in (fl[t], fr[t])]))
+                list(ex.map(lambda t: O.orb_track_step(prm, *feats[2 * t - 2], *feats[2 * t - 1], *feats[2 * t], np.eye(4)),
+                            range(1, n + 1)))
+        return n / (time.perf_counter() - c0)
+
+    v1 = orb_run(n1, 1)
+    vp = orb_run(n_all, cores)
+    return {"value": round(v1, 3), "unit": "stereo pairs/s", "cores": 1, "kind": "port",
+            "sample": f"first {n1} pairs of the same S0 frames, oracle/ (CPU restatement of ORBextractor + the reference's matcher "
+                      f"and pose step, not the reference binary), 1 thread, frame by frame",
+            "all_cores": {"value": round(vp, 3), "cores": cores,
+                          "sample": f"first {n_all} pairs: all {2 * (n_all + 1)} extractions, then all pair steps, one 1-thread oracle "
+                                    f"call per worker thread, {cores} workers ({os.cpu_count()} host cpus visible)"}}
+
+
 def e2e_leg(args, L, R, P1, width):
     """run_kitti_stereo (the reference's CLI, batched runner) on a KITTI-layout directory of the bench's own S0 frames,
     once from PGM and once from PNG files (the reference's input format): pairs/s from process start to exit."""
@@ -229,6 +410,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    exit_code = 0
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -462,51 +644,16 @@ def main():
                                                 "each sequence's relative motions are chained on its GPU and its FULL pose list goes to rank 0 "
                                                 "in one ragged gather inside the timed region; frames are the rank's rendered chunks cycled "
                                                 "(sequence LENGTHS are modelled, not their content)"}
-        src_hash = kernel_source_hash()
-        lk_ms = stage_ms.get("lk")
-        if lk_ms:
-            alg_bytes = pts_total * 4 * LK_BYTES_PER_POINT_CALL       # 4 fused calls per launch
-            achieved = alg_bytes / (lk_ms * 1e-3) / 1e9
-            # HBM bytes and VALU instructions per launch from the rocprofv3 PMC passes of this command
-            # (profiles/), valid only for the kernel source they were measured on
-            traffic, valu = None, None
-            prof = newest_profile("lk", src_hash) if B == 256 else None
-            if prof:
-                traffic = prof.get("traffic_bytes")
-                n_valu = prof.get("valu_wave_instructions")
-                peak = prof.get("valu_peak_wave_instr_per_cycle_per_simd")
-                # shader clock of the profiled launch: GRBM_GUI_ACTIVE counts the cycles of all 8 XCDs over the launch
-                clk = prof.get("clock_ghz_measured") or CLOCK_GHZ
-                if n_valu and peak:
-                    rate = n_valu / (lk_ms * 1e-3 * N_SIMD * clk * 1e9)
-                    valu = {"achieved": round(rate, 4), "peak": peak, "unit": "wave-instructions/cycle/SIMD",
-                            "frac": round(rate / peak, 4), "clock_ghz": clk,
-                            "clock_source": ("GRBM_GUI_ACTIVE / 8 XCDs / launch time of the profiled run" if prof.get("clock_ghz_measured")
-                                             else "MI355X_MICROARCH.md peak clock (no GRBM pass in the profile)"),
-                            "profile": prof["_file"],
-                            "note": "peak = measured issue rate of v_dot2 / v_perm / v_pk_* / DPP / v_cndmask (4 cycles per "
-                                    "wave-instruction); profiles/r02_valu_roof.txt"}
-            out["roofline"] = {"bound": "hbm", "kernel": "lk_kernel (4-call circular chain, one launch per step)",
-                               "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                               "frac_measured_traffic": (round(traffic / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                                                         if traffic else None),
-                               "launch_ms": round(lk_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                               "limiting_resource": "valu-issue", "valu": valu, "kernel_source_sha256_16": src_hash}
-        elif stage_ms.get("orb_cellfast"):
-            # ORB mode: the largest kernel group is the per-cell FAST over the 8-level pyramid
-            # (3.09 W H bytes read per image; the candidate records are negligible)
-            cf_ms = stage_ms["orb_cellfast"]
-            alg_bytes = int(3.09 * W * H * 2 * (B + 1))
-            achieved = alg_bytes / (cf_ms * 1e-3) / 1e9
-            oprof = newest_profile("orb") if B == 256 else None
-            out["roofline"] = {"bound": "hbm", "kernel": "orb_cellfast_kernel (one launch per step over all pyramid levels)",
-                               "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 5),
-                               "traffic": (oprof or {}).get("cellfast_traffic_bytes"), "profile": (oprof or {}).get("_file"),
-                               "launch_ms": round(cf_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
-        else:
-            out["roofline"] = None
+        out["roofline"] = (roofline_lk(stage_ms, pts_total, B) if stage_ms.get("lk") else
+                           roofline_orb(stage_ms, B, W, H) if stage_ms.get("orb_cellfast") else None)
+        if out["roofline"] and args.lk_accum == "sse2":
+            out["roofline"]["kernel"] = "lk_sse2_kernel (lk_accum = sse2: float sums in an x86 OpenCV's lane order)"
+        if world == 1 and not args.config5 and not args.no_self_check and steps > 0:
+            O = entry.load_oracle()
+            O.build()
+            # the context still holds the last step's tracks and masks (B pairs, overlap on, chunks cycled)
+            out["self_check"] = self_check(pkg, O, ctx, res, L, R, W, ((steps - 1) % NC) * B, P1, P2, mode=args.mode,
+                                           sse2=args.lk_accum == "sse2")
 
     # ---- secondary legs (N = 1): M1 with H2D inside the timed region, and the online path ---------
     if world == 1 and not args.no_secondary and not args.config5:
@@ -565,6 +712,82 @@ def main():
         out["online"] = {"ms_per_pair_median": round(float(np.median(lat)), 3), "ms_per_pair_p90": round(float(np.percentile(lat, 90)), 3),
                          "pairs_per_s": round(1e3 / float(np.mean(lat)), 1), "pairs": len(lat), "pairs_ok": ok_on - 8,
                          "definition": "config #2 single-stream: svo_add_frame per stereo pair, frames in host memory, result on the host"}
+        # ---- legs on their own contexts (N = 1): the other BASELINE configs and the x86-order LK mode ----------------
+        if not args.no_legs:
+            O = None
+            if not args.no_self_check or args.cpu_pairs > 0:
+                O = entry.load_oracle()
+                O.build()
+            leg_steps, leg_warm = max(2, min(steps, 6)), 1
+
+            def finish(name, lctx, el, st_ms, recs, f0, n_steps, Bl, extra, check_kw, Lf=L, Rf=R, wd=W):
+                leg = {"value": round(Bl * n_steps / el, 2), "unit": "stereo pairs/s", "ms_per_step": round(1e3 * el / n_steps, 4),
+                       "steps": n_steps, "pairs_per_step": Bl, "pairs_ok_last_step": int(recs["ok"].sum()),
+                       "mean_keypoints_per_pair": round(float(recs["n_prev_kps"].mean()), 1),
+                       "stage_ms_per_step": {k: round(v, 4) for k, v in st_ms.items()}, **extra}
+                if O is not None and not args.no_self_check:
+                    leg["self_check"] = self_check(pkg, O, lctx, recs, Lf, Rf, wd, f0, P1l, P2l, **check_kw)
+                lctx.close()
+                out[name] = leg
+
+            P1l, P2l = P1, P2
+            if args.mode == "lk" and args.lk_accum == "exact":
+                # (1) the LK tracker in an x86 OpenCV's accumulation order: what bit-identity with the reference CPU path costs
+                lctx, el, st_ms, recs, f0 = run_leg(pkg, torch, dev, L, R, W, H, B, leg_steps, leg_warm,
+                                                    dict(P1=P1, P2=P2, lk_accum=pkg.LK_ACCUM_SSE2))
+                finish("lk_accum_sse2", lctx, el, st_ms, recs, f0, leg_steps, B,
+                       {"definition": "the main workload with svo_config.lk_accum = SVO_LK_ACCUM_SSE2 (lk_sse2_kernel: float sums in the "
+                                      "lane order of upstream's CV_SSE2 block, bit-identical to oracle/lk.c mode 2)",
+                        "lk_ms_per_step": round(st_ms.get("lk", 0.0), 4),
+                        "lk_ms_per_step_exact": round(stage_ms.get("lk", 0.0), 4) if stage_ms.get("lk") else None},
+                       dict(mode="lk", sse2=True))
+            if args.mode == "lk":
+                # (2) BASELINE config #3: the ORB extractor + descriptor-match path on the same frames
+                lctx, el, st_ms, recs, f0 = run_leg(pkg, torch, dev, L, R, W, H, B, leg_steps, leg_warm,
+                                                    dict(P1=P1, P2=P2, track_mode=pkg.MODE_ORB, min_move2=0.05 ** 2, max_move2=10.0 ** 2))
+                extra = {"definition": "BASELINE config #3: track_mode ORB_stereof2f_pnp (nFeatures 2000, 8 levels, 20 / 7) on the same S0 frames",
+                         "roofline": roofline_orb(st_ms, B, W, H) if st_ms.get("orb_cellfast") else None}
+                if O is not None and args.cpu_pairs > 0:
+                    n1 = max(4, min(args.cpu_pairs // 4, B))
+                    extra["cpu_baseline"] = cpu_orb(O, L, R, W, P1, P2, n1, min(max(4 * n1, 2 * usable_cores()), B))
+                    extra["vs_cpu_baseline_1_thread"] = None     # filled below
+                finish("orb", lctx, el, st_ms, recs, f0, leg_steps, B, extra, dict(mode="orb"))
+                if out["orb"].get("cpu_baseline"):
+                    out["orb"]["vs_cpu_baseline_1_thread"] = round(out["orb"]["value"] / out["orb"]["cpu_baseline"]["value"], 1)
+            if args.mode == "lk" and args.hd_batch > 0:
+                # (3) BASELINE config #4: 1920x1080, EXACTLY the 2000 highest-response FAST corners per frame
+                Bh, Wh, Hh, Ph = args.hd_batch, 1920, 1080, 1920
+                seqh = synth.StereoSequence(width=Wh, height=Hh, n_frames=2 * Bh + 1, seed=1, device=dev)
+                Lh = torch.zeros((2 * Bh + 1, Hh, Ph), dtype=torch.uint8, device=dev)
+                Rh = torch.zeros_like(Lh)
+                for f in range(2 * Bh + 1):
+                    Lh[f], Rh[f] = seqh.render(f)
+                P1l, P2l = seqh.proj()
+                lctx, el, st_ms, recs, f0 = run_leg(pkg, torch, dev, Lh, Rh, Wh, Hh, Bh, leg_steps, leg_warm,
+                                                    dict(P1=P1l, P2=P2l, max_keypoints=1 << 16, fast_keep_strongest=2000))
+                pts = int(round(float(recs["n_prev_kps"].mean()) * Bh))
+                extra = {"definition": "BASELINE config #4: synthetic 1920x1080 stereo stream, fast_keep_strongest = 2000 (the 2000 "
+                                       "highest-response FAST(20) corners of every frame, ties by raster order), FAST+LK",
+                         "roofline": roofline_lk(st_ms, pts, Bh) if st_ms.get("lk") else None}
+                if O is not None and args.cpu_pairs > 0:
+                    n1 = max(2, min(args.cpu_pairs // 12, Bh))
+                    prm = O.make_params(P1l, P2l)
+                    flh = Lh[:n1 + 1].cpu().numpy()
+                    frh = Rh[:n1 + 1].cpu().numpy()
+                    c0 = time.perf_counter()
+                    for t in range(1, n1 + 1):
+                        kp = O.fast(flh[t - 1])
+                        kp = kp[np.sort(np.argsort(-kp["response"], kind="stable")[:2000])]
+                        O.lk_track_step(prm, flh[t - 1], frh[t - 1], flh[t], frh[t], kp, np.eye(4), threads=1)
+                    v1 = n1 / (time.perf_counter() - c0)
+                    extra["cpu_baseline"] = {"value": round(v1, 3), "unit": "stereo pairs/s", "cores": 1, "kind": "port",
+                                             "sample": f"first {n1} pairs of the same 1920x1080 frames, oracle/ (FAST, selection of the 2000 "
+                                                       f"strongest, LK step), 1 thread"}
+                    extra["vs_cpu_baseline_1_thread"] = None
+                finish("hd", lctx, el, st_ms, recs, f0, leg_steps, Bh, extra, dict(mode="lk", keep=2000, n_check=4), Lf=Lh, Rf=Rh, wd=Wh)
+                if out["hd"].get("cpu_baseline"):
+                    out["hd"]["vs_cpu_baseline_1_thread"] = round(out["hd"]["value"] / out["hd"]["cpu_baseline"]["value"], 1)
+                del Lh, Rh
 
     if rank == 0:
         # ---- cpu_baseline: the oracle (CPU restatement of the reference path) on bounded samples
@@ -617,44 +840,12 @@ def main():
             out["vs_cpu_baseline_1_thread"] = round(out["value"] / v1, 1)
             out["vs_cpu_baseline_all_cores"] = round(out["value"] / vp, 1)
         elif args.cpu_pairs > 0 and world == 1 and args.mode == "orb":
-            # config #3 on the CPU: ORBextractor on the left and right image of every frame, then the matcher + pose step
             O = entry.load_oracle()
             O.build()
-            prm = O.make_params(P1, P2, min_t2=0.05 ** 2, max_t2=10.0 ** 2)
-            cores = usable_cores()
-            from concurrent.futures import ThreadPoolExecutor
-
-            def orb_run(n, workers):
-                fl = L[:n + 1, :, :W].cpu().numpy()
-                fr = R[:n + 1, :, :W].cpu().numpy()
-                c0 = time.perf_counter()
-                if workers == 1:                                 # the reference's order: frame by frame
-                    prev, pose = None, np.eye(4)
-                    for t in range(n + 1):
-                        cur = (O.orb_extract(fl[t])[:2], O.orb_extract(fr[t])[:2])
-                        if prev is not None:
-                            _, pose = O.orb_track_step(prm, *prev[0], *prev[1], *cur[0], pose)
-                        prev = cur
-                else:                                            # every image, then every pair, over the workers
-                    with ThreadPoolExecutor(max_workers=workers) as ex:
-                        feats = list(ex.map(lambda im: O.orb_extract(im)[:2], [im for t in range(n + 1) for im in (fl[t], fr[t])]))
-                        list(ex.map(lambda t: O.orb_track_step(prm, *feats[2 * t - 2], *feats[2 * t - 1], *feats[2 * t], np.eye(4)),
-                                    range(1, n + 1)))
-                return n / (time.perf_counter() - c0)
-
             n1 = min(args.cpu_pairs, B)
-            v1 = orb_run(n1, 1)
-            np_pairs = min(max(4 * args.cpu_pairs, 2 * cores), B)
-            vp = orb_run(np_pairs, cores)
-            out["cpu_baseline"] = {"value": round(v1, 3), "unit": "stereo pairs/s", "cores": 1, "kind": "port",
-                                   "sample": f"first {n1} pairs of the same S0 frames, oracle/ (CPU restatement of ORBextractor + the "
-                                             f"reference's matcher and pose step, not the reference binary), 1 thread, frame by frame",
-                                   "all_cores": {"value": round(vp, 3), "cores": cores,
-                                                 "sample": f"first {np_pairs} pairs: all {2 * (np_pairs + 1)} extractions, then all pair steps, "
-                                                           f"one 1-thread oracle call per worker thread, {cores} workers "
-                                                           f"({os.cpu_count()} host cpus visible)"}}
-            out["vs_cpu_baseline_1_thread"] = round(out["value"] / v1, 1)
-            out["vs_cpu_baseline_all_cores"] = round(out["value"] / vp, 1)
+            out["cpu_baseline"] = cpu_orb(O, L, R, W, P1, P2, n1, min(max(4 * args.cpu_pairs, 2 * usable_cores()), B))
+            out["vs_cpu_baseline_1_thread"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            out["vs_cpu_baseline_all_cores"] = round(out["value"] / out["cpu_baseline"]["all_cores"]["value"], 1)
         else:
             out["cpu_baseline"] = None
 
@@ -662,9 +853,16 @@ def main():
         if world == 1 and args.e2e_frames >= 3 and not args.config5 and not args.no_secondary:
             out["e2e"] = e2e_leg(args, L, R, P1, W)
         print(json.dumps(out), flush=True)
+        checks = [out.get("self_check")] + [out[k].get("self_check") for k in ("lk_accum_sse2", "orb", "hd") if isinstance(out.get(k), dict)]
+        if any(c is not None and not c["ok"] for c in checks):
+            print("bench.py: self_check FAILED -- the timed results differ from the oracle's: " +
+                  json.dumps([c.get("mismatches") for c in checks if c and not c["ok"]]), file=sys.stderr, flush=True)
+            exit_code = 3
     if dist_on:
         dist.destroy_process_group()
     ctx.close()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":
