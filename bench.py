@@ -63,6 +63,9 @@ def parse():
                     "files on disk, process start included; 0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the m1 / online legs (value, roofline, cpu_baseline only)")
     ap.add_argument("--no-self-check", action="store_true", help="skip the oracle comparison of 8 random pairs of the last step")
+    ap.add_argument("--self-check-sabotage", action="store_true",
+                    help="(test of the test) run the main self-check's oracle in the OTHER accumulation order: it must fail and "
+                         "bench.py must exit with 3")
     ap.add_argument("--no-legs", action="store_true", help="skip the lk_accum_sse2 / orb (config #3) / hd (config #4) legs")
     ap.add_argument("--hd-batch", type=int, default=64, help="pairs per step of the hd leg (1920x1080, exactly 2000 corners)")
     ap.add_argument("--no-timing-marks", action="store_true")
@@ -653,7 +656,7 @@ def main():
             O.build()
             # the context still holds the last step's tracks and masks (B pairs, overlap on, chunks cycled)
             out["self_check"] = self_check(pkg, O, ctx, res, L, R, W, ((steps - 1) % NC) * B, P1, P2, mode=args.mode,
-                                           sse2=args.lk_accum == "sse2")
+                                           sse2=(args.lk_accum == "sse2") != args.self_check_sabotage)
 
     # ---- secondary legs (N = 1): M1 with H2D inside the timed region, and the online path ---------
     if world == 1 and not args.no_secondary and not args.config5:
