@@ -502,16 +502,38 @@ def main():
     res_buf = [torch.zeros((B, pkg.STEP_DTYPE.itemsize), dtype=torch.uint8, device=dev) for _ in range(2)]
     pose_off = pkg.STEP_DTYPE.fields["pose"][1]
     trel_off, ok_off = pkg.STEP_DTYPE.fields["T_rel_inv"][1], pkg.STEP_DTYPE.fields["ok"][1]
-    state = {"k": 0}
+    state = {"k": 0, "ctx": None}
+    # config #5: a sequence runs at ITS frame size with ITS rig (KITTI 03: 1242x375, 04-07: 1226x370; a context and a set
+    # of rendered chunks per size).  `sized[rig]` = (L, R, width, context); the 1241x376 entry is the main one.
+    sized = {id(mg.KITTI_RIG_A): (L, R, W, ctx)}
+    if args.config5:
+        for s_ in my_seqs:
+            rig = mg.KITTI_RIGS[s_]
+            if id(rig) in sized:
+                continue
+            seq_r = synth.StereoSequence(n_frames=F, seed=seed + 1000 + rig["width"], device=dev, **rig)
+            Lr = torch.zeros((F, rig["height"], PITCH), dtype=torch.uint8, device=dev)
+            Rr = torch.zeros_like(Lr)
+            for f in range(F):
+                l, r = seq_r.render(f)
+                Lr[f, :, :rig["width"]] = l
+                Rr[f, :, :rig["width"]] = r
+            P1r, P2r = seq_r.proj()
+            cr = pkg.Context(rig["width"], rig["height"], device=local_rank, max_batch=B, P1=P1r, P2=P2r, **mode_kw)
+            cr.set_stream(stream.cuda_stream)
+            cr.set_overlap(not args.no_overlap)
+            sized[id(rig)] = (Lr, Rr, rig["width"], cr)
     # config #5: every sequence's relative motions + ok flags stay on the device until the sequence is
     # chained (svo_chain_relative) and its FULL pose list goes to rank 0 in the one ragged gather
     acc = ({s_: torch.zeros((mg.KITTI_LENGTHS[s_] - 1, 17), dtype=torch.float64, device=dev) for s_ in my_seqs}
            if args.config5 else {})
     gathered = {}
 
-    def chunk(k, n_pairs):
+    def chunk(k, n_pairs, s_):
+        """(left frames, right frames, context) of step k: chunk k % NC of the frames rendered at the sequence's size."""
+        Ls, Rs, ws, cs = sized[id(mg.KITTI_RIGS[s_] if s_ is not None else mg.KITTI_RIG_A)]
         c = k % NC
-        return L[c * B:c * B + n_pairs + 1, :, :W], R[c * B:c * B + n_pairs + 1, :, :W]
+        return Ls[c * B:c * B + n_pairs + 1, :, :ws], Rs[c * B:c * B + n_pairs + 1, :, :ws], cs
 
     def collect(res, item):
         """The only inter-GPU traffic: per pair 16 doubles (poses) or 17 (relative motion + ok) to rank 0."""
@@ -529,8 +551,11 @@ def main():
 
     def step(items):
         k = state["k"]
-        Lk, Rk = chunk(k, items[k % len(items)][1])
-        ctx.track_batch(Lk, Rk, results=res_buf[k & 1])
+        Lk, Rk, ck = chunk(k, items[k % len(items)][1], items[k % len(items)][0])
+        if state["ctx"] is not None and state["ctx"] is not ck:
+            state["ctx"].wait_results()            # another frame size = another context: its pose stage is not ordered
+        state["ctx"] = ck                          # before the next launch by svo_track_batch itself
+        ck.track_batch(Lk, Rk, results=res_buf[k & 1])
         # svo_track_batch(k) has already ordered the context's stream after the pose stage of batch
         # k-1 (it reuses that stage's buffers), so batch k-1's records are complete here
         if k > 0 and (dist_on or by_pairs or args.config5):
@@ -542,8 +567,9 @@ def main():
         sequence on the device and send the full pose lists to rank 0 (one ragged gather)."""
         k = state["k"]
         if k > 0 and (dist_on or by_pairs or args.config5):
-            ctx.wait_results()
+            (state["ctx"] or ctx).wait_results()
             collect(res_buf[(k - 1) & 1], items[(k - 1) % len(items)])
+        state["ctx"] = None
         if args.config5:
             lists = [ctx.chain_relative(acc[s_][:, :16].contiguous(), acc[s_][:, 16].to(torch.int32)) for s_ in my_seqs]
             mine = torch.cat(lists, 0) if lists else torch.zeros((0, 16), dtype=torch.float64, device=dev)
@@ -645,8 +671,10 @@ def main():
                                                            "bytes": int(sum(g.numel() * 8 for g in gathered.values()))},
                                         "note": "--steps ignored: every rank runs ceil((len-1)/B) steps per sequence, the last one ragged; "
                                                 "each sequence's relative motions are chained on its GPU and its FULL pose list goes to rank 0 "
-                                                "in one ragged gather inside the timed region; frames are the rank's rendered chunks cycled "
-                                                "(sequence LENGTHS are modelled, not their content)"}
+                                                "in one ragged gather inside the timed region; every sequence runs at ITS KITTI frame size and rig "
+                                                "(00-02 1241x376, 03 1242x375, 04-07 1226x370: a context per size), on the rank's rendered chunks "
+                                                "of that size, cycled (sequence LENGTHS and SIZES are modelled, not their content)",
+                                        "frame_sizes": [f"{r['width']}x{r['height']}" for r in mg.KITTI_RIGS]}
         out["roofline"] = (roofline_lk(stage_ms, pts_total, B) if stage_ms.get("lk") else
                            roofline_orb(stage_ms, B, W, H) if stage_ms.get("orb_cellfast") else None)
         if out["roofline"] and args.lk_accum == "sse2":
@@ -863,6 +891,9 @@ def main():
             exit_code = 3
     if dist_on:
         dist.destroy_process_group()
+    for _, _, _, cs in sized.values():
+        if cs is not ctx:
+            cs.close()
     ctx.close()
     if exit_code:
         sys.exit(exit_code)

@@ -9,6 +9,15 @@ import torch.distributed as dist
 # KITTI odometry sequence lengths 00..07 (public benchmark numbers; BASELINE config #5)
 KITTI_LENGTHS = (4541, 1101, 4661, 801, 271, 2761, 1101, 1101)
 
+# Frame size and rectified calibration of the same sequences (public KITTI odometry calib.txt values; SURVEY.md 8(d)
+# config #5: "real 03 is 1242x375 and 04-07 1226x370 with different intrinsics; one YAML per sequence").  The reference
+# reads whatever size is on disk (src/System.cpp:75-104) and takes the rig from its YAML (src/parameter.cpp:18-45):
+# 00-02 are the values config/default.yaml ships.
+KITTI_RIG_A = dict(width=1241, height=376, fx=718.856, fy=718.856, cx=607.193, cy=185.216, baseline=0.537)       # 00-02
+KITTI_RIG_B = dict(width=1242, height=375, fx=721.5377, fy=721.5377, cx=609.5593, cy=172.854, baseline=0.53715)  # 03
+KITTI_RIG_C = dict(width=1226, height=370, fx=707.0912, fy=707.0912, cx=601.8873, cy=183.1104, baseline=0.53715)  # 04-12
+KITTI_RIGS = (KITTI_RIG_A, KITTI_RIG_A, KITTI_RIG_A, KITTI_RIG_B, KITTI_RIG_C, KITTI_RIG_C, KITTI_RIG_C, KITTI_RIG_C)
+
 
 def sequence_seed(rank, world):
     """Seed of the synthetic sequence a rank renders (single GPU: S0's seed)."""

@@ -179,11 +179,9 @@ def test_lk_second_seed_24_pairs(pkg, oracle, tc, synth):
     _check_online(pkg, seq, frames, ref)
 
 
-def test_orb_24_pairs_batched_and_online(pkg, oracle, tc, s0_100):
-    """BASELINE config #3 over 24 consecutive pairs: both sides' ORB keypoints and descriptors byte-equal,
-    matches, RANSAC record, pose chain; online and batched."""
-    seq, frames = s0_100
-    frames = frames[:25]
+def _check_orb_sequence(pkg, oracle, tc, seq, frames, min_ok, min_tracked=50):
+    """ORB mode over consecutive pairs: both sides' ORB keypoints and descriptors byte-equal, matches, RANSAC record,
+    pose chain; online and batched."""
     h, w = frames[0][0].shape
     P1, P2 = seq.proj()
     prm = oracle.make_params(P1, P2, min_t2=0.05 ** 2, max_t2=10.0 ** 2)
@@ -206,7 +204,7 @@ def test_orb_24_pairs_batched_and_online(pkg, oracle, tc, s0_100):
         if r["ok"]:
             pose = pose @ r["T_rel_inv"]
         ref.append((r, tr, pnp, pose.copy()))
-    assert sum(r["ok"] for r, _, _, _ in ref) >= 23 and min(r["n_tracked"] for r, _, _, _ in ref) > 50
+    assert sum(r["ok"] for r, _, _, _ in ref) >= min_ok and min(r["n_tracked"] for r, _, _, _ in ref) > min_tracked
     kw = dict(P1=P1, P2=P2, track_mode=pkg.MODE_ORB, min_move2=0.05 ** 2, max_move2=10.0 ** 2)
     c = pkg.Context(w, h, device=0, **kw)
     for t, fr in enumerate(frames):
@@ -232,6 +230,13 @@ def test_orb_24_pairs_batched_and_online(pkg, oracle, tc, s0_100):
         _check_record(res[p], r, pnp)
         assert relfro(res[p]["pose"].reshape(4, 4), pose) <= CHAIN_TIGHT
     c.close()
+
+
+def test_orb_24_pairs_batched_and_online(pkg, oracle, tc, s0_100):
+    """BASELINE config #3 over 24 consecutive pairs: both sides' ORB keypoints and descriptors byte-equal,
+    matches, RANSAC record, pose chain; online and batched."""
+    seq, frames = s0_100
+    _check_orb_sequence(pkg, oracle, tc, seq, frames[:25], min_ok=23)
 
 
 def test_hd_whole_step_on_exactly_2000_strongest_corners(pkg, oracle, tc, synth):

@@ -27,7 +27,7 @@ camera_r.fx: {fx}
 camera_r.fy: {fy}
 camera_r.cx: {cx}
 camera_r.cy: {cy}
-t_lr0: -0.537
+t_lr0: {tlr0}
 t_lr1: 0.00
 t_lr2: 0.00
 R_lr0: 1.0
@@ -72,9 +72,9 @@ def host_built(pkg):
     return HOST
 
 
-def _write_yaml(path, dataset, fx=718.856, fy=718.856, cx=607.193, cy=185.216, mode="LK_stereof2f_pnp"):
+def _write_yaml(path, dataset, fx=718.856, fy=718.856, cx=607.193, cy=185.216, mode="LK_stereof2f_pnp", baseline=0.537):
     with open(path, "w", encoding="utf-8") as f:
-        f.write(YAML.format(dataset=dataset, fx=fx, fy=fy, cx=cx, cy=cy, mode=mode))
+        f.write(YAML.format(dataset=dataset, fx=fx, fy=fy, cx=cx, cy=cy, mode=mode, tlr0=repr(-float(baseline))))
 
 
 def _write_pgm(path, img):
