@@ -243,6 +243,10 @@ int svo_track_uploaded(svo_ctx *ctx, int buf, int n_frames, const double *pose0,
  * (no host round trip; pose0 is ignored); 0 seeds it with pose0 (NULL = identity). */
 int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, const double *pose0, int continue_chain);
 int svo_collect_results(svo_ctx *ctx, svo_step_result *results, int n_pairs);
+/* ABI v6, non-blocking: *n_pairs = the pairs of the OLDEST outstanding async batch when its records are complete (a
+ * following svo_collect_results does not wait), 0 when it is still running or nothing is outstanding.  What a
+ * streaming caller polls between frames (host: System::StreamPoll behind Step_ros, reference src/System.cpp:60-74). */
+int svo_results_ready(svo_ctx *ctx, int *n_pairs);
 
 /* Read-back of the online state (after svo_add_frame), for callers that keep the reference's
  * per-frame carriers or draw what Tracking::displayTracking drew (src/tracking.cpp:345-382):

@@ -103,6 +103,7 @@ def load_library():
     lib.svo_track_uploaded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     lib.svo_track_uploaded_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     lib.svo_collect_results.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.svo_results_ready.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.svo_set_pose.argtypes = [C.c_void_p, C.c_void_p]
     _LIB = lib
     return lib
@@ -450,6 +451,12 @@ class Context:
         out = np.zeros(int(n_pairs), dtype=STEP_DTYPE)
         self._check(self.lib.svo_collect_results(self.h, C.c_void_p(out.ctypes.data), int(n_pairs)))
         return out
+
+    def results_ready(self):
+        """Pairs of the oldest outstanding async batch when its records are complete, else 0 (svo_results_ready)."""
+        n = C.c_int(0)
+        self._check(self.lib.svo_results_ready(self.h, C.byref(n)))
+        return n.value
 
     def set_pose(self, pose):
         pose = np.ascontiguousarray(pose, np.float64).reshape(16)

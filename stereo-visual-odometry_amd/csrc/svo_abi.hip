@@ -806,6 +806,21 @@ extern "C" int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, con
     return rc;
 }
 
+// Non-blocking companion of svo_collect_results (ABI v6): a streaming caller polls between frames.
+extern "C" int svo_results_ready(svo_ctx *ctx, int *n_pairs)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    SVO_ARG(n_pairs, "null output");
+    *n_pairs = 0;
+    if (ctx->async_tail == ctx->async_head) return SVO_OK;
+    const int r = (int)(ctx->async_head & 1);
+    SVO_HIP(hipSetDevice(ctx->device));
+    const hipError_t e = hipEventQuery(ctx->ev_async[r]);
+    if (e == hipSuccess) *n_pairs = ctx->async_n[r];
+    else if (e != hipErrorNotReady) SVO_HIP(e);
+    return SVO_OK;
+}
+
 extern "C" int svo_collect_results(svo_ctx *ctx, svo_step_result *results, int n_pairs)
 {
     if (!ctx) return SVO_ERR_ARG;

@@ -25,6 +25,22 @@ public:
     // batch_size > 1 (additive keys batch_size / decode_threads; absent = the reference's per-frame loop).
     void RunBatched(int batch_size, int decode_threads);
 
+    // additive: a PIPELINED stream behind Step_ros (reference src/System.cpp:60-74 feeds one externally supplied frame per
+    // call and blocks until its pose exists).  Consecutive pairs are independent, so a live stream may
+    // trade latency for throughput: frames are gathered into micro-batches of `stream_depth` pairs in page-locked
+    // memory; a full micro-batch is uploaded and launched WITHOUT waiting (up to two are in flight, the pose chain
+    // continues on the device), and the poses come back `stream_depth` to 3 x `stream_depth` frames late, byte for byte
+    // the per-frame loop's.  YAML key `stream_depth: k` (k >= 1) routes Step_ros and Run() through it.
+    //   StreamPush  : hands one frame over (the images are copied; the frame may be reused at once)
+    //   StreamPoll  : appends the poses (row-major 4x4, frame order, frame 0 = identity included) completed since the
+    //                 last call; wait = true blocks until everything submitted so far is there
+    //   StreamFlush : submits the partial micro-batch, if any; follow it with StreamPoll(poses, true)
+    bool StreamPush(Frame::Ptr frame);
+    int StreamPoll(std::vector<Pose4x4> &poses, bool wait = false);
+    bool StreamFlush();
+    int StreamDepth() const { return stream_depth_; }
+    void SetStreamDepth(int k) { if (!stream_.active) stream_depth_ = k; }
+
     // additive: write one KITTI-format pose row (12 numbers of [R|t]) per frame
     bool SetPoseFile(const std::string &path);
     // additive: per-frame track dump (text), the headless replacement of displayTracking
@@ -62,6 +78,20 @@ private:
     // another System may have loaded ITS file by the time Run() is called)
     int batch_size_ = 1, decode_threads_ = 0;
     double loop_seconds_ = 0;
+    // pipelined stream (StreamPush / StreamPoll)
+    int stream_depth_ = 0;
+    struct StreamState {
+        bool active = false, failed = false;
+        int w = 0, h = 0, pitch = 0;
+        size_t fbytes = 0;
+        uint8_t *pin[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+        int buf = 0, n = 0, chunk = 0;         // current page-locked buffer, frames in it, micro-batches launched
+        bool uploaded[2] = {false, false};
+        std::vector<Pose4x4> done;             // completed poses not yet handed out
+    } stream_;
+    bool StreamSubmit();
+    bool StreamCollect(bool block);
+    void StreamRelease();
 };
 
 // 8-bit grayscale image readers used by NextFrame_kitti: binary PGM (P5) and PNG (8-bit gray or

@@ -47,6 +47,9 @@ public:
     // records and advances frame_pose_ exactly as n_frames - 1 AddFrame calls would.
     bool EnsureBatchContext(int width, int height, int max_batch) { return EnsureContext(width, height, max_batch); }
     svo_ctx *Context() { return ctx_; }
+    // pairs of the oldest outstanding async batch when its records are complete (CollectUploaded will not wait), else 0
+    int ResultsReady();
+    int Outstanding() const { return (int)(async_tail_ - async_head_); }
     bool TrackUploaded(int buf, int n_frames, std::vector<svo_step_result> &out);
     // the same in two halves: launch without waiting for the GPU, then (after the caller has decoded and
     // uploaded the next chunk, whose copy then overlaps this batch's kernels) collect the records

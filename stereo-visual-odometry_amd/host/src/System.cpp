@@ -243,6 +243,14 @@ System::System(std::string &config_path) : config_file_path_(config_path)
     if (Config::Has("fill_features") && Config::Get<int>("fill_features") != 0) tracking_->SetFillFeatures(true);
     batch_size_ = Config::Has("batch_size") ? Config::Get<int>("batch_size") : 1;
     decode_threads_ = Config::Has("decode_threads") ? Config::Get<int>("decode_threads") : 0;    // 0: the usable cores
+    stream_depth_ = Config::Has("stream_depth") ? Config::Get<int>("stream_depth") : 0;           // 0: Step_ros is synchronous
+}
+
+System::~System()
+{
+    StreamRelease();
+    if (pose_file_) fclose(pose_file_);
+    if (tracks_file_) fclose(tracks_file_);
 }
 
 // cores this process may run on (the affinity mask, not the machine's core count), at most 64
@@ -274,12 +282,6 @@ int System::CountFrames() const
     int n = 0;
     while (have(n)) n++;
     return n;
-}
-
-System::~System()
-{
-    if (pose_file_) fclose(pose_file_);
-    if (tracks_file_) fclose(tracks_file_);
 }
 
 bool System::SetTracksFile(const std::string &path)
@@ -329,6 +331,17 @@ void System::Run()
         Shutdown();
         return;
     }
+    if (stream_depth_ > 0) {                               // the per-frame loop through the pipelined stream
+        for (;;) {
+            Frame::Ptr f = NextFrame_kitti();
+            if (f == nullptr || !Step_ros(f)) break;
+        }
+        std::vector<Pose4x4> poses;
+        if (StreamFlush()) StreamPoll(poses, true);
+        for (const auto &P : poses) WritePoseRow(P.m);
+        Shutdown();
+        return;
+    }
     while (1) {
         if (Step() == false) break;
     }
@@ -352,6 +365,15 @@ bool System::Step()
 bool System::Step_ros(Frame::Ptr new_frame)
 {
     if (new_frame == nullptr) return false;
+    if (stream_depth_ > 0) {
+        // pipelined: the frame joins the current micro-batch; poses that have completed meanwhile go to the pose file.
+        // The return value says the frame was ACCEPTED (its own pose follows stream_depth frames later).
+        if (!StreamPush(new_frame)) return false;
+        std::vector<Pose4x4> poses;
+        StreamPoll(poses, false);
+        for (const auto &P : poses) WritePoseRow(P.m);
+        return true;
+    }
     bool success = tracking_->AddFrame(new_frame);
     WritePose();
     WriteTracks();
@@ -498,6 +520,110 @@ void System::RunBatched(int B, int decode_threads)
     loop_seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
     for (int q = 0; q < 2; q++)
         for (int cam = 0; cam < 2; cam++) svo_host_free(ctx, pin[q][cam]);
+}
+
+// ---- pipelined stream ----------------------------------------------------------------------------
+void System::StreamRelease()
+{
+    svo_ctx *ctx = tracking_ ? tracking_->Context() : nullptr;
+    for (int k = 0; k < 2; k++)
+        for (int cam = 0; cam < 2; cam++)
+            if (stream_.pin[k][cam]) { if (ctx) svo_host_free(ctx, stream_.pin[k][cam]); stream_.pin[k][cam] = nullptr; }
+    stream_.active = false;
+}
+
+// the oldest outstanding micro-batch's poses -> stream_.done (block = false: only when they are ready)
+bool System::StreamCollect(bool block)
+{
+    if (tracking_->Outstanding() == 0) return false;
+    if (!block && tracking_->ResultsReady() == 0) return false;
+    std::vector<svo_step_result> recs;
+    if (!tracking_->CollectUploaded(recs)) { stream_.failed = true; return false; }
+    for (const auto &r : recs) {
+        Pose4x4 P;
+        memcpy(P.m, r.pose, sizeof(P.m));
+        stream_.done.push_back(P);
+    }
+    return true;
+}
+
+bool System::StreamSubmit()
+{
+    StreamState &s = stream_;
+    svo_ctx *ctx = tracking_->Context();
+    if (s.n < 2) return true;
+    if (tracking_->Outstanding() == 2 && !StreamCollect(true)) return false;     // at most two in flight
+    if (svo_upload_frames(ctx, s.buf, s.pin[s.buf][0], s.pin[s.buf][1], s.pitch, (int64_t)s.fbytes, s.n) != SVO_OK) {
+        LZB_LOG("ERROR", "svo_upload_frames: %s", svo_last_error(ctx));
+        return false;
+    }
+    s.uploaded[s.buf] = true;
+    if (!tracking_->TrackUploadedAsync(s.buf, s.n, s.chunk > 0)) return false;
+    s.chunk++;
+    // the other buffer takes over: its own upload (two submissions ago) must have left the page-locked memory, and the
+    // last frame of this micro-batch is the halo of the next one
+    const int nb = s.buf ^ 1;
+    if (s.uploaded[nb] && svo_wait_upload(ctx, nb) != SVO_OK) return false;
+    for (int cam = 0; cam < 2; cam++)
+        memcpy(s.pin[nb][cam], s.pin[s.buf][cam] + (size_t)(s.n - 1) * s.fbytes, s.fbytes);
+    s.buf = nb;
+    s.n = 1;
+    return true;
+}
+
+bool System::StreamPush(Frame::Ptr frame)
+{
+    StreamState &s = stream_;
+    if (frame == nullptr || s.failed) return false;
+    const cv::Mat &L = frame->left_img_, &R = frame->right_img_;
+    if (L.empty() || R.empty() || L.cols != R.cols || L.rows != R.rows) return false;
+    const int k = stream_depth_ > 0 ? stream_depth_ : 1;
+    if (!s.active) {
+        if (!tracking_->EnsureBatchContext(L.cols, L.rows, k)) return false;
+        svo_ctx *ctx = tracking_->Context();
+        s.w = L.cols; s.h = L.rows;
+        s.pitch = (s.w + 255) / 256 * 256;
+        s.fbytes = (size_t)s.pitch * s.h;
+        for (int q = 0; q < 2; q++)
+            for (int cam = 0; cam < 2; cam++)
+                if (svo_host_alloc(ctx, s.fbytes * (size_t)(k + 1), (void **)&s.pin[q][cam]) != SVO_OK) {
+                    LZB_LOG("ERROR", "svo_host_alloc: %s", svo_last_error(ctx));
+                    StreamRelease();
+                    return false;
+                }
+        s.active = true;
+        s.buf = 0; s.n = 0; s.chunk = 0;
+        Pose4x4 I = tracking_->GetPose();                   // frame 0: StereoInit_f2f only, the pose it starts from
+        s.done.push_back(I);
+    }
+    if (L.cols != s.w || L.rows != s.h) {
+        LZB_LOG("ERROR", "stream: frame size changed from %dx%d to %dx%d", s.w, s.h, L.cols, L.rows);
+        return false;
+    }
+    const cv::Mat *img[2] = {&L, &R};
+    for (int cam = 0; cam < 2; cam++) {
+        uint8_t *dst = s.pin[s.buf][cam] + (size_t)s.n * s.fbytes;
+        for (int y = 0; y < s.h; y++) memcpy(dst + (size_t)y * s.pitch, img[cam]->ptr(y), (size_t)s.w);
+    }
+    s.n++;
+    if (s.n == k + 1 && !StreamSubmit()) { s.failed = true; return false; }
+    return true;
+}
+
+int System::StreamPoll(std::vector<Pose4x4> &poses, bool wait)
+{
+    while (StreamCollect(false)) {}
+    if (wait) while (tracking_->Outstanding() > 0 && StreamCollect(true)) {}
+    const int n = (int)stream_.done.size();
+    poses.insert(poses.end(), stream_.done.begin(), stream_.done.end());
+    stream_.done.clear();
+    return n;
+}
+
+bool System::StreamFlush()
+{
+    if (!stream_.active || stream_.failed) return stream_.active && !stream_.failed;
+    return StreamSubmit();
 }
 
 void System::Shutdown() {}

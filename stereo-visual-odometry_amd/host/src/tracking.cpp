@@ -275,6 +275,13 @@ bool Tracking::TrackUploadedAsync(int buf, int n_frames, bool continue_chain)
     return true;
 }
 
+int Tracking::ResultsReady()
+{
+    int n = 0;
+    if (!ctx_ || async_tail_ == async_head_ || svo_results_ready(ctx_, &n) != SVO_OK) return 0;
+    return n;
+}
+
 bool Tracking::CollectUploaded(std::vector<svo_step_result> &out)
 {
     if (!ctx_ || async_tail_ == async_head_) return false;

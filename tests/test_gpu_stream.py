@@ -1,0 +1,91 @@
+"""The pipelined stream behind Step_ros (-m gpu): micro-batches of k frames, results k frames late, poses byte for byte
+the per-frame loop's.  Python twin (stream.FrameStream on the C-ABI) for k = 1, 2, 3, 5 and a partial last batch, both
+modes; the C++ System::StreamPush / StreamPoll through `run_kitti_stereo` with the YAML key stream_depth.
+Reference entry point: src/System.cpp:60-74 (Step_ros: one externally supplied frame per call)."""
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import conftest
+
+pytestmark = pytest.mark.gpu
+HOST = os.path.join(conftest.ROOT, "stereo-visual-odometry_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def frames11(synth):
+    seq = synth.StereoSequence(width=416, height=128, n_frames=11, seed=5)
+    return seq, [tuple(x.numpy() for x in seq.render(t)) for t in range(11)]
+
+
+def _online(pkg, seq, frames, **kw):
+    P1, P2 = seq.proj()
+    c = pkg.Context(frames[0][0].shape[1], frames[0][0].shape[0], device=0, P1=P1, P2=P2, **kw)
+    recs = []
+    c.add_frame(*frames[0])
+    for fr in frames[1:]:
+        rc, g = c.add_frame(*fr)
+        recs.append(g)
+    c.close()
+    return recs
+
+
+@pytest.mark.parametrize("mode", ["lk", "orb"])
+@pytest.mark.parametrize("depth", [1, 2, 3, 5])
+def test_frame_stream_equals_the_per_frame_loop(pkg, frames11, depth, mode):
+    stream = importlib.import_module(conftest.entry.PKG_NAME + ".stream")
+    seq, frames = frames11
+    kw = dict(track_mode=pkg.MODE_ORB, min_move2=0.05 ** 2, max_move2=100.0, orb_nlevels=3, orb_nfeatures=400) if mode == "orb" else {}
+    want = _online(pkg, seq, frames, **kw)
+    P1, P2 = seq.proj()
+    c = pkg.Context(416, 128, device=0, P1=P1, P2=P2, max_batch=depth, **kw)
+    c.set_overlap(True)
+    fs = stream.FrameStream(c, depth)
+    got, arrived_at = [], []
+    for t, fr in enumerate(frames):
+        for chunk in fs.push(*fr):
+            got.extend(chunk)
+            arrived_at.extend([t] * len(chunk))
+    for chunk in fs.flush():
+        got.extend(chunk)
+    fs.close()
+    c.close()
+    assert len(got) == len(want) == 10
+    for p, (g, w) in enumerate(zip(got, want)):
+        for k in ("ok", "fail_stage", "n_prev_kps", "n_cur_kps", "n_tracked", "n_inliers", "ransac_iters", "lm_iters"):
+            assert int(g[k]) == int(w[k]), (p, k)
+        assert g["T_rel_inv"].tobytes() == w["T_rel_inv"].tobytes() and g["pose"].tobytes() == w["pose"].tobytes(), p
+    # pair p rides micro-batch p // depth, launched with the push of frame (p // depth + 1) * depth; its records are
+    # there at the latest when the micro-batch after the next one is launched (two in flight)
+    for p, t in enumerate(arrived_at):
+        assert (p // depth + 1) * depth <= t <= (p // depth + 3) * depth, (p, t)
+
+
+def test_run_kitti_stereo_stream_depth(pkg, frames11, tmp_path):
+    """YAML `stream_depth: k`: System::Run feeds Step_ros, which queues the frames (StreamPush) and writes the poses as
+    they complete -- the pose file equals the per-frame loop's byte for byte, in both modes."""
+    from test_host_api import _write_pgm, _write_yaml
+    pkg.build_library()
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    seq, frames = frames11
+    for cam in (0, 1):
+        os.makedirs(tmp_path / f"image_{cam}")
+    for t, (L, R) in enumerate(frames):
+        _write_pgm(tmp_path / "image_0" / f"{t:06d}.pgm", L)
+        _write_pgm(tmp_path / "image_1" / f"{t:06d}.pgm", R)
+    exe = os.path.join(HOST, "run_kitti_stereo")
+    for mode in ("LK_stereof2f_pnp", "ORB_stereof2f_pnp"):
+        _write_yaml(tmp_path / "base.yaml", str(tmp_path), fx=seq.fx, fy=seq.fy, cx=seq.cx, cy=seq.cy, mode=mode)
+        txt = open(tmp_path / "base.yaml", encoding="utf-8").read()
+        outs = {}
+        for name, extra in (("loop", ""), ("k1", "stream_depth: 1\n"), ("k4", "stream_depth: 4\n"), ("k16", "stream_depth: 16\n")):
+            open(tmp_path / f"{name}.yaml", "w", encoding="utf-8").write(txt + extra)
+            out = tmp_path / f"{name}.{mode}.txt"
+            r = subprocess.run([exe, str(tmp_path / f"{name}.yaml"), str(out)], capture_output=True, timeout=300)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            outs[name] = open(out, "rb").read()
+        assert len(outs["loop"].splitlines()) == 11
+        assert outs["k1"] == outs["loop"] and outs["k4"] == outs["loop"] and outs["k16"] == outs["loop"], mode
