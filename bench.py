@@ -333,6 +333,54 @@ def cpu_orb(O, L, R, width, P1, P2, n1, n_all):
                                     f"call per worker thread, {cores} workers ({os.cpu_count()} host cpus visible)"}}
 
 
+def stream_leg(pkg, stream_mod, L, R, width, height, P1, P2, mode_kw, depths=(1, 2, 4, 8, 16, 32), target=4000.0):
+    """The pipelined stream behind Step_ros (FrameStream == System::StreamPush / StreamPoll): frames arrive one at a
+    time in host memory, as fast as the stream accepts them; micro-batches of k pairs, at most two in flight.  Per k:
+    sustained pairs/s from the first push to the last pose on the host, and the latency of a pose = its arrival minus
+    the push of its frame (under saturation: the queueing a k-deep pipeline adds)."""
+    res = {"definition": "frames pushed one by one from host memory as fast as the stream accepts them (closed loop); micro-batches of k "
+                         "pairs through svo_upload_frames + svo_track_uploaded_async(continue_chain), two in flight, records polled; "
+                         "latency = pose on the host - push of its frame; poses are byte-identical to the per-frame loop (tests/test_gpu_stream.py)",
+           "depths": {}}
+    best = None
+    for k in depths:
+        n = int(min(L.shape[0], max(96, 40 * k)))
+        fl = [L[f, :, :width].cpu().numpy() for f in range(n)]
+        fr = [R[f, :, :width].cpu().numpy() for f in range(n)]
+        ctx = pkg.Context(width, height, max_batch=k, P1=P1, P2=P2, **mode_kw)
+        ctx.set_overlap(True)
+        fs = stream_mod.FrameStream(ctx, k)
+        for rep in range(2):                                   # the first pass warms the context up
+            fs.restart()
+            t_push, t_done, ok = [], [], 0
+            t0 = time.perf_counter()
+            for f in range(n):
+                t_push.append(time.perf_counter())
+                for chunk in fs.push(fl[f], fr[f]):
+                    now = time.perf_counter()
+                    t_done.extend([now] * len(chunk))
+                    ok += int(chunk["ok"].sum())
+            for chunk in fs.flush():
+                now = time.perf_counter()
+                t_done.extend([now] * len(chunk))
+                ok += int(chunk["ok"].sum())
+            el = time.perf_counter() - t0
+        fs.close()
+        ctx.close()
+        lat = np.array(t_done) - np.array(t_push[1:len(t_done) + 1])
+        rate = (n - 1) / el
+        res["depths"][str(k)] = {"pairs_per_s": round(rate, 1), "frames": n, "pairs_ok": ok,
+                                 "latency_ms_median": round(1e3 * float(np.median(lat)), 3),
+                                 "latency_ms_p90": round(1e3 * float(np.percentile(lat, 90)), 3)}
+        if best is None and rate >= target:
+            best = k
+    res["target_pairs_per_s"] = target
+    res["smallest_depth_sustaining_target"] = best
+    if best is not None:
+        res["latency_ms_median_at_that_depth"] = res["depths"][str(best)]["latency_ms_median"]
+    return res
+
+
 def e2e_leg(args, L, R, P1, width):
     """run_kitti_stereo (the reference's CLI, batched runner) on a KITTI-layout directory of the bench's own S0 frames,
     once from PGM and once from PNG files (the reference's input format): pairs/s from process start to exit."""
@@ -743,6 +791,10 @@ def main():
         out["online"] = {"ms_per_pair_median": round(float(np.median(lat)), 3), "ms_per_pair_p90": round(float(np.percentile(lat, 90)), 3),
                          "pairs_per_s": round(1e3 / float(np.mean(lat)), 1), "pairs": len(lat), "pairs_ok": ok_on - 8,
                          "definition": "config #2 single-stream: svo_add_frame per stereo pair, frames in host memory, result on the host"}
+        # ---- the pipelined stream behind Step_ros: k frames of latency for throughput -------------------------------
+        if not args.no_legs:
+            out["stream"] = stream_leg(pkg, importlib.import_module(entry.PKG_NAME + ".stream"), L, R, W, H, P1, P2,
+                                       {k: v for k, v in mode_kw.items()})
         # ---- legs on their own contexts (N = 1): the other BASELINE configs and the x86-order LK mode ----------------
         if not args.no_legs:
             O = None

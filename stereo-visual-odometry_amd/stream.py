@@ -20,6 +20,11 @@ class FrameStream:
         self.outstanding = []              # pairs of the micro-batches in flight, oldest first
         self.uploaded = [False, False]
 
+    def restart(self):
+        """A new sequence on the same context (nothing may be in flight): frame 0 next, pose chain from identity."""
+        assert not self.outstanding
+        self.buf, self.n, self.chunk = 0, 0, 0
+
     def close(self):
         for b in self.pin:
             for v in b:
