@@ -226,7 +226,8 @@ int svo_wait_results(svo_ctx *ctx);
  *       lives in the other buffer.  The host memory must stay untouched until svo_wait_upload;
  *   svo_track_uploaded : svo_track_batch on the frames of buffer `buf` (ordered after their upload
  *       on the device, no host wait). */
-int svo_host_alloc(svo_ctx *ctx, size_t bytes, void **out);
+int svo_host_alloc(svo_ctx *ctx, size_t bytes, void **out);   /* ctx may be NULL (ABI v6): the memory is portable across
+                                                                  devices, so it can be pinned while svo_create still runs */
 int svo_host_free(svo_ctx *ctx, void *p);
 int svo_upload_frames(svo_ctx *ctx, int buf, const uint8_t *left_frames, const uint8_t *right_frames,
                       int pitch, int64_t frame_stride, int n_frames);

@@ -2102,47 +2102,50 @@ int orb_alloc(svo_ctx *ctx)
     ctx->orb_cand_cap = 4 * ctx->cfg.max_keypoints < 65535 ? 4 * ctx->cfg.max_keypoints : 65535;
     const int kCandCap = ctx->orb_cand_cap;
     SVO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), svo_bit_pattern_31, 1024));
+#define DA(ptr, bytes) do { if (dev_alloc(ctx, &(ptr), (bytes)) != SVO_OK) return SVO_ERR_HIP; } while (0)
     {
         std::vector<int2> xt; std::vector<int4> yt;
         orb_make_tables(g, xt, yt);
-        SVO_HIP(hipMalloc(&ctx->orb_xtab, sizeof(int2) * (xt.size() + 1)));
-        SVO_HIP(hipMalloc(&ctx->orb_ytab, sizeof(int4) * (yt.size() + 1)));
-        if (!xt.empty()) SVO_HIP(hipMemcpy(ctx->orb_xtab, xt.data(), sizeof(int2) * xt.size(), hipMemcpyHostToDevice));
-        if (!yt.empty()) SVO_HIP(hipMemcpy(ctx->orb_ytab, yt.data(), sizeof(int4) * yt.size(), hipMemcpyHostToDevice));
+        DA(ctx->orb_xtab, sizeof(int2) * (xt.size() + 1));
+        DA(ctx->orb_ytab, sizeof(int4) * (yt.size() + 1));
+        // (inside svo_create the buffers exist only after the context's one allocation: the uploads wait for it)
+        const int rc_up = dev_defer(ctx, [ctx, xt, yt]() {
+            if (!xt.empty()) SVO_HIP(hipMemcpy(ctx->orb_xtab, xt.data(), sizeof(int2) * xt.size(), hipMemcpyHostToDevice));
+            if (!yt.empty()) SVO_HIP(hipMemcpy(ctx->orb_ytab, yt.data(), sizeof(int4) * yt.size(), hipMemcpyHostToDevice));
+            return SVO_OK;
+        });
+        if (rc_up != SVO_OK) return rc_up;
     }
-    SVO_HIP(hipMalloc(&ctx->orb_slots, (size_t)g.slot_bytes * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_blur, (size_t)g.blur_total * n_img + 64));     // + the descriptor kernel's last dword past a row end
-    SVO_HIP(hipMalloc(&ctx->orb_cell_cand, sizeof(float4) * (size_t)g.cells_total * kCellCap * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_cell_cnt, sizeof(int) * (size_t)g.cells_total * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_lvl_cand, sizeof(float4) * (size_t)kCandCap * L * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_lvl_cnt, sizeof(int) * (size_t)L * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_qkeys, sizeof(uint2) * (size_t)kCandCap * L * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_qtmp, sizeof(uint2) * (size_t)kCandCap * L * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_sel, sizeof(int) * (size_t)ctx->orb_node_cap * L * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_sel_cnt, sizeof(int) * (size_t)L * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_overflow, sizeof(int) * (size_t)n_img));
-    SVO_HIP(hipMemset(ctx->orb_overflow, 0, sizeof(int) * (size_t)n_img));
+    DA(ctx->orb_slots, (size_t)g.slot_bytes * n_img);
+    DA(ctx->orb_blur, (size_t)g.blur_total * n_img + 64);     // + the descriptor kernel's last dword past a row end
+    DA(ctx->orb_cell_cand, sizeof(float4) * (size_t)g.cells_total * kCellCap * n_img);
+    DA(ctx->orb_cell_cnt, sizeof(int) * (size_t)g.cells_total * n_img);
+    DA(ctx->orb_lvl_cand, sizeof(float4) * (size_t)kCandCap * L * n_img);
+    DA(ctx->orb_lvl_cnt, sizeof(int) * (size_t)L * n_img);
+    DA(ctx->orb_qkeys, sizeof(uint2) * (size_t)kCandCap * L * n_img);
+    DA(ctx->orb_qtmp, sizeof(uint2) * (size_t)kCandCap * L * n_img);
+    DA(ctx->orb_sel, sizeof(int) * (size_t)ctx->orb_node_cap * L * n_img);
+    DA(ctx->orb_sel_cnt, sizeof(int) * (size_t)L * n_img);
+    DA(ctx->orb_overflow, sizeof(int) * (size_t)n_img);
+    {
+        const int rc_z = dev_defer(ctx, [ctx, n_img]() { SVO_HIP(hipMemset(ctx->orb_overflow, 0, sizeof(int) * (size_t)n_img)); return SVO_OK; });
+        if (rc_z != SVO_OK) return rc_z;
+    }
     ctx->orb_kp_cap = ctx->cfg.max_keypoints;
-    SVO_HIP(hipMalloc(&ctx->orb_kps, sizeof(svo_keypoint) * (size_t)ctx->orb_kp_cap * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_desc, (size_t)32 * ctx->orb_kp_cap * n_img));
-    SVO_HIP(hipMalloc(&ctx->orb_n, sizeof(int) * (size_t)n_img));
+    DA(ctx->orb_kps, sizeof(svo_keypoint) * (size_t)ctx->orb_kp_cap * n_img);
+    DA(ctx->orb_desc, (size_t)32 * ctx->orb_kp_cap * n_img);
+    DA(ctx->orb_n, sizeof(int) * (size_t)n_img);
     const int B = ctx->cfg.max_batch;
     for (int k = 0; k < 2; k++) {
-        SVO_HIP(hipMalloc(&ctx->orb_midx[k], sizeof(int) * (size_t)ctx->orb_kp_cap * B));
-        SVO_HIP(hipMalloc(&ctx->orb_mdist[k], sizeof(float) * (size_t)ctx->orb_kp_cap * B));
+        DA(ctx->orb_midx[k], sizeof(int) * (size_t)ctx->orb_kp_cap * B);
+        DA(ctx->orb_mdist[k], sizeof(float) * (size_t)ctx->orb_kp_cap * B);
     }
+#undef DA
     ctx->orb_ready = true;
     return SVO_OK;
 }
 
-void orb_free(svo_ctx *c)
-{
-    auto F = [](void *p) { if (p) (void)hipFree(p); };
-    F(c->orb_slots); F(c->orb_xtab); F(c->orb_ytab); F(c->orb_blur); F(c->orb_cell_cand); F(c->orb_cell_cnt); F(c->orb_lvl_cand);
-    F(c->orb_lvl_cnt); F(c->orb_qkeys); F(c->orb_qtmp);
-    F(c->orb_sel); F(c->orb_sel_cnt); F(c->orb_overflow); F(c->orb_kps); F(c->orb_desc); F(c->orb_n);
-    for (int k = 0; k < 2; k++) { F(c->orb_midx[k]); F(c->orb_mdist[k]); }
-}
+void orb_free(svo_ctx *) {}        // the ORB buffers belong to the context's arena (or its lazy extras): freed with it
 
 // ORBextractor::operator() on `n_img` images (image b at img + b*img_stride, or interleaved L/R
 // when img2 != null) into output slots [slot0, slot0 + n_img).

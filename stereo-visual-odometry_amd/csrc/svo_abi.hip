@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <vector>
 #include "svo_ctx.h"
@@ -27,6 +28,49 @@ int pipeline_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t
 }  // namespace svo
 
 static int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+namespace svo {
+int dev_alloc_raw(svo_ctx *ctx, void **out, size_t bytes)
+{
+    *out = nullptr;
+    if (bytes == 0) bytes = 1;
+    if (ctx->arena.planning) {
+        ctx->arena.plan.emplace_back(out, ctx->arena.planned);
+        ctx->arena.planned += (bytes + 255) / 256 * 256;
+        return SVO_OK;
+    }
+    SVO_HIP(hipMalloc(out, bytes));
+    ctx->arena.extra.push_back(*out);
+    return SVO_OK;
+}
+
+int dev_defer(svo_ctx *ctx, std::function<int()> fn)
+{
+    if (!ctx->arena.planning) return fn();
+    ctx->arena.after.push_back(std::move(fn));
+    return SVO_OK;
+}
+
+static int dev_commit(svo_ctx *ctx)
+{
+    DevArena &a = ctx->arena;
+    a.planning = false;
+    SVO_HIP(hipMalloc((void **)&a.base, a.planned + 256));
+    for (auto &e : a.plan) *e.first = a.base + e.second;
+    a.plan.clear();
+    for (auto &fn : a.after) { const int rc = fn(); if (rc != SVO_OK) return rc; }
+    a.after.clear();
+    return SVO_OK;
+}
+
+static void dev_release(svo_ctx *ctx)
+{
+    for (void *p : ctx->arena.extra) if (p) (void)hipFree(p);
+    ctx->arena.extra.clear();
+    if (ctx->arena.base) (void)hipFree(ctx->arena.base);
+    ctx->arena.base = nullptr;
+}
+}  // namespace svo
 
 // Pyramid geometry: buildOpticalFlowPyramid stops adding levels once the next one would not
 // exceed the 21-pixel window ("if (sz.width <= winSize.width || sz.height <= winSize.height)").
@@ -98,26 +142,18 @@ extern "C" void svo_default_config(svo_config *cfg, int width, int height)
 
 static void free_all(svo_ctx *c)
 {
-    auto F = [](void *p) { if (p) (void)hipFree(p); };
-    F(c->slots); F(c->stage_img); F(c->score); F(c->rowcount); F(c->kp_xy); F(c->kp_resp); F(c->kp_n);
-    F(c->pts_in);
-    for (int i = 0; i < 4; i++) { F(c->pts_out[i]); F(c->status[i]); F(c->cmp[i]); }
-    F(c->keep); F(c->m_out); F(c->X3); F(c->pnp_ws); F(c->d_results); F(c->bslots); F(c->kp_n_snap);
+    dev_release(c);                                   // every device buffer: the arena + the lazy extras
     if (c->ev_front) (void)hipEventDestroy(c->ev_front);
     if (c->ev_back) (void)hipEventDestroy(c->ev_back);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     for (int k = 0; k < 2; k++) {
-        F(c->fb[k]);
         if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]);
         if (c->ev_fb_free[k]) (void)hipEventDestroy(c->ev_fb_free[k]);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    for (int k = 0; k < 2; k++) {
-        F(c->d_async[k]);
+    for (int k = 0; k < 2; k++)
         if (c->ev_async[k]) (void)hipEventDestroy(c->ev_async[k]);
-    }
     if (c->fetch_stream) (void)hipStreamDestroy(c->fetch_stream);
-    orb_free(c);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (int k = 0; k < 2; k++) if (c->ev_stage[k]) (void)hipEventDestroy(c->ev_stage[k]);
@@ -125,9 +161,20 @@ static void free_all(svo_ctx *c)
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
 }
 
+// SVO_TIMING=1: milliseconds of svo_create's phases on stderr (where a short run's start-up goes)
+static double now_ms()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+#define PHASE(name) do { if (timing_on) { const double t__ = now_ms(); fprintf(stderr, "[svo_create] %8.2f ms  %s\n", t__ - t_phase, name); t_phase = t__; } } while (0)
+
 extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
 {
     if (!cfg || !out) return SVO_ERR_ARG;
+    const bool timing_on = getenv("SVO_TIMING") != nullptr;
+    double t_phase = now_ms();
     *out = nullptr;
     if (cfg->width < 32 || cfg->height < 32 || cfg->max_keypoints < 64 || cfg->max_batch < 1 ||
         cfg->num_slots < 4 || cfg->width > 16384 || cfg->height > 16384)
@@ -157,60 +204,91 @@ extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
         delete ctx;
         return SVO_ERR_HIP;
     }
+    PHASE("hipGetDeviceCount (HIP runtime start)");
     auto fail = [&](int code) { free_all(ctx); delete ctx; return code; };
 #define CK(call) do { if ((call) != hipSuccess) { fprintf(stderr, "svo_create: %s failed\n", #call); return fail(SVO_ERR_HIP); } } while (0)
     CK(hipSetDevice(device));
     CK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
+    PHASE("hipSetDevice + stream");
     make_geom(cfg->width, cfg->height, &ctx->geom);
 
     const int w = cfg->width, h = cfg->height, cap = cfg->max_keypoints, B = cfg->max_batch;
     const int n_img = B + 1;
     ctx->n_img = n_img;
-    CK(hipMalloc(&ctx->slots, (size_t)cfg->num_slots * ctx->geom.slot_bytes));
-    CK(hipMemsetAsync(ctx->slots, 0, (size_t)cfg->num_slots * ctx->geom.slot_bytes, ctx->stream));
+    const bool orb = cfg->track_mode == SVO_MODE_ORB;
+    if (!orb && cfg->track_mode != SVO_MODE_LK) return fail(SVO_ERR_ARG);
+    // What only the LK pipeline touches is sized for ONE item in an ORB context (the stage API -- svo_fast_detect,
+    // svo_lk_track, svo_circular_match -- stays usable there); the ORB buffers of an LK context are allocated on first use.
+    const int n_fast = orb ? 1 : n_img, B_lk = orb ? 1 : B;
+    ctx->arena.planning = true;
+#define DA(ptr, bytes) do { if (dev_alloc(ctx, &(ptr), (bytes)) != SVO_OK) return fail(SVO_ERR_HIP); } while (0)
+    DA(ctx->slots, (size_t)cfg->num_slots * ctx->geom.slot_bytes);
+    dev_defer(ctx, [ctx]() { SVO_HIP(hipMemsetAsync(ctx->slots, 0, (size_t)ctx->cfg.num_slots * ctx->geom.slot_bytes, ctx->stream)); return SVO_OK; });
     ctx->slot_built.assign(cfg->num_slots, 0);
     ctx->stage_pitch = align_up(w, 256);
-    CK(hipMalloc(&ctx->stage_img, (size_t)ctx->stage_pitch * h * 2));
-    CK(hipHostMalloc(&ctx->h_stage, (size_t)ctx->stage_pitch * h * 2, hipHostMallocDefault));
-    for (int k = 0; k < 2; k++) CK(hipEventCreateWithFlags(&ctx->ev_stage[k], hipEventDisableTiming));
+    DA(ctx->stage_img, (size_t)ctx->stage_pitch * h * 2);
     ctx->spitch = align_up(w, 64);
     ctx->score_stride = (int64_t)ctx->spitch * h;
-    CK(hipMalloc(&ctx->score, (size_t)ctx->score_stride * n_img));
+    DA(ctx->score, (size_t)ctx->score_stride * n_fast);
     ctx->rowcount_stride = align_up(h, 64);
-    CK(hipMalloc(&ctx->rowcount, sizeof(int) * (size_t)ctx->rowcount_stride * n_img));
-    CK(hipMalloc(&ctx->kp_xy, sizeof(float2) * (size_t)cap * n_img));
-    CK(hipMalloc(&ctx->kp_resp, sizeof(float) * (size_t)cap * n_img));
-    CK(hipMalloc(&ctx->kp_n, sizeof(int) * (size_t)n_img));
-    CK(hipMalloc(&ctx->pts_in, sizeof(float2) * (size_t)cap * B));
+    DA(ctx->rowcount, sizeof(int) * (size_t)ctx->rowcount_stride * n_fast);
+    DA(ctx->kp_xy, sizeof(float2) * (size_t)cap * n_fast);
+    DA(ctx->kp_resp, sizeof(float) * (size_t)cap * n_fast);
+    DA(ctx->kp_n, sizeof(int) * (size_t)n_fast);
+    DA(ctx->pts_in, sizeof(float2) * (size_t)cap * B_lk);
     for (int i = 0; i < 4; i++) {
-        CK(hipMalloc(&ctx->pts_out[i], sizeof(float2) * (size_t)cap * B));
-        CK(hipMalloc(&ctx->status[i], (size_t)cap * B));
-        CK(hipMalloc(&ctx->cmp[i], sizeof(float2) * (size_t)cap * B));
+        DA(ctx->pts_out[i], sizeof(float2) * (size_t)cap * B_lk);
+        DA(ctx->status[i], (size_t)cap * B_lk);
+        DA(ctx->cmp[i], sizeof(float2) * (size_t)cap * B);
     }
-    CK(hipMalloc(&ctx->keep, (size_t)cap * B));
-    CK(hipMalloc(&ctx->m_out, sizeof(int) * (size_t)B));
-    CK(hipMalloc(&ctx->X3, sizeof(float) * 3 * (size_t)cap * B));
+    DA(ctx->keep, (size_t)cap * B_lk);
+    DA(ctx->m_out, sizeof(int) * (size_t)B);
+    DA(ctx->X3, sizeof(float) * 3 * (size_t)cap * B);
     if (geom_workspace_bytes(*cfg, B, &ctx->pnp_ws_bytes) != SVO_OK) return fail(SVO_ERR_ARG);
-    CK(hipMalloc(&ctx->pnp_ws, ctx->pnp_ws_bytes));
-    if (geom_workspace_init(ctx) != SVO_OK) return fail(SVO_ERR_HIP);
-    CK(hipMalloc(&ctx->d_results, sizeof(svo_step_result) * (size_t)B));
-    CK(hipMalloc(&ctx->bslots, (size_t)2 * n_img * ctx->geom.slot_bytes));
-    CK(hipMalloc(&ctx->kp_n_snap, sizeof(int) * (size_t)(3 * n_img)));
+    PHASE("plan + kernel attributes (code object load)");
+    DA(ctx->pnp_ws, ctx->pnp_ws_bytes);
+    dev_defer(ctx, [ctx]() { return geom_workspace_init(ctx); });
+    DA(ctx->d_results, sizeof(svo_step_result) * (size_t)B);
+    DA(ctx->bslots, orb ? 256 : (size_t)2 * n_img * ctx->geom.slot_bytes);
+    DA(ctx->kp_n_snap, sizeof(int) * (size_t)(3 * n_img));
+    if (B > 1) {
+        // a batch context is what the runner and the stream create: their frame buffers and record rings come with it
+        const size_t per_cam = (size_t)ctx->stage_pitch * h * (size_t)(B + 1);
+        for (int k = 0; k < 2; k++) {
+            DA(ctx->fb[k], 2 * per_cam);
+            DA(ctx->d_async[k], sizeof(svo_step_result) * (size_t)B);
+        }
+    }
+    if (orb) {
+        int rc = orb_alloc(ctx);
+        if (rc != SVO_OK) { fprintf(stderr, "svo_create: %s\n", ctx->err.c_str()); return fail(rc); }
+    }
+#undef DA
+    if (dev_commit(ctx) != SVO_OK) { fprintf(stderr, "svo_create: device memory (%zu MB): %s\n", ctx->arena.planned >> 20, ctx->err.c_str()); return fail(SVO_ERR_HIP); }
+    PHASE("one device allocation + deferred initialisation");
+    CK(hipHostMalloc(&ctx->h_stage, (size_t)ctx->stage_pitch * h * 2, hipHostMallocDefault));
+    for (int k = 0; k < 2; k++) CK(hipEventCreateWithFlags(&ctx->ev_stage[k], hipEventDisableTiming));
     CK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     CK(hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&ctx->ev_back, hipEventDisableTiming));
+    if (B > 1) {
+        for (int k = 0; k < 2; k++) {
+            CK(hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming));
+            CK(hipEventCreateWithFlags(&ctx->ev_fb_free[k], hipEventDisableTiming));
+            CK(hipEventCreateWithFlags(&ctx->ev_async[k], hipEventDisableTiming));
+        }
+        CK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        CK(hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking));
+        ctx->async_ready = true;
+    }
     ctx->h_pinned_bytes = sizeof(svo_step_result) * (size_t)B + 4096 +
                           (size_t)cap * (sizeof(svo_keypoint) + 32) + sizeof(int) * 64;
     CK(hipHostMalloc(&ctx->h_pinned, ctx->h_pinned_bytes, hipHostMallocDefault));
+    PHASE("events, streams, page-locked scratch");
     CK(hipStreamSynchronize(ctx->stream));
+    PHASE("stream sync");
 #undef CK
-    if (cfg->track_mode == SVO_MODE_ORB) {
-        int rc = orb_alloc(ctx);
-        if (rc != SVO_OK) { fprintf(stderr, "svo_create: %s\n", ctx->err.c_str()); return fail(rc); }
-    } else if (cfg->track_mode != SVO_MODE_LK) {
-        return fail(SVO_ERR_ARG);
-    }
     *out = ctx;
     return SVO_OK;
 }
@@ -671,19 +749,25 @@ extern "C" int svo_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const u
 }
 
 // ---- host-resident frame batches ---------------------------------------------------------------
+// ctx may be NULL (ABI v6): page-locked memory does not belong to a context or a device (hipHostMallocPortable), so a
+// runner can pin its frame buffers on one thread WHILE svo_create builds the context on another -- on a short run
+// page-locking half a gigabyte (0.25 ms per MB) and context creation are each a quarter of the wall time.
 extern "C" int svo_host_alloc(svo_ctx *ctx, size_t bytes, void **out)
 {
-    if (!ctx) return SVO_ERR_ARG;
-    SVO_ARG(out && bytes > 0, "null output / zero size");
-    SVO_HIP(hipSetDevice(ctx->device));
-    SVO_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    if (!out || bytes == 0) { if (ctx) ctx->err = "bad argument: null output / zero size"; return SVO_ERR_ARG; }
+    *out = nullptr;
+    if (ctx && hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return SVO_ERR_HIP; }
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) {
+        if (ctx) ctx->err = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+        return SVO_ERR_HIP;
+    }
     return SVO_OK;
 }
 
 extern "C" int svo_host_free(svo_ctx *ctx, void *p)
 {
-    if (!ctx) return SVO_ERR_ARG;
-    if (p) SVO_HIP(hipHostFree(p));
+    if (p && hipHostFree(p) != hipSuccess) { if (ctx) ctx->err = "hipHostFree failed"; return SVO_ERR_HIP; }
     return SVO_OK;
 }
 
@@ -692,7 +776,7 @@ static int frame_buffers(svo_ctx *ctx)
     if (ctx->copy_stream) return SVO_OK;
     const size_t per_cam = (size_t)ctx->stage_pitch * ctx->cfg.height * (size_t)(ctx->cfg.max_batch + 1);
     for (int k = 0; k < 2; k++) {
-        SVO_HIP(hipMalloc(&ctx->fb[k], 2 * per_cam));
+        if (dev_alloc(ctx, &ctx->fb[k], 2 * per_cam) != SVO_OK) return SVO_ERR_HIP;
         SVO_HIP(hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming));
         SVO_HIP(hipEventCreateWithFlags(&ctx->ev_fb_free[k], hipEventDisableTiming));
     }
@@ -765,23 +849,12 @@ extern "C" int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, con
     SVO_ARG(ctx->async_tail - ctx->async_head < 2, "two batches are already outstanding: collect one first");
     SVO_HIP(hipSetDevice(ctx->device));
     const int r = (int)(ctx->async_tail & 1), n_pairs = n_frames - 1;
-    if (!ctx->async_ready) {
-        // all or nothing: a context whose second allocation (or an event, or the stream) failed must not
-        // look set up to the next call
-        auto release = [&]() {
-            for (int k = 0; k < 2; k++) {
-                if (ctx->d_async[k]) { (void)hipFree(ctx->d_async[k]); ctx->d_async[k] = nullptr; }
-                if (ctx->ev_async[k]) { (void)hipEventDestroy(ctx->ev_async[k]); ctx->ev_async[k] = nullptr; }
-            }
-            if (ctx->fetch_stream) { (void)hipStreamDestroy(ctx->fetch_stream); ctx->fetch_stream = nullptr; }
-        };
-        hipError_t e = hipSuccess;
-        for (int k = 0; k < 2 && e == hipSuccess; k++) {
-            e = hipMalloc(&ctx->d_async[k], sizeof(svo_step_result) * (size_t)ctx->cfg.max_batch);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_async[k], hipEventDisableTiming);
+    if (!ctx->async_ready) {                       // an online-sized context (max_batch 1) sets the ring up on first use
+        for (int k = 0; k < 2; k++) {
+            if (!ctx->d_async[k] && dev_alloc(ctx, &ctx->d_async[k], sizeof(svo_step_result) * (size_t)ctx->cfg.max_batch) != SVO_OK) return SVO_ERR_HIP;
+            if (!ctx->ev_async[k]) SVO_HIP(hipEventCreateWithFlags(&ctx->ev_async[k], hipEventDisableTiming));
         }
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { release(); SVO_HIP(e); }
+        if (!ctx->fetch_stream) SVO_HIP(hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking));
         ctx->async_ready = true;
     }
     if (continue_chain) {

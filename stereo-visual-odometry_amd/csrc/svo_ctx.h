@@ -1,13 +1,30 @@
 // svo_ctx.h -- the context object behind the C-ABI (internal).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <string>
+#include <utility>
 #include <vector>
 #include "../../include/svo_abi.h"
 #include "svo_kernels.h"
 
+// Every device buffer of a context comes out of ONE hipMalloc (svo_create: ~30 separate allocations were a fifth of a
+// short run's start-up): while `planning`, dev_alloc only records (where the pointer goes, size); dev_commit allocates
+// the sum, hands the pointers out and runs the initialisations that were waiting for them (dev_defer).  Allocations made
+// after the commit (lazy paths: ORB buffers of an LK context, frame buffers of an online context) are separate and
+// remembered in `extra`.
+struct DevArena {
+    char *base = nullptr;
+    size_t planned = 0;
+    bool planning = false;
+    std::vector<std::pair<void **, size_t>> plan;
+    std::vector<std::function<int()>> after;
+    std::vector<void *> extra;
+};
+
 struct svo_ctx {
     svo_config cfg;
+    DevArena arena;
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string err;
@@ -107,6 +124,10 @@ struct svo_ctx {
     } while (0)
 
 namespace svo {
+// svo_abi.hip: the context's device memory
+int dev_alloc_raw(svo_ctx *ctx, void **out, size_t bytes);
+template <class T> inline int dev_alloc(svo_ctx *ctx, T **out, size_t bytes) { return dev_alloc_raw(ctx, (void **)out, bytes); }
+int dev_defer(svo_ctx *ctx, std::function<int()> fn);      // runs fn now, or after dev_commit while the arena is being planned
 // geometry.hip
 int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes);
 int geom_workspace_init(svo_ctx *ctx);

@@ -78,6 +78,10 @@ private:
     // another System may have loaded ITS file by the time Run() is called)
     int batch_size_ = 1, decode_threads_ = 0;
     double loop_seconds_ = 0;
+    // RunBatched's page-locked chunk buffers: kept for the next run of this System, released with it (un-pinning half a
+    // gigabyte is a fifth of a short run's wall time, and a process about to exit need not do it)
+    uint8_t *batch_pin_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    size_t batch_pin_bytes_ = 0;
     // pipelined stream (StreamPush / StreamPoll)
     int stream_depth_ = 0;
     struct StreamState {

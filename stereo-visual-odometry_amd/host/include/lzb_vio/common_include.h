@@ -66,6 +66,9 @@ struct Pose4x4 {
 };
 }  // namespace lzb_vio
 
+// LZB_VIO_TIMING=1: seconds since the process started, at the phases of a run (where a short run's wall time goes)
+namespace lzb_vio { double lzb_seconds_since_start(); }
+#define LZB_PHASE(name) do { if (getenv("LZB_VIO_TIMING")) fprintf(stderr, "[TIMING] %8.4f s  %s\n", lzb_vio::lzb_seconds_since_start(), name); } while (0)
 #define LZB_LOG(level, ...) do { fprintf(stderr, "[" level "] " __VA_ARGS__); fprintf(stderr, "\n"); } while (0)
 
 #endif

@@ -12,6 +12,11 @@
 
 namespace lzb_vio {
 
+// seconds since the process started (/proc/self/stat's start time is in clock ticks: the static initialiser below runs
+// when liblzb_vio.so is loaded, a few milliseconds after exec -- close enough for a phase log)
+static const std::chrono::steady_clock::time_point g_process_t0 = std::chrono::steady_clock::now();
+double lzb_seconds_since_start() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - g_process_t0).count(); }
+
 // ---- image readers ---------------------------------------------------------------------------
 static bool read_file(const std::string &path, std::vector<uint8_t> &buf)
 {
@@ -249,6 +254,8 @@ System::System(std::string &config_path) : config_file_path_(config_path)
 System::~System()
 {
     StreamRelease();
+    for (int q = 0; q < 2; q++)
+        for (int cam = 0; cam < 2; cam++) if (batch_pin_[q][cam]) svo_host_free(nullptr, batch_pin_[q][cam]);
     if (pose_file_) fclose(pose_file_);
     if (tracks_file_) fclose(tracks_file_);
 }
@@ -420,17 +427,28 @@ void System::RunBatched(int B, int decode_threads)
     if (!ReadStereo(0, l0, r0)) { LZB_LOG("WARNING", "cannot find images at index %d", 0); return; }
     const int w = l0.cols, h = l0.rows;
     if (r0.cols != w || r0.rows != h) { LZB_LOG("ERROR", "left/right size mismatch at index %d", 0); return; }
-    if (!tracking_->EnsureBatchContext(w, h, B)) return;
-    svo_ctx *ctx = tracking_->Context();
+    LZB_PHASE("first frame read (size known)");
     const int pitch = (w + 255) / 256 * 256;                // the library's staging pitch: one copy per camera
     const size_t fbytes = (size_t)pitch * h;
-    uint8_t *pin[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    for (int k = 0; k < 2; k++)
-        for (int cam = 0; cam < 2; cam++)
-            if (svo_host_alloc(ctx, fbytes * (size_t)(B + 1), (void **)&pin[k][cam]) != SVO_OK) {
-                LZB_LOG("ERROR", "svo_host_alloc: %s", svo_last_error(ctx));
-                return;
+    uint8_t *(&pin)[2][2] = batch_pin_;
+    const size_t pin_bytes = fbytes * (size_t)(B + 1);
+    if (batch_pin_bytes_ < pin_bytes) {                     // (a second run with larger chunks: start over)
+        for (int q = 0; q < 2; q++)
+            for (int cam = 0; cam < 2; cam++) if (pin[q][cam]) { svo_host_free(nullptr, pin[q][cam]); pin[q][cam] = nullptr; }
+        batch_pin_bytes_ = 0;
+    }
+    const bool have_pins = batch_pin_bytes_ >= pin_bytes;
+    // Start-up, overlapped: page-locking the four chunk buffers (0.25 ms per MB) runs on a thread of its own BESIDE the
+    // context creation (HIP runtime start + one device allocation), and chunk 0 is decoded as soon as ITS two buffers
+    // are there -- on a 1000-frame run these three were, one after the other, half of the wall time.
+    std::atomic<int> pinned(0);                             // buffers page-locked so far (2 = chunk 0's pair), -1 = failed
+    std::thread pin_thread([&]() {
+        for (int k = 0; k < 2; k++)
+            for (int cam = 0; cam < 2; cam++) {
+                if (!have_pins && svo_host_alloc(nullptr, pin_bytes, (void **)&pin[k][cam]) != SVO_OK) { pinned.store(-1); return; }
+                pinned.fetch_add(1);
             }
+    });
     // decode_threads < 1: every core this process may use.  A work item is ONE image (left and right of a
     // frame are inflated side by side), handed out through a counter, decoded straight into the page-locked chunk.
     const int T = decode_threads < 1 ? usable_cores() : decode_threads;
@@ -462,14 +480,39 @@ void System::RunBatched(int B, int decode_threads)
         return n;
     };
     auto upload = [&](int k, int n) {
-        int rc = svo_upload_frames(ctx, k, pin[k][0], pin[k][1], pitch, (int64_t)fbytes, n);
-        if (rc != SVO_OK) LZB_LOG("ERROR", "svo_upload_frames: %s", svo_last_error(ctx));
+        svo_ctx *c = tracking_->Context();
+        int rc = svo_upload_frames(c, k, pin[k][0], pin[k][1], pitch, (int64_t)fbytes, n);
+        if (rc != SVO_OK) LZB_LOG("ERROR", "svo_upload_frames: %s", svo_last_error(c));
         return rc == SVO_OK;
     };
 
-    const auto t_loop = std::chrono::steady_clock::now();    // context, buffers and frame 0's size are known: the loop proper
+    int cur_n = 0;
+    double decode0_seconds = 0;
+    std::thread first_decode([&]() {
+        while (pinned.load() >= 0 && pinned.load() < 2) std::this_thread::yield();
+        const auto t0 = std::chrono::steady_clock::now();
+        if (pinned.load() >= 2) cur_n = decode(0, 0, 0, B + 1);
+        decode0_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    });
+    const bool have_ctx = tracking_->EnsureBatchContext(w, h, B);
+    LZB_PHASE("svo_create done");
+    first_decode.join();
+    LZB_PHASE("chunk 0 decoded");
+    pin_thread.join();
+    LZB_PHASE("page-locked buffers allocated");
+    svo_ctx *ctx = have_ctx ? tracking_->Context() : nullptr;
+    if (!ctx || pinned.load() < 0) {
+        if (pinned.load() < 0) LZB_LOG("ERROR", "svo_host_alloc failed (page-locked frame buffers)");
+        for (int q = 0; q < 2; q++)
+            for (int cam = 0; cam < 2; cam++) if (pin[q][cam]) { svo_host_free(nullptr, pin[q][cam]); pin[q][cam] = nullptr; }
+        batch_pin_bytes_ = 0;
+        return;
+    }
+    batch_pin_bytes_ = pin_bytes;
+    // the loop's own clock: chunk 0's decode (it ran beside the context creation: its own duration is added at the
+    // end) + everything from here to the last pose row
+    const auto t_loop = std::chrono::steady_clock::now();
     int k = 0, next = 0;
-    int cur_n = decode(0, 0, 0, B + 1);
     next = cur_n;
     current_image_index_ = cur_n > 0 ? 1 : 0;
     if (cur_n > 0) WritePose();                             // frame 0: StereoInit_f2f, pose = identity
@@ -517,9 +560,8 @@ void System::RunBatched(int B, int decode_threads)
     }
     while (ok && outstanding > 0) { ok = flush(0.0, 0); outstanding--; }
     svo_sync(ctx);
-    loop_seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
-    for (int q = 0; q < 2; q++)
-        for (int cam = 0; cam < 2; cam++) svo_host_free(ctx, pin[q][cam]);
+    loop_seconds_ = decode0_seconds + std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
+    LZB_PHASE("loop done (last pose row written)");
 }
 
 // ---- pipelined stream ----------------------------------------------------------------------------
@@ -643,11 +685,14 @@ int RunSequences(const std::vector<std::string> &yamls, const std::vector<std::s
     // the other on this thread -- each reads its own YAML completely in its constructor -- and only then run
     std::vector<std::unique_ptr<System>> sys((size_t)n_seq);
     std::vector<int> frames((size_t)n_seq, 0);
+    std::vector<char> no_output((size_t)n_seq, 0);        // the sequence's pose file could not be opened: it is NOT run
     for (int i = 0; i < n_seq; i++) {
         std::string path = yamls[(size_t)i];
         sys[(size_t)i].reset(new System(path));
-        if (i < (int)pose_files.size() && !pose_files[(size_t)i].empty() && !sys[(size_t)i]->SetPoseFile(pose_files[(size_t)i]))
-            LZB_LOG("ERROR", "cannot open %s for writing", pose_files[(size_t)i].c_str());
+        if (i < (int)pose_files.size() && !pose_files[(size_t)i].empty() && !sys[(size_t)i]->SetPoseFile(pose_files[(size_t)i])) {
+            LZB_LOG("ERROR", "cannot open %s for writing: sequence %d is not run", pose_files[(size_t)i].c_str(), i);
+            no_output[(size_t)i] = 1;
+        }
         frames[(size_t)i] = sys[(size_t)i]->CountFrames();
     }
     // one worker per device; a lone device gets two (one sequence decodes while the other's kernels run)
@@ -673,6 +718,7 @@ int RunSequences(const std::vector<std::string> &yamls, const std::vector<std::s
             for (int s : mine[(size_t)wk]) {
                 SequenceReport &r = rep[(size_t)s];
                 r.yaml = yamls[(size_t)s]; r.device = dev; r.worker = wk;
+                if (no_output[(size_t)s]) { sys[(size_t)s].reset(); continue; }      // r.ok stays false: counted as failed
                 const auto t0 = std::chrono::steady_clock::now();
                 sys[(size_t)s]->SetDevice(dev);
                 sys[(size_t)s]->Run();

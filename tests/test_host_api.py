@@ -418,3 +418,6 @@ def test_run_kitti_stereo_multi_sequence(host_built, synth, tmp_path):
     r = subprocess.run([exe, yamls[0], str(bad), "--poses-dir", str(tmp_path / "out")], capture_output=True, timeout=300)
     assert r.returncode == 1 and "[FAILED]" in r.stderr.decode()
     assert open(tmp_path / "out" / "s0.yaml.poses.txt", "rb").read() == single[0]
+    # a pose file that cannot be opened: that sequence is not run and counts as failed (exit code 1), not silently dropped
+    r = subprocess.run([exe, yamls[0], yamls[1], "--poses-dir", str(tmp_path / "no_such_dir")], capture_output=True, timeout=300)
+    assert r.returncode == 1 and r.stderr.decode().count("[FAILED]") == 2 and "is not run" in r.stderr.decode()
