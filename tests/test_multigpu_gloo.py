@@ -101,6 +101,51 @@ def test_pose_gather_and_sharding_world2(tmp_path):
     assert r0[2] == "0,2,4,6" and r1[2] == "1,3,5,7"             # KITTI 00-07 dealt round-robin
 
 
+def _worker_world8(rank, world, port, out_dir):
+    """BASELINE config #5 at its REAL world size: one KITTI sequence per rank, every rank's full pose list (270 ... 4660
+    rows of 16 doubles) to rank 0 in one ragged gather, the slowest rank's time by all-reduce."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    conftest.entry.load_package()
+    import importlib
+    mg = importlib.import_module(conftest.entry.PKG_NAME + ".multigpu")
+    deal = mg.deal_sequences(mg.KITTI_LENGTHS, world)
+    (s_,) = deal[rank]                                            # exactly one sequence per rank
+    n = mg.KITTI_LENGTHS[s_] - 1
+    mine = (torch.arange(n * 16, dtype=torch.float64).view(n, 16) + 1e7 * s_)     # row p of sequence s_: 1e7 s_ + 16 p + column
+    got = mg.gather_ragged(mine, rank, world, dst=0)
+    tmax = mg.max_over_ranks(0.001 * n, torch.device("cpu"), world)               # "busy time" ~ sequence length
+    ok = abs(tmax - 4.660) < 1e-12                                                # sequence 02 sets the wall time
+    ok = ok and mg.steps_for(mg.KITTI_LENGTHS, deal[rank], 256) == (n + 255) // 256
+    if rank == 0:
+        ok = ok and [g.shape[0] for g in got] == [mg.KITTI_LENGTHS[d[0]] - 1 for d in deal]
+        ok = ok and sorted(g.shape[0] for g in got) == [270, 800, 1100, 1100, 1100, 2760, 4540, 4660]
+        for r, g in enumerate(got):
+            sq = deal[r][0]
+            ok = ok and float(g[0, 0]) == 1e7 * sq and float(g[-1, -1]) == 1e7 * sq + g.shape[0] * 16 - 1
+    else:
+        ok = ok and got is None
+    rig = mg.KITTI_RIGS[s_]
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(f"{int(ok)} {s_} {rig['width']}x{rig['height']}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config5_control_flow_at_world_size_8(tmp_path):
+    """The 8-rank control flow has run once before a node shows up (CPU, gloo): the deal is one sequence per rank,
+    longest first (rank 0 = sequence 02), eight DIFFERENT message lengths through the ragged gather, the max
+    all-reduce; every rank knows its sequence's frame size.  (Eight ranks SHARING the one GPU of a test box are
+    not possible: the box allows six processes on the card.)"""
+    world = 8
+    mp.spawn(_worker_world8, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rows = [open(tmp_path / f"rank{r}.txt").read().split() for r in range(world)]
+    assert all(r[0] == "1" for r in rows)
+    assert [int(r[1]) for r in rows] == [2, 0, 5, 1, 6, 7, 3, 4]                   # longest first, ties by index
+    assert [r[2] for r in rows] == ["1241x376", "1241x376", "1226x370", "1241x376", "1226x370", "1226x370", "1242x375", "1226x370"]
+
+
 def test_deal_sequences_balances_kitti_lengths(pkg):
     """Longest-first greedy deal of the KITTI 00-07 lengths: every sequence exactly once; with 8 ranks it
     is one sequence per rank (the imbalance BASELINE config #5 has by construction: the wall time is
