@@ -102,17 +102,19 @@ def launch_ranks(args):
     the GPU (no torch import, no HIP call) and never execs: it waits, stops the other ranks as soon as
     one of them fails (by exact PID) and returns the first non-zero exit code.  Rank 0's one JSON line
     goes straight to the inherited stdout."""
-    import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    import tempfile
+    # rendezvous through a FILE, not a TCP port picked here: a port found free now can be taken by another process before
+    # rank 0's store binds it (the ranks would then hang in init_process_group until the timeout)
+    rdv = tempfile.NamedTemporaryFile(prefix="svo_bench_rdv_", delete=False)
+    rdv.close()
+    os.unlink(rdv.name)                             # torch creates it; a stale file from another run must not exist
     n = args.gpus
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SVO_BENCH_SELF_LAUNCHED="1")
+                   SVO_BENCH_RDV_FILE=rdv.name, SVO_BENCH_SELF_LAUNCHED="1")
+        env.pop("MASTER_PORT", None)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc, live, t_fail = 0, set(range(n)), None
@@ -132,6 +134,10 @@ def launch_ranks(args):
             if t_fail is not None and time.monotonic() - t_fail > 20:      # a rank that ignored SIGTERM
                 for q in live:
                     procs[q].kill()
+    try:
+        os.unlink(rdv.name)
+    except OSError:
+        pass
     return rc
 
 
@@ -481,17 +487,24 @@ def main():
     torch.cuda.set_device(local_rank)
     dist_on = world > 1 or args.dist_single
     if dist_on:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if "MASTER_PORT" not in os.environ:            # only a --dist-single run gets here without one
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        # under torch.distributed.run the launcher's MASTER_ADDR / MASTER_PORT store is used; the ranks bench.py starts
+        # itself (and a --dist-single run) meet through a file: no port to lose a race for
+        init_kw = {}
+        rdv_file = os.environ.get("SVO_BENCH_RDV_FILE")
+        if rdv_file is None and "MASTER_PORT" not in os.environ:
+            import tempfile
+            fd, rdv_file = tempfile.mkstemp(prefix="svo_bench_rdv_")
+            os.close(fd)
+            os.unlink(rdv_file)
+        if rdv_file is not None:
+            init_kw["init_method"] = "file://" + rdv_file
+        else:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if gloo:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, **init_kw)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+                                    device_id=torch.device("cuda", local_rank), **init_kw)
 
     pkg = entry.load_package()
     import importlib

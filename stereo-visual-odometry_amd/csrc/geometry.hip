@@ -944,8 +944,11 @@ int stage_chain_relative(svo_ctx *ctx, const double *T, const int32_t *ok, int n
 
 // ------------------------------------------------------------------------------------------
 // workspace layout inside ctx->pnp_ws (n = max_batch items):
-//   [PnpRecord x n][mask bytes x n*cap][PnpState x n][PnpHyp x n*448][counts x n*448][subsets x n*2*448*5]
-//   [EPnP hand-over records x n*7*105*64 doubles][cv::RNG(-1) states x kRngStream]
+//   [PnpRecord x n][mask bytes x n*cap][PnpState x n][PnpHyp x n*512][counts x n*512][subsets x n*2*512*5]
+//   [EPnP hand-over records x n * 8 blocks * 105 * 64 doubles][cv::RNG(-1) states x kRngStream]
+// (kPhaseHyps = 512 hypotheses per phase in kPhaseBlocks = 8 blocks of 64.)  The hand-over records are the large part:
+// 430 KB per item, 110 MB for a 256-pair context, in BOTH modes -- a later phase of an LK-mode solve launches all eight
+// blocks too.  INTEGRATION.md lists a context's device memory.
 static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 static size_t ws_off_mask(int n_items) { return al256(sizeof(PnpRecord) * (size_t)n_items); }
 static size_t ws_off_state(const svo_config &cfg, int n_items) { return al256(ws_off_mask(n_items) + (size_t)n_items * cfg.max_keypoints); }

@@ -2079,6 +2079,15 @@ int orb_alloc(svo_ctx *ctx)
     OrbGeom &g = ctx->orb_geom;
     int rc = orb_make_geom(ctx->cfg, &g);
     if (rc) { ctx->err = "ORB geometry: unsupported image size / level count"; return rc; }
+    // DistributeOctTree starts from nIni = round(width / height) root strips of the level's keypoint area; both quadtree
+    // kernels hold at most 64 of them.  A panorama beyond 64 : 1 is refused here instead of losing the strips silently.
+    for (int l = 0; l < g.nlevels; l++) {
+        const int aw = g.w[l] - 32, ah = g.h[l] - 32;
+        if (aw > 0 && ah > 0 && (int)roundf((float)aw / (float)ah) > 64) {
+            ctx->err = "ORB mode: a pyramid level is wider than 64 : 1 (more than 64 quadtree root strips): unsupported";
+            return SVO_ERR_ARG;
+        }
+    }
     const int n_img = 2 * ctx->n_img;                  // left + right of every frame slot
     const int L = g.nlevels;
     {

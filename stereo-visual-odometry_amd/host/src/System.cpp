@@ -198,6 +198,22 @@ static bool png_decode(const std::vector<uint8_t> &b, GetDst dst_for)
             }
         }
     }
+    // The rows are complete, the STREAM must be too: one more inflate with a one-byte output buffer has to reach
+    // Z_STREAM_END without producing anything -- that is where zlib compares the Adler-32 trailer (a damaged literal
+    // inside valid deflate syntax yields Z_DATA_ERROR here) and where extra rows or trailing bytes show.
+    for (bool ended = false; ok && !ended;) {
+        uint8_t extra = 0;
+        zs.next_out = &extra; zs.avail_out = 1;
+        if (zs.avail_in == 0 && chunk + 1 < idat.size()) {
+            chunk++;
+            zs.next_in = const_cast<Bytef *>(&b[idat[chunk].first]); zs.avail_in = (uInt)idat[chunk].second;
+        }
+        const int rc = inflate(&zs, Z_FINISH);
+        if (zs.avail_out == 0) ok = false;                  // more pixels than the header announced
+        else if (rc == Z_STREAM_END) ended = true;
+        else if (rc == Z_BUF_ERROR || rc == Z_OK) ok = zs.avail_in == 0 && chunk + 1 < idat.size();   // needs the next IDAT chunk
+        else ok = false;                                    // Z_DATA_ERROR: checksum mismatch / corrupt stream
+    }
     inflateEnd(&zs);
     return ok;
 }

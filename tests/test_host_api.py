@@ -150,6 +150,44 @@ def test_png_reader_stream_shapes(host_built, tmp_path):
         assert f"image{i + 1} ok=1 rows={im.shape[0]} cols={im.shape[1]} hash={_hash(im)}" in out, files[i]
 
 
+def _png_bytes(img, payload_edit=None, rows_in_stream=None):
+    """A gray 8-bit PNG built by hand (filter 0, stored deflate blocks so that image bytes sit in the stream as they are),
+    every chunk CRC correct; payload_edit(bytearray of the zlib stream) may damage it, rows_in_stream lies about the height."""
+    import struct
+    import zlib
+    h, w = img.shape
+    rows = img if rows_in_stream is None else np.vstack([img] * 2)[:rows_in_stream]
+    raw = b"".join(b"\x00" + rows[y].tobytes() for y in range(rows.shape[0]))
+    z = bytearray(zlib.compress(raw, 0))
+    if payload_edit:
+        payload_edit(z)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) + chunk(b"IDAT", bytes(z)) + chunk(b"IEND", b"")
+
+
+def test_png_reader_checks_the_stream_end(host_built, tmp_path):
+    """A PNG whose deflate syntax is intact but whose bytes are not what was compressed (Adler-32 mismatch), one that
+    carries more rows than its header says, and one cut short: all refused; the untouched file decodes."""
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (40, 57), dtype=np.uint8)
+
+    def flip(z):
+        z[len(z) // 2] ^= 0x10               # a literal byte inside a stored block: still valid deflate, wrong checksum
+
+    (tmp_path / "good.png").write_bytes(_png_bytes(img))
+    (tmp_path / "flipped.png").write_bytes(_png_bytes(img, payload_edit=flip))
+    (tmp_path / "extra_rows.png").write_bytes(_png_bytes(img, rows_in_stream=43))
+    (tmp_path / "short.png").write_bytes(_png_bytes(img, rows_in_stream=31))
+    _write_yaml(tmp_path / "cfg.yaml", "/data/kitti/00")
+    out = subprocess.check_output([os.path.join(host_built, "host_selftest"), str(tmp_path / "cfg.yaml")] +
+                                  [str(tmp_path / f) for f in ("good.png", "flipped.png", "extra_rows.png", "short.png")],
+                                  stderr=subprocess.DEVNULL).decode()
+    assert f"image1 ok=1 rows=40 cols=57 hash={_hash(img)}" in out
+    assert "image2 ok=0" in out and "image3 ok=0" in out and "image4 ok=0" in out
+
+
 def test_usage_error_returns_nonzero(host_built):
     r = subprocess.run([os.path.join(host_built, "run_kitti_stereo")], stderr=subprocess.DEVNULL)
     assert r.returncode == 2
