@@ -803,6 +803,33 @@ __device__ inline void epnp5_L_rows_d(const double *big, int bs, double *Lm, int
         row[9 * ls] = dot3_d(dv[3], dv[3]);
     }
 }
+// the same rows from the HAND-OVER record (v = ut rows 11, 10, 9, 8 at kEpnpHandV): the back kernel of the split
+// hypothesis launch has no image in LDS
+template <int ROW0, int NROWS>
+__device__ inline void epnp5_L_rows_hand_d(const double *hand, int hs, double *Lm, int ls)
+{
+#pragma unroll
+    for (int i = ROW0; i < ROW0 + NROWS; i++) {
+        const int a = i < 3 ? 0 : i < 5 ? 1 : 2, b = i < 3 ? i + 1 : i < 5 ? i - 1 : 3;
+        double dv[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                dv[q][c] = hand[(kEpnpHandV + q * 12 + 3 * a + c) * hs] - hand[(kEpnpHandV + q * 12 + 3 * b + c) * hs];
+        double *row = Lm + 10 * i * ls;
+        row[0 * ls] = dot3_d(dv[0], dv[0]);
+        row[1 * ls] = 2.0 * dot3_d(dv[0], dv[1]);
+        row[2 * ls] = dot3_d(dv[1], dv[1]);
+        row[3 * ls] = 2.0 * dot3_d(dv[0], dv[2]);
+        row[4 * ls] = 2.0 * dot3_d(dv[1], dv[2]);
+        row[5 * ls] = dot3_d(dv[2], dv[2]);
+        row[6 * ls] = 2.0 * dot3_d(dv[0], dv[3]);
+        row[7 * ls] = 2.0 * dot3_d(dv[1], dv[3]);
+        row[8 * ls] = 2.0 * dot3_d(dv[2], dv[3]);
+        row[9 * ls] = dot3_d(dv[3], dv[3]);
+    }
+}
 // compute_rho from the control points of the hand-over record into rho_m[0..5]
 __device__ inline void epnp5_rho_d(const double *hand, int hs, double *rho_m, int rs)
 {

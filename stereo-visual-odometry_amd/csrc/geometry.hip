@@ -350,7 +350,17 @@ __global__ __launch_bounds__(64) void pnp_begin_kernel(PnpArgs a)
 constexpr int kPnpLdsDoubles = 66 + 40 + 27 + 55;          // per lane: L + rho + the three solve workspaces (> the 144 + 12 of the SVD)
 constexpr size_t kPnpLdsBytes = (size_t)(kPnpLdsDoubles * 64) * sizeof(double);   // 94 KB: ONE workgroup per CU
 constexpr int kPhaseBlocks = kPhaseHyps / kHypBlock;       // hand-over records: one per block of a phase
-__device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem_w)
+// The hypothesis launch is TWO kernels:
+//   pnp_hyp_front_kernel: the lane-private front (wave 0), the 12x12 eigenproblem by staged Jacobi (four waves), the
+//       sort, the four null-space vectors into the hand-over record.  LDS: the lane-interleaved image + singular
+//       values = 78 KB, at most 256 registers: TWO blocks share a CU, i.e. two waves per SIMD -- the sweeps are one
+//       dependent f64 chain per stage, which a lone wave issues at 8 cycles per instruction and two waves at 4 each
+//       (profiles/r02_valu_roof.txt).  The sweeps are 62 % of a hypothesis' cycles.
+//   pnp_hyp_back_kernel: L and rho (shared by the three approximations), the three beta approximations side by side
+//       on three waves, compute_pose's rule.  94 KB of LDS, 300+ registers: one block per CU, as the single kernel was.
+// Everything a hypothesis carries from one to the other is in its hand-over record (global memory, L2-resident).
+constexpr size_t kPnpFrontLdsBytes = (size_t)((144 + 12) * 64) * sizeof(double);          // 78 KB
+__device__ __forceinline__ void pnp_hyp_front_body(const PnpArgs &a, double *pnp_smem_w)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
     PnpState *st = a.state + b;
@@ -372,12 +382,6 @@ __device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem_
     const bool active = h < st->phase_hyps;                  // idle lanes solve points 0..4 (they take part in the barriers)
     double *big = pnp_smem_w + lane, *W = pnp_smem_w + 144 * 64 + lane;
     double *hand = a.hand + ((int64_t)b * kPhaseBlocks + blockIdx.x) * (kEpnpHandDoubles * 64) + lane;   // element e at hand[e * 64]
-#ifdef SVO_PNP_DIAG
-    long long tq[6]; tq[0] = clock64();
-#define PNP_STAMP(i) tq[i] = clock64()
-#else
-#define PNP_STAMP(i)
-#endif
     if (wave == 0) {
         Epnp5 e;
         const float *X3 = a.X3 + (int64_t)b * a.stride * 3;
@@ -402,25 +406,37 @@ __device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem_
         jacobi_init_d<12, 12>(big, 64, W, 64, nullptr, 0);
     }
     __syncthreads();
-    PNP_STAMP(1);
     jacobi_sweeps_coop<12, 12, 4>(big, 64, W, 64, nullptr, 0, wave);
-    PNP_STAMP(2);
     if (wave == 0) {
         double d12[12];
         jacobi_finish_d<12, 12>(big, 64, d12, nullptr, 0, true);
         for (int i = 0; i < 4; i++)                          // ut rows 11, 10, 9, 8
             for (int k = 0; k < 12; k++) hand[(kEpnpHandV + i * 12 + k) * 64] = big[((11 - i) * 12 + k) * 64];
     }
-    __syncthreads();                                         // sorted image + hand-over record complete
-    // L (6 x 10) and rho are the same for the three approximations: computed once, two rows per wave and rho by
-    // the fourth, into the dead rows 0..5 of the image (the null-space vectors they are read from are rows 8..11)
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pnp_hyp_front_kernel(PnpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double pnp_smem[];
+    pnp_hyp_front_body(a, pnp_smem);
+}
+
+__device__ __forceinline__ void pnp_hyp_back_body(const PnpArgs &a, double *pnp_smem_w)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    const PnpState *st = a.state + b;
+    const int h = blockIdx.x * kHypBlock + lane;
+    if (st->next_base != a.phase_base) return;               // phase not needed
+    if (blockIdx.x * kHypBlock >= st->phase_hyps) return;    // block beyond the phase
+    const bool active = h < st->phase_hyps;
+    double *big = pnp_smem_w + lane;
+    const double *hand = a.hand + ((int64_t)b * kPhaseBlocks + blockIdx.x) * (kEpnpHandDoubles * 64) + lane;
+    // L (6 x 10) and rho are the same for the three approximations: computed once, two rows per wave and rho by the fourth
     double *Lm = big, *rho_m = big + 60 * 64;
-    if (wave == 0) epnp5_L_rows_d<0, 2>(big, 64, Lm, 64);
-    else if (wave == 1) epnp5_L_rows_d<2, 2>(big, 64, Lm, 64);
-    else if (wave == 2) epnp5_L_rows_d<4, 2>(big, 64, Lm, 64);
+    if (wave == 0) epnp5_L_rows_hand_d<0, 2>(hand, 64, Lm, 64);
+    else if (wave == 1) epnp5_L_rows_hand_d<2, 2>(hand, 64, Lm, 64);
+    else if (wave == 2) epnp5_L_rows_hand_d<4, 2>(hand, 64, Lm, 64);
     else epnp5_rho_d(hand, 64, rho_m, 64);
-    __syncthreads();                                         // everything behind L and rho is free now
-    PNP_STAMP(3);
+    __syncthreads();
     PnpHyp out;
     double rep = 0;
     // workspaces behind L and rho: svd_solve of 6 x 4 / 6 x 3 / 6 x 5 (M*N + N*N doubles: 40, 27, 55); a wave's
@@ -429,12 +445,6 @@ __device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem_
     if (wave == 0) rep = epnp5_betas_pose_d<1>(Lm, rho_m, 64, hand, 64, a.fx, a.fy, a.cx, a.cy, ws, 64, out.R, out.t);
     else if (wave == 1) rep = epnp5_betas_pose_d<2>(Lm, rho_m, 64, hand, 64, a.fx, a.fy, a.cx, a.cy, ws, 64, out.R, out.t);
     else if (wave == 2) rep = epnp5_betas_pose_d<3>(Lm, rho_m, 64, hand, 64, a.fx, a.fy, a.cx, a.cy, ws, 64, out.R, out.t);
-    PNP_STAMP(4);
-#ifdef SVO_PNP_DIAG
-    if (blockIdx.x == 0 && b == 0 && lane == 0)
-        printf("pnp_hyp diag: phase_base %d wave %d  front %lld  sweeps %lld  finish+L %lld  back %lld cycles\n", a.phase_base, wave,
-               tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3]);
-#endif
     if (wave == 1 || wave == 2) {
         double *dst = ws;
         for (int i = 0; i < 9; i++) dst[i * 64] = out.R[i];
@@ -456,10 +466,10 @@ __device__ __forceinline__ void pnp_hyp_body(const PnpArgs &a, double *pnp_smem_
         if (active) a.hyp[(int64_t)b * kPhaseHyps + h] = out;
     }
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void pnp_hyp_kernel(PnpArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void pnp_hyp_back_kernel(PnpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double pnp_smem[];
-    pnp_hyp_body(a, pnp_smem);
+    pnp_hyp_back_body(a, pnp_smem);
 }
 
 // findInliers for the hypotheses of the phase: grid (blocks of 64 hypotheses, items, point chunks),
@@ -965,7 +975,10 @@ const uint8_t *pnp_inlier_mask(const svo_ctx *ctx) { return (const uint8_t *)ctx
 int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
 {
     // called once per context at creation: the EPnP and refit kernels need more dynamic LDS than the default limit
-    if (hipFuncSetAttribute((const void *)pnp_hyp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void *)pnp_hyp_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kPnpFrontLdsBytes) != hipSuccess)
+        return SVO_ERR_HIP;
+    if (hipFuncSetAttribute((const void *)pnp_hyp_back_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPnpLdsBytes) != hipSuccess)
         return SVO_ERR_HIP;
     if (hipFuncSetAttribute((const void *)pnp_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1015,7 +1028,8 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
         a.phase_base = base; a.phase_cap = cap; a.phase_index = phase;
         // one block per CU (94 KB of LDS, one wave per SIMD); beside the next batch's front end that leaves the
         // LDS-staged front-end kernels room on the CU (two 78 KB blocks locked them out: ORB mode, 1.7 ms per step)
-        hipLaunchKernelGGL(pnp_hyp_kernel, dim3(blocks + 1, n_items), dim3(256), kPnpLdsBytes, st, a);   // + the drawer
+        hipLaunchKernelGGL(pnp_hyp_front_kernel, dim3(blocks + 1, n_items), dim3(256), kPnpFrontLdsBytes, st, a);   // + the drawer
+        hipLaunchKernelGGL(pnp_hyp_back_kernel, dim3(blocks, n_items), dim3(256), kPnpLdsBytes, st, a);
         hipLaunchKernelGGL(pnp_score_kernel, dim3(blocks, n_items, zchunks), dim3(256), 0, st, a);
         hipLaunchKernelGGL(pnp_select_kernel, dim3(n_items), dim3(64), 0, st, a);
         base += cap;

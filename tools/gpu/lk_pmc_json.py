@@ -11,9 +11,10 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "lk_kernel"          # or lk_sse2_kernel (bench.py --lk-accum sse2)
 vals = {}
 for line in open(sys.argv[1]):
-    if "lk_kernel" not in line:
+    if KERNEL not in line:
         continue
     parts = line.split()
     name = [p for p in parts if p.isupper() or p.endswith("_sum")][0]
@@ -24,14 +25,14 @@ avg_ns = None
 if len(sys.argv) > 2 and os.path.exists(sys.argv[2]):
     import csv
     for row in csv.DictReader(open(sys.argv[2])):
-        if "lk_kernel" in row["Name"]:
+        if KERNEL in row["Name"]:
             avg_ns = float(row["AverageNs"])
 h = hashlib.sha256()
-for f in ("lk.hip", "svo_device.h", "svo_kernels.h"):
+for f in ("lk.hip", "lk_common.h", "svo_device.h", "svo_kernels.h") + (("lk_sse2.hip",) if KERNEL != "lk_kernel" else ()):
     h.update(open(os.path.join(ROOT, "stereo-visual-odometry_amd", "csrc", f), "rb").read())
 fetch_kb, write_kb = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
 out = {
-    "kernel": "svo::lk_kernel",
+    "kernel": "svo::" + KERNEL,
     "command": "tools/gpu/prof.sh: rocprofv3 --pmc <one group per run> --kernel-include-regex svo:: -- python3 bench.py --steps 2 "
                "--warmup 1 --cpu-pairs 0 --no-secondary --no-timing-marks --no-overlap (256 S0 pairs per launch)",
     "source_sha256_16": h.hexdigest()[:16],
