@@ -141,10 +141,10 @@ def launch_ranks(args):
     return rc
 
 
-def kernel_source_hash():
-    """sha256 over the sources lk_kernel is built from: profile-derived numbers are only valid for them."""
+def kernel_source_hash(sse2=False):
+    """sha256 over the sources lk_kernel (sse2: lk_sse2_kernel) is built from: profile-derived numbers are only valid for them."""
     h = hashlib.sha256()
-    for f in ("lk.hip", "lk_common.h", "svo_device.h", "svo_kernels.h"):
+    for f in ("lk.hip", "lk_common.h", "svo_device.h", "svo_kernels.h") + (("lk_sse2.hip",) if sse2 else ()):
         with open(os.path.join(entry.PKG_DIR, "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -161,16 +161,16 @@ def newest_profile(name, src_hash=None):
     return None
 
 
-def roofline_lk(stage_ms, pts_total, B):
+def roofline_lk(stage_ms, pts_total, B, sse2=False):
     """The LK launch of a mean step against the HBM roof (4257 algorithmic bytes per point per call,
     4 fused calls per launch) and against the VALU issue roof it actually sits under; the profile-derived fields
     (PMC traffic, instruction count) are valid only for the kernel source they were measured on."""
     lk_ms = stage_ms["lk"]
-    src_hash = kernel_source_hash()
+    src_hash = kernel_source_hash(sse2)
     alg_bytes = pts_total * 4 * LK_BYTES_PER_POINT_CALL
     achieved = alg_bytes / (lk_ms * 1e-3) / 1e9
     traffic, valu = None, None
-    prof = newest_profile("lk", src_hash) if B == 256 else None
+    prof = newest_profile("lk_sse2" if sse2 else "lk", src_hash) if B == 256 else None
     if prof:
         traffic = prof.get("traffic_bytes")
         n_valu = prof.get("valu_wave_instructions")
@@ -186,7 +186,8 @@ def roofline_lk(stage_ms, pts_total, B):
                     "profile": prof["_file"],
                     "note": "peak = measured issue rate of v_dot2 / v_perm / v_pk_* / DPP / v_cndmask (4 cycles per "
                             "wave-instruction); profiles/r02_valu_roof.txt"}
-    return {"bound": "hbm", "kernel": "lk_kernel (4-call circular chain, one launch per step)",
+    return {"bound": "hbm", "kernel": ("lk_sse2_kernel (lk_accum = sse2: float sums in an x86 OpenCV's lane order; " if sse2 else "lk_kernel (") +
+                                      "4-call circular chain, one launch per step)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             "frac_measured_traffic": (round(traffic / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
@@ -736,10 +737,8 @@ def main():
                                                 "(00-02 1241x376, 03 1242x375, 04-07 1226x370: a context per size), on the rank's rendered chunks "
                                                 "of that size, cycled (sequence LENGTHS and SIZES are modelled, not their content)",
                                         "frame_sizes": [f"{r['width']}x{r['height']}" for r in mg.KITTI_RIGS]}
-        out["roofline"] = (roofline_lk(stage_ms, pts_total, B) if stage_ms.get("lk") else
+        out["roofline"] = (roofline_lk(stage_ms, pts_total, B, sse2=args.lk_accum == "sse2") if stage_ms.get("lk") else
                            roofline_orb(stage_ms, B, W, H) if stage_ms.get("orb_cellfast") else None)
-        if out["roofline"] and args.lk_accum == "sse2":
-            out["roofline"]["kernel"] = "lk_sse2_kernel (lk_accum = sse2: float sums in an x86 OpenCV's lane order)"
         if world == 1 and not args.config5 and not args.no_self_check and steps > 0:
             O = entry.load_oracle()
             O.build()
@@ -834,6 +833,7 @@ def main():
                 finish("lk_accum_sse2", lctx, el, st_ms, recs, f0, leg_steps, B,
                        {"definition": "the main workload with svo_config.lk_accum = SVO_LK_ACCUM_SSE2 (lk_sse2_kernel: float sums in the "
                                       "lane order of upstream's CV_SSE2 block, bit-identical to oracle/lk.c mode 2)",
+                        "roofline": roofline_lk(st_ms, int(round(float(recs["n_prev_kps"].mean()) * B)), B, sse2=True) if st_ms.get("lk") else None,
                         "lk_ms_per_step": round(st_ms.get("lk", 0.0), 4),
                         "lk_ms_per_step_exact": round(stage_ms.get("lk", 0.0), 4) if stage_ms.get("lk") else None},
                        dict(mode="lk", sse2=True))

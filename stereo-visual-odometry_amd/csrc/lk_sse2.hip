@@ -57,8 +57,9 @@ struct Sse2Lane {
     uint32_t wb[10];        // b term j of slot 0 goes to LDS byte address wb[j]
     uint32_t wa_lo, wa_hi[4];   // patch word i < 4 goes to wa_lo + (i * kAqStride) * 4, word 4 + i to wa_hi[i]
     uint32_t cb, ca;        // chain read addresses (b, A) of this lane's chain, the lane's slot included
+    uint32_t cb2, ca2;      // ... past the part every chain has (b: term 44, A: word 24): own chain or the idle lanes' common address
     uint32_t selA;          // v_perm selector that puts the two factors of this lane's A sum side by side
-    bool b_tail, a_tail;
+    bool b_tail, a_tail, b_chain, a_chain;      // chain roles of lane c: b: c < 10 (8, 9 = tails), A: c < 15 (12..14 = tails)
 };
 
 __device__ __forceinline__ void lds_store(uint32_t byte_addr, uint32_t v) { *(lds_u32 *)(size_t)byte_addr = v; }
@@ -92,13 +93,32 @@ __device__ __forceinline__ Sse2Lane make_lane(int lane, uint32_t lds_base)
     }
     const int c = lane & 15;
     const uint32_t stage_s = stage0 + (uint32_t)((lane >> 4) * kStageDw) * 4;
-    L.b_tail = c == 8 || c == 9;
-    L.cb = stage_s + (uint32_t)(c < 8 ? c * kSStride : (L.b_tail ? kTBase + (c - 8) * kTStride : 0)) * 4;
+    L.b_tail = c == 8 || c == 9; L.b_chain = c < 10; L.a_chain = c < 15;
+    L.cb = c < 8 ? stage_s + (uint32_t)(c * kSStride) * 4 : (L.b_tail ? stage_s + (uint32_t)(kTBase + (c - 8) * kTStride) * 4 : stage0);
+    L.cb2 = L.b_tail ? L.cb : stage0;
     L.a_tail = c >= 12;
-    L.ca = stage_s + (uint32_t)(c < 12 ? (c & 3) * kAqStride : kAtBase) * 4;
+    L.ca = c < 12 ? stage_s + (uint32_t)((c & 3) * kAqStride) * 4 : (c < 15 ? stage_s + (uint32_t)kAtBase * 4 : stage0);
+    L.ca2 = c < 12 ? L.ca : stage0;
     const int type = c < 12 ? c >> 2 : (c - 12) % 3;          // 0: Ix Ix, 1: Ix Iy, 2: Iy Iy
     L.selA = type == 0 ? 0x01000100u : (type == 1 ? 0x03020100u : 0x03020302u);
     return L;
+}
+
+// DPP inside a row of 16: the value of the lane N above (row_shl) ...
+template <int N>
+__device__ __forceinline__ float row_shl(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xF, 0xF, true));
+}
+// ... and lane Q (0..3) of the row's first quad in every lane of the row: two masked row shifts carry quad 0 to the
+// other three quads, a quad broadcast picks the lane
+template <int Q>
+__device__ __forceinline__ float row_first(float v)
+{
+    int x = __float_as_int(v);
+    x = __builtin_amdgcn_update_dpp(x, x, 0x114, 0xF, 0x2, false);      // row_shr:4 into bank 1 (lanes 4..7)
+    x = __builtin_amdgcn_update_dpp(x, x, 0x118, 0xF, 0xC, false);      // row_shr:8 into banks 2, 3 (lanes 8..15)
+    return __int_as_float(quad_bcast<Q>(x));
 }
 
 // value of lane `j` of this lane's row of 16
@@ -196,11 +216,14 @@ __device__ __forceinline__ void mismatch_slot8(const uint32_t (&C)[9], uint32_t 
 // b: lanes c = 0..7 of a row run the 42-term lane chains, c = 8, 9 the 105-term tails (the other lanes add garbage)
 __device__ __forceinline__ float chain_b(const Sse2Lane &L)
 {
-    lds_cf32x4 *p = (lds_cf32x4 *)(size_t)L.cb;
+    // Straight-line code for all 64 lanes (every read is issued before the first add needs it).  The LDS pipeline is as
+    // busy as the vector unit in this kernel, so a lane that has nothing to read reads the SAME address as all the
+    // other idle lanes (one broadcast access): past term 42 only the two tail lanes of a row fetch their own data.
+    lds_cf32x4 *p = (lds_cf32x4 *)(size_t)L.cb, *p2 = (lds_cf32x4 *)(size_t)L.cb2;
     float acc = 0.f, acc42 = 0.f;
 #pragma unroll
     for (int t = 0; t < 27; t++) {
-        const f32x4 q = p[t];
+        const f32x4 q = t < 11 ? p[t] : p2[t];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int idx = 4 * t + e;
@@ -214,11 +237,11 @@ __device__ __forceinline__ float chain_b(const Sse2Lane &L)
 // product of two 16-bit patch values: exact in float (< 2^24), so _mm_mul_ps(fx, fy) and (float)(ix * iy) coincide.
 __device__ __forceinline__ float chain_a(const Sse2Lane &L)
 {
-    lds_cu32x4 *p = (lds_cu32x4 *)(size_t)L.ca;
+    lds_cu32x4 *p = (lds_cu32x4 *)(size_t)L.ca, *p2 = (lds_cu32x4 *)(size_t)L.ca2;      // ca2: the tails read nothing past word 23
     float acc = 0.f, acc21 = 0.f;
 #pragma unroll
     for (int t = 0; t < 27; t++) {
-        const u32x4 q = p[t];
+        const u32x4 q = t < 6 ? p[t] : p2[t];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int idx = 4 * t + e;
@@ -410,11 +433,14 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
             float b1f, b2f;
             {
                 const float r = chain_b(L);
-                // bbuf = qb0 + qb1; ib1 += bbuf[0] + bbuf[2]; ib2 += bbuf[1] + bbuf[3]  (the tails are already in ib)
-                const float bb0 = row_lane(r, lane, 0) + row_lane(r, lane, 4), bb1 = row_lane(r, lane, 1) + row_lane(r, lane, 5),
-                            bb2 = row_lane(r, lane, 2) + row_lane(r, lane, 6), bb3 = row_lane(r, lane, 3) + row_lane(r, lane, 7);
-                b1f = (row_lane(r, lane, 8) + (bb0 + bb2)) * FLT_SCALE;
-                b2f = (row_lane(r, lane, 9) + (bb1 + bb3)) * FLT_SCALE;
+                // bbuf = qb0 + qb1; ib1 += bbuf[0] + bbuf[2]; ib2 += bbuf[1] + bbuf[3]  (the tails are already in ib), on the
+                // DPP network inside the row: lane c of the row adds lane c + 4 (bb_c, c < 4), then lane c + 2 (c < 2),
+                // then the tail of lane c + 8; lanes 0 and 1 hold b1 and b2, handed to the whole row
+                const float bb = r + row_shl<4>(r);
+                const float u = bb + row_shl<2>(bb);
+                const float f = row_shl<8>(r) + u;
+                b1f = row_first<0>(f) * FLT_SCALE;
+                b2f = row_first<1>(f) * FLT_SCALE;
             }
             wave_lds_fence();                    // the next iteration's terms overwrite these
             const float dlx = (A12 * b2f - A22 * b1f) * D;

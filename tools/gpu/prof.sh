@@ -20,7 +20,7 @@ for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $PMC --kernel-include-regex "svo::" --output-format csv -d /tmp/prof_pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 $BARGS --no-timing-marks --no-overlap > $R/gpurun_out/prof_${TAG}_pmc$i.log 2>&1; echo "pmc$i exit=$?"
+  rm -rf /tmp/prof_pmc$i; rocprofv3 --pmc $PMC --kernel-include-regex "svo::" --output-format csv -d /tmp/prof_pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 $BARGS --no-timing-marks --no-overlap > $R/gpurun_out/prof_${TAG}_pmc$i.log 2>&1; echo "pmc$i exit=$?"
   f=$(find /tmp/prof_pmc$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 $R/tools/gpu/pmc_summary.py "$f" > $R/gpurun_out/prof_${TAG}_pmc$i.txt
 done
