@@ -241,7 +241,13 @@ int svo_track_uploaded(svo_ctx *ctx, int buf, int n_frames, const double *pose0,
  * -- the upload of chunk k+1 and, in overlap mode, the pose stage of chunk k run beside chunk k+1's
  * front end, and the host only ever waits for a batch that has a successor queued behind it.
  * continue_chain != 0 seeds the pose chain with the LAST pose of the previous async batch on the device
- * (no host round trip; pose0 is ignored); 0 seeds it with pose0 (NULL = identity). */
+ * (no host round trip; pose0 is ignored); 0 seeds it with pose0 (NULL = identity).
+ * ABI v6: continue_chain may also carry SVO_CONTINUE_CARRY_FRAME (continue_chain = SVO_CONTINUE_CHAIN |
+ * SVO_CONTINUE_CARRY_FRAME): the caller states that frame 0 of this batch IS the last frame of the previous async batch
+ * (the halo frame of a stream's micro-batches); its pyramids / keypoints / descriptors are then carried over on the device
+ * instead of being computed again from the uploaded copy. */
+#define SVO_CONTINUE_CHAIN       1
+#define SVO_CONTINUE_CARRY_FRAME 2
 int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, const double *pose0, int continue_chain);
 int svo_collect_results(svo_ctx *ctx, svo_step_result *results, int n_pairs);
 /* ABI v6, non-blocking: *n_pairs = the pairs of the OLDEST outstanding async batch when its records are complete (a

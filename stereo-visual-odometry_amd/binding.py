@@ -438,14 +438,16 @@ class Context:
         self._check(self.lib.svo_track_uploaded(self.h, int(buf), int(n_frames), p0, C.c_void_p(out.ctypes.data), MEM_HOST))
         return out
 
-    def track_uploaded_async(self, buf, n_frames, pose0=None, continue_chain=False):
+    def track_uploaded_async(self, buf, n_frames, pose0=None, continue_chain=False, carry_frame=False):
         """svo_track_uploaded without waiting for the GPU; the records are fetched by collect_results()
-        (up to two batches outstanding, collected in launch order)."""
+        (up to two batches outstanding, collected in launch order).  carry_frame (with continue_chain): frame 0 of this
+        batch is the previous batch's last frame -- its features are carried over on the device, not computed again."""
         p0 = None
         if pose0 is not None:
             pose0 = np.ascontiguousarray(pose0, np.float64).reshape(16)
             p0 = C.c_void_p(pose0.ctypes.data)
-        self._check(self.lib.svo_track_uploaded_async(self.h, int(buf), int(n_frames), p0, int(bool(continue_chain))))
+        flags = (1 if continue_chain else 0) | (2 if continue_chain and carry_frame else 0)
+        self._check(self.lib.svo_track_uploaded_async(self.h, int(buf), int(n_frames), p0, flags))
 
     def collect_results(self, n_pairs):
         out = np.zeros(int(n_pairs), dtype=STEP_DTYPE)

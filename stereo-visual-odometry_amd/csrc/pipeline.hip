@@ -68,6 +68,44 @@ static int ingest_frames(svo_ctx *ctx, const uint8_t *L, const uint8_t *R, int p
 
 static int run_back(svo_ctx *ctx, int n_pairs, const double *pose0_host, svo_step_result *results_dev);
 
+// A micro-batch of a stream starts with the frame the previous one ended with: instead of building that frame's
+// pyramids and detecting its features again, what the pair needs of it is carried from frame slot `last` to slot 0
+// (LK mode: the two pyramid slots, the FAST keypoints + responses + count; ORB mode: both images' keypoints, descriptors,
+// counts and capacity flags) -- ONE launch, 16 bytes per thread.
+struct CarryArgs { uint8_t *dst[4]; const uint8_t *src[4]; size_t bytes[4]; int n; };
+__global__ __launch_bounds__(256) void carry_frame_kernel(CarryArgs a)
+{
+    const int seg = blockIdx.y;
+    if (seg >= a.n) return;
+    const size_t n16 = a.bytes[seg] / 16, rest = a.bytes[seg] - n16 * 16;
+    const uint4 *s = (const uint4 *)a.src[seg];
+    uint4 *d = (uint4 *)a.dst[seg];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) d[i] = s[i];
+    if (blockIdx.x == 0 && threadIdx.x < rest) a.dst[seg][n16 * 16 + threadIdx.x] = a.src[seg][n16 * 16 + threadIdx.x];
+}
+
+static void carry_last_frame(svo_ctx *ctx, int last)
+{
+    CarryArgs c{};
+    const size_t cap = (size_t)ctx->cfg.max_keypoints;
+    auto seg = [&](void *dst, const void *src, size_t bytes) {
+        c.dst[c.n] = (uint8_t *)dst; c.src[c.n] = (const uint8_t *)src; c.bytes[c.n] = bytes; c.n++;
+    };
+    if (ctx->cfg.track_mode == SVO_MODE_ORB) {
+        const size_t kcap = (size_t)ctx->orb_kp_cap;
+        seg(ctx->orb_kps, (const svo_keypoint *)ctx->orb_kps + 2 * (size_t)last * kcap, 2 * kcap * sizeof(svo_keypoint));
+        seg(ctx->orb_desc, ctx->orb_desc + 2 * (size_t)last * kcap * 32, 2 * kcap * 32);
+        seg(ctx->orb_n, ctx->orb_n + 2 * last, 2 * sizeof(int));
+        seg(ctx->orb_overflow, ctx->orb_overflow + 2 * last, 2 * sizeof(int));
+    } else {
+        seg(ctx->bslots, ctx->bslots + (size_t)(2 * last) * ctx->geom.slot_bytes, (size_t)2 * ctx->geom.slot_bytes);
+        seg(ctx->kp_xy, ctx->kp_xy + (size_t)last * cap, cap * sizeof(float2));
+        seg(ctx->kp_resp, ctx->kp_resp + (size_t)last * cap, cap * sizeof(float));
+        seg(ctx->kp_n, ctx->kp_n + last, sizeof(int));
+    }
+    hipLaunchKernelGGL(carry_frame_kernel, dim3(64, c.n), dim3(256), 0, ctx->stream, c);
+}
+
 // Tracks `n_pairs` pairs; pair p = (frame slot fp0 + p*fstep, frame slot fc0 + p*fstep).
 // Front half on the context's stream: circular LK, compaction, triangulation.  Back half (pose
 // solver, gates, chain, optional copy of the records to `results_dev`) on `back_stream`, which is
@@ -163,7 +201,7 @@ static int run_back(svo_ctx *ctx, int n_pairs, const double *pose0_host, svo_ste
 
 int pipeline_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t *right_frames, int pitch,
                          int64_t frame_stride, int n_frames, const double *pose0,
-                         svo_step_result *results, int results_mem)
+                         svo_step_result *results, int results_mem, int carry_first)
 {
     // results == NULL with SVO_MEM_DEVICE: the records stay in the context (svo_collect_results)
     SVO_ARG(left_frames && right_frames && (results || results_mem == SVO_MEM_DEVICE), "null pointer");
@@ -172,9 +210,18 @@ int pipeline_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t
     SVO_ARG(results_mem == SVO_MEM_HOST || results_mem == SVO_MEM_DEVICE, "bad results_mem");
     SVO_HIP(hipSetDevice(ctx->device));
     const int n_pairs = n_frames - 1;
+    // carry_first: frame 0 of this batch IS the last frame of the previous batch on this context (a stream's halo frame):
+    // its features are carried over instead of being computed again
+    const int carry_from = carry_first && ctx->last_batch_pairs > 0 ? ctx->last_batch_pairs : 0;
     ctx->last_batch_pairs = n_pairs;
     mark(ctx, kT0);
-    int rc = ingest_frames(ctx, left_frames, right_frames, pitch, frame_stride, 0, n_frames);
+    int rc;
+    if (carry_from > 0) {
+        carry_last_frame(ctx, carry_from);
+        rc = ingest_frames(ctx, left_frames + frame_stride, right_frames + frame_stride, pitch, frame_stride, 1, n_frames - 1);
+    } else {
+        rc = ingest_frames(ctx, left_frames, right_frames, pitch, frame_stride, 0, n_frames);
+    }
     if (rc) return rc;
     // the LK outputs use the keypoint stride (cap) per item: frame slots are consecutive (fstep 1)
     rc = run_pairs(ctx, n_pairs, 0, 1, 1, pose0, results_mem == SVO_MEM_DEVICE ? results : nullptr);

@@ -24,7 +24,7 @@ int pipeline_add_frame(svo_ctx *ctx, const uint8_t *left, const uint8_t *right, 
                        svo_step_result *res);
 int pipeline_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t *right_frames, int pitch,
                          int64_t frame_stride, int n_frames, const double *pose0,
-                         svo_step_result *results, int results_mem);
+                         svo_step_result *results, int results_mem, int carry_first = 0);
 }  // namespace svo
 
 static int align_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -866,7 +866,8 @@ extern "C" int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, con
     const size_t fbytes = (size_t)ctx->stage_pitch * ctx->cfg.height, per_cam = fbytes * (size_t)(ctx->cfg.max_batch + 1);
     SVO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_up[buf], 0));
     int rc = pipeline_track_batch(ctx, ctx->fb[buf], ctx->fb[buf] + per_cam, ctx->stage_pitch, (int64_t)fbytes, n_frames,
-                                  continue_chain ? nullptr : pose0, ctx->d_async[r], SVO_MEM_DEVICE);
+                                  continue_chain ? nullptr : pose0, ctx->d_async[r], SVO_MEM_DEVICE,
+                                  (continue_chain & SVO_CONTINUE_CARRY_FRAME) != 0);
     ctx->seed_dev = nullptr;
     if (rc < 0) return rc;
     SVO_HIP(hipEventRecord(ctx->ev_fb_free[buf], ctx->stream));

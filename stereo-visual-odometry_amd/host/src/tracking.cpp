@@ -265,7 +265,9 @@ bool Tracking::TrackUploaded(int buf, int n_frames, std::vector<svo_step_result>
 bool Tracking::TrackUploadedAsync(int buf, int n_frames, bool continue_chain)
 {
     if (!ctx_ || n_frames < 2 || async_tail_ - async_head_ >= 2) return false;
-    int rc = svo_track_uploaded_async(ctx_, buf, n_frames, frame_pose_.m, continue_chain ? 1 : 0);
+    // a chunk that continues the chain starts with the previous chunk's last frame (the runner's and the stream's one-frame
+    // halo): its features are carried over on the device instead of being extracted again
+    int rc = svo_track_uploaded_async(ctx_, buf, n_frames, frame_pose_.m, continue_chain ? (SVO_CONTINUE_CHAIN | SVO_CONTINUE_CARRY_FRAME) : 0);
     if (rc < 0) {
         LZB_LOG("ERROR", "svo_track_uploaded_async: %s", svo_last_error(ctx_));
         return false;

@@ -43,7 +43,7 @@ class FrameStream:
         b = self.buf
         self.ctx.upload_frames(b, self.pin[b][0][:self.n], self.pin[b][1][:self.n])
         self.uploaded[b] = True
-        self.ctx.track_uploaded_async(b, self.n, continue_chain=self.chunk > 0)
+        self.ctx.track_uploaded_async(b, self.n, continue_chain=self.chunk > 0, carry_frame=self.chunk > 0)
         self.outstanding.append(self.n - 1)
         self.chunk += 1
         nb = b ^ 1
