@@ -12,11 +12,11 @@ import conftest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("tool,seeds", [("stress_lk_parity.py", "4"), ("stress_parity.py", "3")])
+@pytest.mark.parametrize("tool,seeds", [("stress_lk_parity.py", "4"), ("stress_lk_parity.py", "4 sse2"), ("stress_parity.py", "3")])
 def test_adversarial_stress(tool, seeds):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    r = subprocess.run([sys.executable, os.path.join(conftest.ROOT, "tools", tool), seeds], capture_output=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(conftest.ROOT, "tools", tool)] + seeds.split(), capture_output=True, timeout=900)
     out = r.stdout.decode()
     assert r.returncode == 0 and "stress result: OK" in out, out[-3000:] + r.stderr.decode()[-2000:]

@@ -4,7 +4,9 @@
 run closest to their 32-bit limits), sub-pixel start points everywhere including outside the
 image, large displacements (many iterations, tile restaging), flat regions (min-eigenvalue
 rejections).  Every output point and status byte must be bit-identical.
-Usage: python tools/stress_lk_parity.py [n_seeds=12]"""
+Usage: python tools/stress_lk_parity.py [n_seeds=12] [exact|sse2]     (sse2: svo_config.lk_accum = SSE2 against the
+oracle's accumulation mode 2 -- float sums in an x86 OpenCV's lane order, where the pair sums of a binary texture exceed
+2^24 and the conversions round)"""
 import os
 import sys
 
@@ -33,9 +35,12 @@ def texture(rng, h, w, kind):
 
 def main():
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    sse2 = len(sys.argv) > 2 and sys.argv[2] == "sse2"
     pkg = entry.load_package()
     O = entry.load_oracle()
     O.build()
+    O.set_lk_accum(O.LK_ACCUM_FLOAT_SSE if sse2 else O.LK_ACCUM_EXACT)
+    ctx_kw = dict(lk_accum=pkg.LK_ACCUM_SSE2) if sse2 else {}
     bad = 0
     for seed in range(n_seeds):
         rng = np.random.default_rng(1000 + seed)
@@ -49,7 +54,7 @@ def main():
         pts = np.stack([rng.uniform(-15, w + 15, n), rng.uniform(-15, h + 15, n)], 1).astype(np.float32)
         pts[::7] = np.round(pts[::7])               # exact integers
         pts[1::7] = np.floor(pts[1::7]) + 0.5        # exact halves
-        ctx = pkg.Context(w, h, device=0)
+        ctx = pkg.Context(w, h, device=0, **ctx_kw)
         ctx.build_pyramid(0, I)
         ctx.build_pyramid(1, J)
         for a, b_, A, B in ((0, 1, I, J), (1, 0, J, I)):
