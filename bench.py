@@ -820,17 +820,19 @@ def main():
                 O.build()
             leg_steps, leg_warm = max(2, min(steps, 6)), 1
 
-            def finish(name, lctx, el, st_ms, recs, f0, n_steps, Bl, extra, check_kw, Lf=L, Rf=R, wd=W):
+            def finish(name, lctx, el, st_ms, recs, f0, n_steps, Bl, extra, check_kw, frames=(L, R, W), proj=(P1, P2)):
+                """The leg's entry of the JSON line; its last step is checked against the oracle before the context goes."""
                 leg = {"value": round(Bl * n_steps / el, 2), "unit": "stereo pairs/s", "ms_per_step": round(1e3 * el / n_steps, 4),
                        "steps": n_steps, "pairs_per_step": Bl, "pairs_ok_last_step": int(recs["ok"].sum()),
                        "mean_keypoints_per_pair": round(float(recs["n_prev_kps"].mean()), 1),
                        "stage_ms_per_step": {k: round(v, 4) for k, v in st_ms.items()}, **extra}
                 if O is not None and not args.no_self_check:
-                    leg["self_check"] = self_check(pkg, O, lctx, recs, Lf, Rf, wd, f0, P1l, P2l, **check_kw)
+                    leg["self_check"] = self_check(pkg, O, lctx, recs, frames[0], frames[1], frames[2], f0, proj[0], proj[1], **check_kw)
+                if leg.get("cpu_baseline"):
+                    leg["vs_cpu_baseline_1_thread"] = round(leg["value"] / leg["cpu_baseline"]["value"], 1)
                 lctx.close()
                 out[name] = leg
 
-            P1l, P2l = P1, P2
             if args.mode == "lk" and args.lk_accum == "exact":
                 # (1) the LK tracker in an x86 OpenCV's accumulation order: what bit-identity with the reference CPU path costs
                 lctx, el, st_ms, recs, f0 = run_leg(pkg, torch, dev, L, R, W, H, B, leg_steps, leg_warm,
@@ -851,10 +853,7 @@ def main():
                 if O is not None and args.cpu_pairs > 0:
                     n1 = max(4, min(args.cpu_pairs // 4, B))
                     extra["cpu_baseline"] = cpu_orb(O, L, R, W, P1, P2, n1, min(max(4 * n1, 2 * usable_cores()), B))
-                    extra["vs_cpu_baseline_1_thread"] = None     # filled below
                 finish("orb", lctx, el, st_ms, recs, f0, leg_steps, B, extra, dict(mode="orb"))
-                if out["orb"].get("cpu_baseline"):
-                    out["orb"]["vs_cpu_baseline_1_thread"] = round(out["orb"]["value"] / out["orb"]["cpu_baseline"]["value"], 1)
             if args.mode == "lk" and args.hd_batch > 0:
                 # (3) BASELINE config #4: 1920x1080, EXACTLY the 2000 highest-response FAST corners per frame
                 Bh, Wh, Hh, Ph = args.hd_batch, 1920, 1080, 1920
@@ -863,16 +862,16 @@ def main():
                 Rh = torch.zeros_like(Lh)
                 for f in range(2 * Bh + 1):
                     Lh[f], Rh[f] = seqh.render(f)
-                P1l, P2l = seqh.proj()
+                P1h, P2h = seqh.proj()
                 lctx, el, st_ms, recs, f0 = run_leg(pkg, torch, dev, Lh, Rh, Wh, Hh, Bh, leg_steps, leg_warm,
-                                                    dict(P1=P1l, P2=P2l, max_keypoints=1 << 16, fast_keep_strongest=2000))
+                                                    dict(P1=P1h, P2=P2h, max_keypoints=1 << 16, fast_keep_strongest=2000))
                 pts = int(round(float(recs["n_prev_kps"].mean()) * Bh))
                 extra = {"definition": "BASELINE config #4: synthetic 1920x1080 stereo stream, fast_keep_strongest = 2000 (the 2000 "
                                        "highest-response FAST(20) corners of every frame, ties by raster order), FAST+LK",
                          "roofline": roofline_lk(st_ms, pts, Bh) if st_ms.get("lk") else None}
                 if O is not None and args.cpu_pairs > 0:
                     n1 = max(2, min(args.cpu_pairs // 12, Bh))
-                    prm = O.make_params(P1l, P2l)
+                    prm = O.make_params(P1h, P2h)
                     flh = Lh[:n1 + 1].cpu().numpy()
                     frh = Rh[:n1 + 1].cpu().numpy()
                     c0 = time.perf_counter()
@@ -884,10 +883,8 @@ def main():
                     extra["cpu_baseline"] = {"value": round(v1, 3), "unit": "stereo pairs/s", "cores": 1, "kind": "port",
                                              "sample": f"first {n1} pairs of the same 1920x1080 frames, oracle/ (FAST, selection of the 2000 "
                                                        f"strongest, LK step), 1 thread"}
-                    extra["vs_cpu_baseline_1_thread"] = None
-                finish("hd", lctx, el, st_ms, recs, f0, leg_steps, Bh, extra, dict(mode="lk", keep=2000, n_check=4), Lf=Lh, Rf=Rh, wd=Wh)
-                if out["hd"].get("cpu_baseline"):
-                    out["hd"]["vs_cpu_baseline_1_thread"] = round(out["hd"]["value"] / out["hd"]["cpu_baseline"]["value"], 1)
+                finish("hd", lctx, el, st_ms, recs, f0, leg_steps, Bh, extra, dict(mode="lk", keep=2000, n_check=4),
+                       frames=(Lh, Rh, Wh), proj=(P1h, P2h))
                 del Lh, Rh
 
     if rank == 0:

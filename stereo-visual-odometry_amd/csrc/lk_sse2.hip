@@ -59,7 +59,7 @@ struct Sse2Lane {
     uint32_t cb, ca;        // chain read addresses (b, A) of this lane's chain, the lane's slot included
     uint32_t cb2, ca2;      // ... past the part every chain has (b: term 44, A: word 24): own chain or the idle lanes' common address
     uint32_t selA;          // v_perm selector that puts the two factors of this lane's A sum side by side
-    bool b_tail, a_tail, b_chain, a_chain;      // chain roles of lane c: b: c < 10 (8, 9 = tails), A: c < 15 (12..14 = tails)
+    bool b_tail, a_tail;    // lane c of a row runs a tail chain (b: c = 8, 9; A: c = 12..14)
 };
 
 __device__ __forceinline__ void lds_store(uint32_t byte_addr, uint32_t v) { *(lds_u32 *)(size_t)byte_addr = v; }
@@ -93,7 +93,7 @@ __device__ __forceinline__ Sse2Lane make_lane(int lane, uint32_t lds_base)
     }
     const int c = lane & 15;
     const uint32_t stage_s = stage0 + (uint32_t)((lane >> 4) * kStageDw) * 4;
-    L.b_tail = c == 8 || c == 9; L.b_chain = c < 10; L.a_chain = c < 15;
+    L.b_tail = c == 8 || c == 9;
     L.cb = c < 8 ? stage_s + (uint32_t)(c * kSStride) * 4 : (L.b_tail ? stage_s + (uint32_t)(kTBase + (c - 8) * kTStride) * 4 : stage0);
     L.cb2 = L.b_tail ? L.cb : stage0;
     L.a_tail = c >= 12;
