@@ -11,14 +11,14 @@
  * so a 64-lane GPU reduction is bit-identical.  Everything else is upstream's single-precision
  * recipe with FP contraction off.
  *
- * SENSITIVITY SWITCH (orc_lk_set_accum, tests only; never the parity target): the same function with
- * upstream's x86 accumulation instead -- acctype = itemtype = float (every OpenCV 3 build that is not
+ * ACCUMULATION SWITCH (orc_lk_set_accum, tests only).  Mode 0 is the parity target of lk_kernel (svo_config.lk_accum =
+ * exact, the default); mode 2 is the parity target of lk_sse2_kernel (lk_accum = sse2, round 4); mode 1 exists for the
+ * sensitivity study only.  Modes 1 and 2 are the same function with upstream's x86 accumulation instead -- acctype = itemtype = float (every OpenCV 3 build that is not
  * the Tegra one), either in plain raster order (the scalar loop of lkpyramid.cpp) or in the lane order
  * of its CV_SSE2 block as recalled from OpenCV 3.4 (A: four lanes over x = 0..19 plus a scalar tail
  * for x = 20; b: two 4-lane accumulators fed by _mm_madd_epi16 pairs (d_k, d_k+4) over x = 0..15 plus
  * a scalar tail for x = 16..20).  tests/test_lk_accum_sensitivity.py measures how far tracks and
- * poses move between the three orders: the evidence that the pose bar holds whichever one the
- * reference author's OpenCV used.
+ * poses move between the three orders; tests/test_gpu_parity_lk_sse2.py holds the HIP kernel to mode 2 bit for bit.
  */
 #include "svo_oracle.h"
 #include <math.h>
