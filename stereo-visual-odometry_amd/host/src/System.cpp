@@ -583,10 +583,9 @@ void System::RunBatched(int B, int decode_threads)
 // ---- pipelined stream ----------------------------------------------------------------------------
 void System::StreamRelease()
 {
-    svo_ctx *ctx = tracking_ ? tracking_->Context() : nullptr;
     for (int k = 0; k < 2; k++)
         for (int cam = 0; cam < 2; cam++)
-            if (stream_.pin[k][cam]) { if (ctx) svo_host_free(ctx, stream_.pin[k][cam]); stream_.pin[k][cam] = nullptr; }
+            if (stream_.pin[k][cam]) { svo_host_free(nullptr, stream_.pin[k][cam]); stream_.pin[k][cam] = nullptr; }
     stream_.active = false;
 }
 
