@@ -376,6 +376,15 @@ def orb_track_step(params, lastL, dLastL, lastR, dLastR, curL, dCurL, pose):
     return d, pose.reshape(4, 4)
 
 
+def orb_distribute(xyr, min_x, max_x, min_y, max_y, n_features):
+    """DistributeOctTree on (n, 3) float32 candidates (x, y, response): indices of the kept ones, list order."""
+    xyr = np.ascontiguousarray(xyr, np.float32).reshape(-1, 3)
+    sel = np.zeros(max(len(xyr), 1), np.int32)
+    m = lib().orc_orb_distribute(xyr.ctypes.data_as(C.c_void_p), len(xyr), int(min_x), int(max_x), int(min_y), int(max_y),
+                                 int(n_features), sel.ctypes.data_as(C.c_void_p))
+    return sel[:m].copy()
+
+
 def orb_candidates(img, level, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, cap=1 << 16):
     img, p = _u8(img)
     h, w = img.shape

@@ -550,6 +550,18 @@ int orc_orb_pyramid_level(const uint8_t *img, int w, int h, int pitch, float sca
     return 0;
 }
 
+/* DistributeOctTree alone on caller-supplied candidates (x, y, response triples): the selected candidate indices in
+ * list order (tests of the host mirror's ORBextractor::DistributeOctTree) */
+int orc_orb_distribute(const float *xyr, int n, int minX, int maxX, int minY, int maxY, int N, int *sel)
+{
+    orb_cand *c = (orb_cand *)malloc(sizeof(orb_cand) * (size_t)(n > 0 ? n : 1));
+    int i, m;
+    for (i = 0; i < n; i++) { c[i].x = xyr[3 * i]; c[i].y = xyr[3 * i + 1]; c[i].response = xyr[3 * i + 2]; }
+    m = orb_distribute(c, n, minX, maxX, minY, maxY, N, sel);
+    free(c);
+    return m;
+}
+
 /* FAST candidates of one level before the quadtree (x, y relative to the 16-px border, response) */
 int orc_orb_candidates(const uint8_t *img, int w, int h, int pitch, float scaleFactor, int nlevels, int level,
                        int iniTh, int minTh, float *out3, int cap)

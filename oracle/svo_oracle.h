@@ -156,6 +156,7 @@ void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, int spitch, uint8_
                           int dpitch);
 int  orc_orb_pyramid_level(const uint8_t *img, int w, int h, int pitch, float scaleFactor, int nlevels, int level,
                            uint8_t *out /* tight, may be NULL */, int *ow, int *oh);
+int  orc_orb_distribute(const float *xyr, int n, int minX, int maxX, int minY, int maxY, int N, int *sel);
 int  orc_orb_candidates(const uint8_t *img, int w, int h, int pitch, float scaleFactor, int nlevels, int level,
                         int iniTh, int minTh, float *out3, int cap);
 float orc_fast_atan2(float y, float x);

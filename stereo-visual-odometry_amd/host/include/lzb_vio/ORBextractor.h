@@ -5,9 +5,19 @@
 // the six getters and the public mvImagePyramid.  The extraction itself -- 8-level bilinear pyramid,
 // per-cell FAST with threshold fallback, quadtree distribution, intensity-centroid orientation, 7x7
 // blur, rotated BRIEF -- runs on the GPU behind svo_orb_extract (include/svo_abi.h); there is no CPU
-// implementation behind this class.  The protected ORB-SLAM2 stages (ComputePyramid,
-// ComputeKeyPointsOctTree, DistributeOctTree, ComputeKeyPointsOld) and the ExtractorNode helper type
-// are therefore not part of the mirror; the protected data members a subclass could read are kept.
+// implementation of the extraction behind this class.
+//
+// The protected ORB-SLAM2 stages a subclass of the reference class may call (include/lzb_vio/ORBextractor.h:77-85)
+// are kept so that such a subclass compiles and behaves (round 4):
+//   ComputePyramid(image)            fills mvImagePyramid (it runs the extraction on the GPU and keeps its result)
+//   ComputeKeyPointsOctTree(all)     the keypoints of the image last given to ComputePyramid, per level, in LEVEL
+//                                    coordinates, oriented -- what src/ORBextractor.cpp:717-807 leaves in allKeypoints
+//   DistributeOctTree(...)           ORB-SLAM2's quadtree on the HOST for the caller's own keypoints (the extraction
+//                                    itself distributes on the GPU); ties of the "largest node first" order are broken
+//                                    by creation order, where the reference sorts by heap address
+//   ComputeKeyPointsOld(all)         NOT built (the reference never calls it, src/ORBextractor.cpp:1006): forwards to
+//                                    ComputeKeyPointsOctTree and says so once
+// and so are the ExtractorNode helper type and the protected data members (`pattern` = the 512 rBRIEF test points).
 //
 // Additive: Ok() / LastError() (the reference aborts inside OpenCV on a bad image; this returns an
 // empty keypoint set and keeps the message), SetKeepPyramid(false) to skip the device-to-host copy
@@ -20,6 +30,18 @@
 #include "svo_abi.h"
 
 namespace lzb_vio {
+
+// node of DistributeOctTree's quadtree (reference include/lzb_vio/ORBextractor.h:11-23)
+class ExtractorNode {
+public:
+    ExtractorNode() : bNoMore(false) {}
+    void DivideNode(ExtractorNode &n1, ExtractorNode &n2, ExtractorNode &n3, ExtractorNode &n4);
+
+    std::vector<cv::KeyPoint> vKeys;
+    cv::Point2i UL, UR, BL, BR;
+    std::list<ExtractorNode>::iterator lit;
+    bool bNoMore;
+};
 
 class ORBextractor {
 public:
@@ -54,6 +76,13 @@ public:
     const std::vector<int> &FeaturesPerLevel() const { return mnFeaturesPerLevel; }
 
 protected:
+    void ComputePyramid(cv::Mat image);
+    void ComputeKeyPointsOctTree(std::vector<std::vector<cv::KeyPoint>> &allKeypoints);
+    std::vector<cv::KeyPoint> DistributeOctTree(const std::vector<cv::KeyPoint> &vToDistributeKeys, const int &minX, const int &maxX,
+                                                const int &minY, const int &maxY, const int &nFeatures, const int &level);
+    void ComputeKeyPointsOld(std::vector<std::vector<cv::KeyPoint>> &allKeypoints);
+    std::vector<cv::Point> pattern;
+
     int nfeatures;
     double scaleFactor;
     int nlevels;
@@ -71,6 +100,8 @@ private:
     std::string err_;
     std::vector<svo_keypoint> kp_buf_;
     std::vector<uint8_t> desc_buf_;
+    std::vector<cv::KeyPoint> last_keys_;      // of the image last given to ComputePyramid (ComputeKeyPointsOctTree splits them)
+    bool have_last_keys_ = false;
 };
 
 }  // namespace lzb_vio

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <list>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -22,6 +23,13 @@ struct Point2f {
     Point2f() {}
     Point2f(float x_, float y_) : x(x_), y(y_) {}
 };
+
+struct Point2i {
+    int x = 0, y = 0;
+    Point2i() {}
+    Point2i(int x_, int y_) : x(x_), y(y_) {}
+};
+typedef Point2i Point;
 
 // field order of cv::KeyPoint == svo_keypoint
 struct KeyPoint {

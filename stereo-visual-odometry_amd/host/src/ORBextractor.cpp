@@ -2,7 +2,10 @@
 // src/ORBextractor.cpp:359-418 constructor tables, :990-1055 operator()).
 #include "lzb_vio/ORBextractor.h"
 
+#include <algorithm>
 #include <cmath>
+
+#include "../../csrc/orb_pattern.h"        // the 256 x 4 rBRIEF table (constant data shared with the device code)
 
 namespace lzb_vio {
 
@@ -46,6 +49,9 @@ ORBextractor::ORBextractor(int nfeatures_, float scaleFactor_, int nlevels_, int
         while (umax[v0] == umax[v0 + 1]) ++v0;
         umax[v] = v0++;
     }
+    // "std::copy(pattern0, pattern0 + npoints, std::back_inserter(pattern))" (reference src/ORBextractor.cpp:394-396)
+    pattern.reserve(512);
+    for (int i = 0; i < 512; i++) pattern.push_back(cv::Point(svo_bit_pattern_31[2 * i], svo_bit_pattern_31[2 * i + 1]));
 }
 
 ORBextractor::~ORBextractor()
@@ -129,6 +135,161 @@ void ORBextractor::operator()(cv::InputArray image, cv::InputArray /*mask*/, std
         for (int y = 0; y < h; y++) memcpy(lvl.ptr(y), tight.data() + (size_t)y * w, (size_t)w);
         mvImagePyramid[(size_t)l] = lvl;
     }
+}
+
+// ---- the protected ORB-SLAM2 stages -------------------------------------------------------------------------------
+
+// reference src/ORBextractor.cpp:1061-1085 builds the pyramid on the CPU; here the whole extraction runs on the GPU
+// and its keypoints are kept for ComputeKeyPointsOctTree
+void ORBextractor::ComputePyramid(cv::Mat image)
+{
+    const bool keep = keep_pyramid_;
+    keep_pyramid_ = true;
+    cv::Mat desc;
+    (*this)(image, cv::Mat(), last_keys_, desc);
+    keep_pyramid_ = keep;
+    have_last_keys_ = Ok() && !image.empty();
+}
+
+// reference src/ORBextractor.cpp:717-807: per level FAST on cells, DistributeOctTree, then
+// "keypoints[i].pt.x += minBorderX; .octave = level; .size = scaledPatchSize" and computeOrientation.  operator()
+// returns exactly those keypoints with "keypoint->pt *= scale" applied (:1043-1049): the level coordinates are integers,
+// so dividing by the scale and rounding recovers them exactly.
+void ORBextractor::ComputeKeyPointsOctTree(std::vector<std::vector<cv::KeyPoint>> &allKeypoints)
+{
+    allKeypoints.assign((size_t)(nlevels > 0 ? nlevels : 0), std::vector<cv::KeyPoint>());
+    if (!have_last_keys_) {
+        LZB_LOG("ERROR", "ORBextractor::ComputeKeyPointsOctTree: call ComputePyramid(image) first");
+        return;
+    }
+    for (const cv::KeyPoint &k : last_keys_) {
+        if (k.octave < 0 || k.octave >= nlevels) continue;
+        cv::KeyPoint q = k;
+        if (k.octave > 0) {
+            q.pt.x = std::rint(k.pt.x / mvScaleFactor[(size_t)k.octave]);
+            q.pt.y = std::rint(k.pt.y / mvScaleFactor[(size_t)k.octave]);
+        }
+        allKeypoints[(size_t)k.octave].push_back(q);
+    }
+}
+
+void ORBextractor::ComputeKeyPointsOld(std::vector<std::vector<cv::KeyPoint>> &allKeypoints)
+{
+    static bool said = false;
+    if (!said) {
+        LZB_LOG("WARNING", "ORBextractor::ComputeKeyPointsOld is not built (the reference never calls it): ComputeKeyPointsOctTree runs instead");
+        said = true;
+    }
+    ComputeKeyPointsOctTree(allKeypoints);
+}
+
+// reference src/ORBextractor.cpp:430-485: the four children of a node and the keys that fall into each
+void ExtractorNode::DivideNode(ExtractorNode &n1, ExtractorNode &n2, ExtractorNode &n3, ExtractorNode &n4)
+{
+    const int halfX = (int)std::ceil((float)(UR.x - UL.x) / 2), halfY = (int)std::ceil((float)(BR.y - UL.y) / 2);
+    const int midX = UL.x + halfX, midY = UL.y + halfY;
+    n1.UL = UL;                       n1.UR = cv::Point2i(midX, UL.y);  n1.BL = cv::Point2i(UL.x, midY);  n1.BR = cv::Point2i(midX, midY);
+    n2.UL = n1.UR;                    n2.UR = UR;                       n2.BL = n1.BR;                    n2.BR = cv::Point2i(UR.x, midY);
+    n3.UL = n1.BL;                    n3.UR = n1.BR;                    n3.BL = BL;                       n3.BR = cv::Point2i(midX, BL.y);
+    n4.UL = n3.UR;                    n4.UR = n2.BR;                    n4.BL = n3.BR;                    n4.BR = BR;
+    ExtractorNode *child[4] = {&n1, &n2, &n3, &n4};
+    for (ExtractorNode *c : child) c->vKeys.reserve(vKeys.size());
+    for (const cv::KeyPoint &kp : vKeys) {
+        const int right = kp.pt.x < (float)midX ? 0 : 1, below = kp.pt.y < (float)midY ? 0 : 2;
+        child[right + below]->vKeys.push_back(kp);
+    }
+    for (ExtractorNode *c : child) c->bNoMore = c->vKeys.size() == 1;
+}
+
+// reference src/ORBextractor.cpp:487-715.  The list walk of a pass: every node with more than one key is divided, its
+// non-empty children go to the FRONT of the list; once the next pass could overshoot N the nodes to expand are taken
+// largest first until N nodes exist; every node then keeps its best-response key.
+std::vector<cv::KeyPoint> ORBextractor::DistributeOctTree(const std::vector<cv::KeyPoint> &vToDistributeKeys, const int &minX,
+                                                          const int &maxX, const int &minY, const int &maxY, const int &N,
+                                                          const int & /*level*/)
+{
+    std::vector<cv::KeyPoint> result;
+    if (maxY <= minY || maxX <= minX || vToDistributeKeys.empty()) return result;
+    const int nIni = (int)std::round((float)(maxX - minX) / (float)(maxY - minY));
+    if (nIni <= 0) return result;
+    const float hX = (float)(maxX - minX) / (float)nIni;
+    std::list<ExtractorNode> nodes;
+    std::vector<ExtractorNode *> roots((size_t)nIni);
+    for (int i = 0; i < nIni; i++) {
+        ExtractorNode ni;
+        ni.UL = cv::Point2i((int)(hX * (float)i), 0);
+        ni.UR = cv::Point2i((int)(hX * (float)(i + 1)), 0);
+        ni.BL = cv::Point2i(ni.UL.x, maxY - minY);
+        ni.BR = cv::Point2i(ni.UR.x, maxY - minY);
+        ni.vKeys.reserve(vToDistributeKeys.size());
+        nodes.push_back(ni);
+        roots[(size_t)i] = &nodes.back();
+    }
+    for (const cv::KeyPoint &kp : vToDistributeKeys) {
+        const int strip = (int)(kp.pt.x / hX);
+        if (strip >= 0 && strip < nIni) roots[(size_t)strip]->vKeys.push_back(kp);
+    }
+    for (auto it = nodes.begin(); it != nodes.end();) {
+        if (it->vKeys.size() == 1) { it->bNoMore = true; ++it; }
+        else if (it->vKeys.empty()) it = nodes.erase(it);
+        else ++it;
+    }
+    // (keys, creation number, node): the creation number breaks ties where the reference compares heap addresses
+    struct ToExpand { int size; long seq; ExtractorNode *node; };
+    long created = 0;
+    std::vector<ToExpand> expand;
+    auto add_children = [&](ExtractorNode (&c)[4], int *n_big) {
+        for (ExtractorNode &ch : c) {
+            if (ch.vKeys.empty()) continue;
+            nodes.push_front(ch);
+            nodes.front().lit = nodes.begin();
+            if (ch.vKeys.size() > 1) {
+                if (n_big) ++*n_big;
+                expand.push_back(ToExpand{(int)ch.vKeys.size(), created, &nodes.front()});
+            }
+            ++created;
+        }
+    };
+    bool finish = false;
+    while (!finish) {
+        const size_t prev_size = nodes.size();
+        int n_to_expand = 0;
+        expand.clear();
+        for (auto it = nodes.begin(); it != nodes.end();) {
+            if (it->bNoMore) { ++it; continue; }
+            ExtractorNode c[4];
+            it->DivideNode(c[0], c[1], c[2], c[3]);
+            add_children(c, &n_to_expand);
+            it = nodes.erase(it);
+        }
+        if ((int)nodes.size() >= N || nodes.size() == prev_size) finish = true;
+        else if ((int)nodes.size() + n_to_expand * 3 > N) {
+            while (!finish) {
+                const size_t before = nodes.size();
+                std::vector<ToExpand> todo;
+                todo.swap(expand);
+                std::sort(todo.begin(), todo.end(), [](const ToExpand &a, const ToExpand &b) {
+                    return a.size != b.size ? a.size < b.size : a.seq < b.seq;
+                });
+                for (size_t j = todo.size(); j-- > 0;) {
+                    ExtractorNode c[4];
+                    todo[j].node->DivideNode(c[0], c[1], c[2], c[3]);
+                    add_children(c, nullptr);
+                    nodes.erase(todo[j].node->lit);
+                    if ((int)nodes.size() >= N) break;
+                }
+                if ((int)nodes.size() >= N || nodes.size() == before) finish = true;
+            }
+        }
+    }
+    result.reserve(nodes.size());
+    for (const ExtractorNode &nd : nodes) {
+        const cv::KeyPoint *best = &nd.vKeys[0];
+        for (const cv::KeyPoint &kp : nd.vKeys)
+            if (kp.response > best->response) best = &kp;
+        result.push_back(*best);
+    }
+    return result;
 }
 
 }  // namespace lzb_vio

@@ -8,12 +8,48 @@
 //                                                       the keypoints, descriptors and of mvImagePyramid
 #include "lzb_vio/ORBextractor.h"
 #include "lzb_vio/System.h"
+#include <cmath>
 
 static unsigned long long hash_bytes(const void *p, size_t n, unsigned long long h = 0)
 {
     const unsigned char *b = (const unsigned char *)p;
     for (size_t i = 0; i < n; i++) h = h * 31 + b[i];
     return h;
+}
+
+// a subclass of the extractor, as a user of the reference class could write one: it reaches the protected stages
+struct OpenExtractor : lzb_vio::ORBextractor {
+    using lzb_vio::ORBextractor::ORBextractor;
+    using lzb_vio::ORBextractor::ComputePyramid;
+    using lzb_vio::ORBextractor::ComputeKeyPointsOctTree;
+    using lzb_vio::ORBextractor::ComputeKeyPointsOld;
+    using lzb_vio::ORBextractor::DistributeOctTree;
+    using lzb_vio::ORBextractor::pattern;
+    using lzb_vio::ORBextractor::umax;
+};
+
+// host_selftest --quadtree keys.txt minX maxX minY maxY N : DistributeOctTree (host code, no GPU) on "x y response" lines
+static int quadtree_mode(int argc, char **argv)
+{
+    if (argc < 8) return 2;
+    FILE *f = fopen(argv[2], "r");
+    if (!f) return 3;
+    std::vector<cv::KeyPoint> keys;
+    float x, y, r;
+    while (fscanf(f, "%f %f %f", &x, &y, &r) == 3) {
+        cv::KeyPoint k;
+        k.pt.x = x; k.pt.y = y; k.response = r; k.class_id = (int)keys.size();      // class_id carries the input index
+        keys.push_back(k);
+    }
+    fclose(f);
+    OpenExtractor ex(2000, 1.2f, 8, 20, 7);
+    printf("pattern=%zu first=%d,%d last=%d,%d umax0=%d umax15=%d\n", ex.pattern.size(), ex.pattern[0].x, ex.pattern[0].y,
+           ex.pattern[511].x, ex.pattern[511].y, ex.umax[0], ex.umax[15]);
+    const std::vector<cv::KeyPoint> out = ex.DistributeOctTree(keys, atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), 0);
+    printf("selected %zu:", out.size());
+    for (const auto &k : out) printf(" %d", k.class_id);
+    printf("\n");
+    return 0;
 }
 
 static int orb_mode(int argc, char **argv)
@@ -46,6 +82,36 @@ static int orb_mode(int argc, char **argv)
         unsigned long long h = 0;
         for (int y = 0; y < m.rows; y++) h = hash_bytes(m.ptr(y), (size_t)m.cols, h);
         printf("pyramid%zu rows=%d cols=%d hash=%llu\n", l, m.rows, m.cols, h);
+    }
+    // the protected stages through a subclass: ComputePyramid + ComputeKeyPointsOctTree on the LEFT image give its keypoints
+    // per level in level coordinates; scaled back they are operator()'s keypoints bit for bit
+    {
+        OpenExtractor ox(p.nFeatures_, p.fScaleFactor_, p.nLevels_, p.fIniThFAST_, p.fMinThFAST_);
+        cv::Mat img;
+        if (!lzb_vio::ReadImageGray(argv[3], img)) return 4;
+        std::vector<std::vector<cv::KeyPoint>> all, old;
+        ox.ComputePyramid(img);
+        ox.ComputeKeyPointsOctTree(all);
+        ox.ComputeKeyPointsOld(old);
+        std::vector<cv::KeyPoint> ref;
+        cv::Mat d;
+        ox(img, cv::Mat(), ref, d);
+        size_t at = 0;
+        bool same = old.size() == all.size();
+        printf("octree levels=%zu counts", all.size());
+        for (size_t l = 0; l < all.size(); l++) {
+            printf(" %zu", all[l].size());
+            const float sc = ox.GetScaleFactors()[l];
+            for (const cv::KeyPoint &k : all[l]) {
+                const bool integral = k.pt.x == std::floor(k.pt.x) && k.pt.y == std::floor(k.pt.y);
+                const float bx = l ? k.pt.x * sc : k.pt.x, by = l ? k.pt.y * sc : k.pt.y;
+                same = same && at < ref.size() && integral && k.octave == (int)l && bx == ref[at].pt.x && by == ref[at].pt.y &&
+                       k.angle == ref[at].angle && k.response == ref[at].response && k.size == ref[at].size;
+                at++;
+            }
+        }
+        printf(" total=%zu of %zu same=%d pyramid0=%dx%d\n", at, ref.size(), (int)(same && at == ref.size()),
+               ox.mvImagePyramid[0].cols, ox.mvImagePyramid[0].rows);
     }
     // an empty image returns an empty set (src/ORBextractor.cpp:994-995)
     std::vector<cv::KeyPoint> none;
@@ -97,6 +163,7 @@ int main(int argc, char **argv)
     if (argc < 2) return 2;
     if (std::string(argv[1]) == "--track") return track_mode(argc, argv);
     if (std::string(argv[1]) == "--orb") return orb_mode(argc, argv);
+    if (std::string(argv[1]) == "--quadtree") return quadtree_mode(argc, argv);
     if (!lzb_vio::Config::SetParameterFile(argv[1])) return 3;
     lzb_vio::Parameter p;
     printf("track_mode=%s\n", p.track_mode_.c_str());

@@ -188,6 +188,28 @@ def test_png_reader_checks_the_stream_end(host_built, tmp_path):
     assert "image2 ok=0" in out and "image3 ok=0" in out and "image4 ok=0" in out
 
 
+@pytest.mark.parametrize("n,n_features,w,h,seed", [(3000, 500, 1209, 344, 1), (700, 2000, 600, 300, 2), (5000, 60, 200, 190, 3),
+                                                    (40, 100, 90, 400, 4), (1, 10, 300, 100, 5)])
+def test_distribute_octtree_host_matches_oracle(host_built, oracle, tmp_path, n, n_features, w, h, seed):
+    """lzb_vio::ORBextractor::DistributeOctTree (protected in the reference, include/lzb_vio/ORBextractor.h:79-80; host
+    code, no GPU) through a subclass, against the oracle's restatement of src/ORBextractor.cpp:487-715: dense sets that
+    reach the "largest node first" phase, integer responses with many ties, a set smaller than N, a tall region
+    (nIni = 0 -> nothing), a single key."""
+    rng = np.random.default_rng(seed)
+    xyr = np.stack([rng.integers(0, w, n), rng.integers(0, h, n), rng.integers(7, 60, n)], 1).astype(np.float32)
+    with open(tmp_path / "k.txt", "w") as f:
+        for x, y, r in xyr:
+            f.write(f"{x:.1f} {y:.1f} {r:.1f}\n")
+    out = subprocess.check_output([os.path.join(host_built, "host_selftest"), "--quadtree", str(tmp_path / "k.txt"),
+                                   "16", str(16 + w), "16", str(16 + h), str(n_features)], stderr=subprocess.DEVNULL).decode().splitlines()
+    assert out[0] == "pattern=512 first=8,-3 last=0,-11 umax0=15 umax15=3"          # src/ORBextractor.cpp:101, :356 (second point), umax table
+    want = oracle.orb_distribute(xyr, 16, 16 + w, 16, 16 + h, n_features)
+    got = [int(v) for v in out[1].split(":")[1].split()]
+    assert got == want.tolist() and out[1].startswith(f"selected {len(want)}:")
+    if n >= 700:
+        assert len(want) >= min(n_features, 50)
+
+
 def test_usage_error_returns_nonzero(host_built):
     r = subprocess.run([os.path.join(host_built, "run_kitti_stereo")], stderr=subprocess.DEVNULL)
     assert r.returncode == 2
@@ -350,7 +372,13 @@ def test_orbextractor_class_matches_oracle(host_built, oracle, small_seq, tmp_pa
         lvl = oracle.orb_pyramid_level(R, l)                    # the RIGHT image's pyramid
         kv = dict(x.split("=") for x in lines[3 + l].split()[1:])
         assert (int(kv["rows"]), int(kv["cols"])) == lvl.shape and int(kv["hash"]) == bhash(lvl.tobytes())
-    assert lines[11] == "empty n=0 rows=0"
+    # the protected stages through a subclass (ComputePyramid + ComputeKeyPointsOctTree / ...Old on the LEFT image):
+    # per-level counts of the oracle, level coordinates integral, scaled back == operator()'s keypoints bit for bit
+    kpL, _, per = oracle.orb_extract(L)
+    oct_ = lines[11].split()
+    assert oct_[0] == "octree" and oct_[1] == "levels=8" and [int(v) for v in oct_[3:11]] == per.tolist()
+    assert oct_[11] == f"total={len(kpL)}" and oct_[13] == str(len(kpL)) and oct_[14] == "same=1" and oct_[15] == f"pyramid0={w}x{h}"
+    assert lines[12] == "empty n=0 rows=0"
 
 
 def test_image_readers_survive_corrupted_files(host_built, tmp_path):
