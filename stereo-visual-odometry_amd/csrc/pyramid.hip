@@ -47,53 +47,66 @@ __global__ __launch_bounds__(256) void pyr_copy0_kernel(PyrArgs a)
 // frame of level l: every padded position outside the interior copies its reflect-101 source.
 // Workgroup g < 2*kPad handles one full top/bottom frame row; the others handle four interior
 // rows each (64 lanes = the 2 x 32 side bytes of a row), so no workgroup is launched for nothing.
-constexpr int kBorderRows = 16;              // interior rows whose side bytes one workgroup writes
+constexpr int kBorderRows = 16;              // interior rows whose side bytes one pass of a workgroup writes
+// A workgroup takes kFrameRowsPerWg full frame rows or kSidePasses x 16 interior rows: with one row / 16 rows per
+// workgroup the launch was 45 k tiny workgroups per level and bound by their dispatch (58 us for 80 MB of frames)
+constexpr int kFrameRowsPerWg = 4, kSidePasses = 4;
+__host__ __device__ inline int border_top_groups() { return 2 * kPad / kFrameRowsPerWg; }
+__host__ __device__ inline int border_side_groups(int h) { return (h + kBorderRows * kSidePasses - 1) / (kBorderRows * kSidePasses); }
 __global__ __launch_bounds__(256) void pyr_border_kernel(PyrArgs a, int l)
 {
     const int b = blockIdx.y;
     const int w = a.g.w[l], h = a.g.h[l], pitch = a.g.pitch[l];
     uint8_t *lvl = a.slots + (int64_t)b * a.slot_stride + a.g.origin[l];
-    const int gidx = blockIdx.x;
-    if (gidx < 2 * kPad) {
-        // a full frame row, four bytes per thread (the padded row starts 4-byte aligned)
-        const int py = gidx < kPad ? gidx - kPad : h + (gidx - kPad);
-        const uint8_t *src = lvl + (int64_t)refl101(py, h) * pitch;
-        uint8_t *dst = lvl + (int64_t)py * pitch;
-        for (int px = ((int)threadIdx.x << 2) - kPad; px < w + kPad; px += 1024) {
-            uint32_t v = 0;
-            if (px >= 0 && px + 4 <= w) v = *(const uint32_t *)(src + px);     // above / below the interior: an aligned dword of the mirrored row
-            else {
+    if ((int)blockIdx.x < border_top_groups()) {
+        // full frame rows, four bytes per thread (the padded row starts 4-byte aligned)
+        for (int q = 0; q < kFrameRowsPerWg; q++) {
+            const int gidx = blockIdx.x * kFrameRowsPerWg + q;
+            const int py = gidx < kPad ? gidx - kPad : h + (gidx - kPad);
+            const uint8_t *src = lvl + (int64_t)refl101(py, h) * pitch;
+            uint8_t *dst = lvl + (int64_t)py * pitch;
+            for (int px = ((int)threadIdx.x << 2) - kPad; px < w + kPad; px += 1024) {
+                uint32_t v = 0;
+                if (px >= 0 && px + 4 <= w) v = *(const uint32_t *)(src + px);     // above / below the interior: an aligned dword of the mirrored row
+                else {
 #pragma unroll
-                for (int q = 0; q < 4; q++) v |= (uint32_t)src[refl101(min(px + q, w + kPad - 1), w)] << (8 * q);
+                    for (int k = 0; k < 4; k++) v |= (uint32_t)src[refl101(min(px + k, w + kPad - 1), w)] << (8 * k);
+                }
+                if (px + 4 <= w + kPad) *(uint32_t *)(dst + px) = v;
+                else for (int k = 0; px + k < w + kPad; k++) dst[px + k] = (uint8_t)(v >> (8 * k));
             }
-            if (px + 4 <= w + kPad) *(uint32_t *)(dst + px) = v;
-            else for (int q = 0; px + q < w + kPad; q++) dst[px + q] = (uint8_t)(v >> (8 * q));
         }
-    } else if (w >= 2 * kPad) {
-        // the 2 x 32 side bytes of sixteen interior rows, a DWORD per thread (sixteen per row: 64 one-byte loads and
+        return;
+    }
+    const int sgroup = blockIdx.x - border_top_groups();
+    if (w >= 2 * kPad) {
+        // the 2 x 32 side bytes of sixteen interior rows per pass, a DWORD per thread (sixteen per row: 64 one-byte loads and
         // stores per row made this launch four times slower than its bytes): the four frame bytes px .. px + 3 are the
         // interior bytes at the mirrored columns in reverse order -- one unaligned load, one byte swap, one store
         static_assert(kBorderRows == 16 && kPad == 32, "256 threads = 16 rows x 16 dwords");
         typedef uint32_t u32_unaligned __attribute__((aligned(1)));
         const int k = threadIdx.x & 15, r = threadIdx.x >> 4;
-        const int py = (gidx - 2 * kPad) * kBorderRows + r;
-        if (py >= h) return;
-        uint8_t *row = lvl + (int64_t)py * pitch;
         // left: px = -32 + 4 k mirrors columns 32 - 4 k .. 29 - 4 k; right: px = w + 4 (k - 8) mirrors w - 2 - 4 (k - 8) .. - 3
         const int px = k < 8 ? -kPad + 4 * k : w + 4 * (k - 8);
         const int c0 = k < 8 ? kPad - 3 - 4 * k : w - 5 - 4 * (k - 8);
-        const uint32_t v = *(const u32_unaligned *)(row + c0);
-        *(u32_unaligned *)(row + px) = __builtin_amdgcn_perm(0u, v, 0x00010203u);
+        for (int q = 0; q < kSidePasses; q++) {
+            const int py = (sgroup * kSidePasses + q) * kBorderRows + r;
+            if (py >= h) return;
+            uint8_t *row = lvl + (int64_t)py * pitch;
+            const uint32_t v = *(const u32_unaligned *)(row + c0);
+            *(u32_unaligned *)(row + px) = __builtin_amdgcn_perm(0u, v, 0x00010203u);
+        }
     } else {
         const int t = threadIdx.x & 63;
         const int px = t < kPad ? t - kPad : w + (t - kPad);
         const int sx = refl101(px, w);
-        for (int r = threadIdx.x >> 6; r < kBorderRows; r += 4) {
-            const int py = (gidx - 2 * kPad) * kBorderRows + r;
-            if (py >= h) return;
-            uint8_t *row = lvl + (int64_t)py * pitch;
-            row[px] = row[sx];
-        }
+        for (int q = 0; q < kSidePasses; q++)
+            for (int r = threadIdx.x >> 6; r < kBorderRows; r += 4) {
+                const int py = (sgroup * kSidePasses + q) * kBorderRows + r;
+                if (py >= h) return;
+                uint8_t *row = lvl + (int64_t)py * pitch;
+                row[px] = row[sx];
+            }
     }
 }
 
@@ -167,7 +180,7 @@ void launch_pyramid(const PyrArgs &a, int batch, hipStream_t st)
             shape((a.g.w[l] + 3) / 4, a.g.h[l], g, bk, batch);
             hipLaunchKernelGGL(pyr_down_kernel, g, bk, 0, st, a, l);
         }
-        dim3 gb(2 * kPad + (a.g.h[l] + kBorderRows - 1) / kBorderRows, batch, 1);
+        dim3 gb(border_top_groups() + border_side_groups(a.g.h[l]), batch, 1);
         hipLaunchKernelGGL(pyr_border_kernel, gb, blk, 0, st, a, l);
     }
 }
