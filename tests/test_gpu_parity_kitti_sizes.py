@@ -44,6 +44,18 @@ def test_lk_eight_pairs_at_kitti_03_and_04_sizes(pkg, oracle, tc, synth, mg, whi
     _check_online(pkg, seq, frames, ref)
 
 
+def test_lk_sse2_mode_at_kitti_04_size(pkg, oracle, tc, synth, mg):
+    """The x86-order LK mode on a frame size whose pyramid levels are all odd-sized (1226x370 -> 613x185 -> 307x93 -> 154x47)."""
+    seq, frames = _render_rig(synth, tc, mg.KITTI_RIG_C, 4, 371)
+    old = oracle.set_lk_accum(oracle.LK_ACCUM_FLOAT_SSE)
+    try:
+        ref = _oracle_lk_sequence(oracle, seq, frames)
+    finally:
+        oracle.set_lk_accum(old)
+    _check_batch(pkg, tc, seq, frames, ref, lk_accum=pkg.LK_ACCUM_SSE2)
+    _check_online(pkg, seq, frames, ref, lk_accum=pkg.LK_ACCUM_SSE2)
+
+
 @pytest.mark.parametrize("which", ["B", "C"])
 def test_orb_eight_pairs_at_kitti_03_and_04_sizes(pkg, oracle, tc, synth, mg, which):
     rig = {"B": mg.KITTI_RIG_B, "C": mg.KITTI_RIG_C}[which]

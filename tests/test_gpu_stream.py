@@ -64,6 +64,46 @@ def test_frame_stream_equals_the_per_frame_loop(pkg, frames11, depth, mode):
         assert (p // depth + 1) * depth <= t <= (p // depth + 3) * depth, (p, t)
 
 
+def test_frame_stream_with_failing_pairs_and_polling(pkg, frames11):
+    """A blank frame in the stream: the two pairs that touch it fail (few keypoints / few tracks), the pose chain skips
+    them exactly as the per-frame loop does; svo_results_ready says 0 with nothing in flight and the pair count once a
+    micro-batch is complete."""
+    import time
+    stream = importlib.import_module(conftest.entry.PKG_NAME + ".stream")
+    seq, frames = frames11
+    frames = list(frames[:9])
+    blank = np.full_like(frames[0][0], 128)
+    frames[4] = (blank, blank)
+    want = _online(pkg, seq, frames)
+    assert [int(w["ok"]) for w in want] == [1, 1, 1, 0, 0, 1, 1, 1]
+    P1, P2 = seq.proj()
+    c = pkg.Context(416, 128, device=0, P1=P1, P2=P2, max_batch=3)
+    c.set_overlap(True)
+    assert c.results_ready() == 0
+    fs = stream.FrameStream(c, 3)
+    got = []
+    for fr in frames[:4]:
+        for chunk in fs.push(*fr):
+            got.extend(chunk)
+    for _ in range(2000):                                     # the first micro-batch (3 pairs) is in flight: wait for it by polling
+        if c.results_ready():
+            break
+        time.sleep(0.001)
+    assert c.results_ready() == 3
+    for fr in frames[4:]:
+        for chunk in fs.push(*fr):
+            got.extend(chunk)
+    for chunk in fs.flush():
+        got.extend(chunk)
+    assert c.results_ready() == 0
+    fs.close()
+    c.close()
+    assert len(got) == len(want) == 8
+    for g, w in zip(got, want):
+        assert int(g["ok"]) == int(w["ok"]) and int(g["fail_stage"]) == int(w["fail_stage"])
+        assert g["pose"].tobytes() == w["pose"].tobytes() and g["T_rel_inv"].tobytes() == w["T_rel_inv"].tobytes()
+
+
 def test_run_kitti_stereo_stream_depth(pkg, frames11, tmp_path):
     """YAML `stream_depth: k`: System::Run feeds Step_ros, which queues the frames (StreamPush) and writes the poses as
     they complete -- the pose file equals the per-frame loop's byte for byte, in both modes."""
