@@ -143,6 +143,12 @@ static int16_t *scharr_deriv(const uint8_t *lvl, int w, int h, int pad, int pitc
     return d;
 }
 
+/* Iteration log (tools only: the wave-grouping cost models of DESIGN.md section 6): when set, the number of
+ * iterations every (point, level) ran is written to log[point * ORC_LK_MAX_LEVELS + level] (-1: level skipped). */
+static int32_t *g_iter_log = NULL;
+static _Thread_local int g_iter_pt = 0;
+void orc_lk_set_iter_log(int32_t *log) { g_iter_log = log; }
+
 static int g_lk_accum = 0;      /* 0 exact int64 (CANONICAL), 1 float raster order, 2 float SSE2 lane order */
 void orc_lk_set_accum(int mode) { g_lk_accum = (mode == 1 || mode == 2) ? mode : 0; }
 int orc_lk_get_accum(void) { return g_lk_accum; }
@@ -308,6 +314,7 @@ static void lk_point_level(const uint8_t *I, int pitchI, const int16_t *dI, int 
         }
         pdx = dlx; pdy = dly;
     }
+    if (g_iter_log) g_iter_log[(size_t)g_iter_pt * ORC_LK_MAX_LEVELS + level] = j < max_iter ? j + 1 : max_iter;
 
     /* err is requested by the reference (error1..4) and flags has no GET_MIN_EIGENVALS: the
      * level-0 post-pass can still clear status when the final window is out of bounds
@@ -350,6 +357,8 @@ int orc_lk_track(const orc_pyramid *prev, const orc_pyramid *next, const orc_pt2
         for (i = 0; i < n; i++) {
             status[i] = 1;
             next_pts[i].x = 0.f; next_pts[i].y = 0.f;
+            g_iter_pt = i;
+            if (g_iter_log) for (lv = 0; lv < ORC_LK_MAX_LEVELS; lv++) g_iter_log[(size_t)i * ORC_LK_MAX_LEVELS + lv] = -1;
             for (lv = max_level; lv >= 0; lv--) {
                 int dp = (prev->w[lv] + 2 * pad) * 2;
                 lk_point_level(prev->data[lv] + (size_t)pad * prev->pitch[lv] + pad,

@@ -65,6 +65,7 @@ void orc_pyr_down(const uint8_t *src, int w, int h, int spitch, uint8_t *dst, in
  * float accumulation in raster order, 2 = in the lane order of upstream's SSE2 block.  Process-wide. */
 void orc_lk_set_accum(int mode);
 int orc_lk_get_accum(void);
+void orc_lk_set_iter_log(int32_t *log);      /* tools only: iterations per (point, level) of the next orc_lk_track calls */
 int orc_lk_track(const orc_pyramid *prev, const orc_pyramid *next,
                  const orc_pt2f *prev_pts, int n, orc_pt2f *next_pts, uint8_t *status,
                  int win, int max_iter, double eps, float min_eig, int threads);

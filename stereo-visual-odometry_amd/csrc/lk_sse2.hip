@@ -2,7 +2,7 @@
 // FLOAT, in the order of upstream's x86 build (svo_config.lk_accum = SVO_LK_ACCUM_SSE2).
 //
 // Why: the reference's four cv::calcOpticalFlowPyrLK calls (src/tracking.cpp:593-618) run an OpenCV 3 whose
-// accumulators are float (acctype = itemtype = float outside the Tegra build) and whose CV_SSE2 block fixes the
+// accumulators are float (acctype = itemtype = float outside the Tegra build) and whose SIMD block fixes the
 // order of the additions: oracle/lk.c restates that order (orc_lk_set_accum(2)), and lk.hip's exact integer sums
 // (canonical choice C0) differ from it in the last bits of 12 % of the track coordinates --
 // enough to move RANSAC's inlier set on one pair in seven.  This kernel reproduces the x86 order bit for bit:
@@ -16,50 +16,73 @@
 // A float sum in a fixed order is a SERIAL chain: it cannot be reduced over the lanes.  What can be shared is the
 // instruction stream: the wave still tracks four points ("slots", lk.hip), the 63 pixel lanes of a slot produce the
 // TERMS in parallel (exact int32 products / pair sums, converted once), write them to LDS in chain order, and then
-// every chain of all four slots runs in its own lane -- 4 x (8 + 2) chains for b, 4 x (12 + 3) for A -- through ONE
-// loop of 105 dependent v_add_f32 fed by ds_read_b128.  Pixel ownership follows the SSE groups: lane (row, seg)
-// owns window row `row`, columns 8 seg .. 8 seg + 7 (seg 2: the five tail columns 16..20), so a madd pair (k, k + 4)
-// is ONE v_dot2_i32_i16 of packed (diff_k, diff_k+4) x (Ix_k, Ix_k+4) inside a lane.
+// every chain of all four slots runs in its own lane through ONE loop of 105 dependent v_add_f32.
+//
+// Round 5 layout (the round-4 kernel was bound by the LDS pipeline: 60 % busy, 40 % of it bank conflicts, and by a
+// dependent add chain that one-and-three-quarter waves per SIMD cannot hide):
+//   * pixel lanes in CHAIN ORDER: lanes 0..41 = (window row lane >> 1, SSE group lane & 1: columns 8 g .. 8 g + 7),
+//     lanes 42..62 = the tail lanes (row lane - 42, columns 16..20).  A group lane's term t = lane of every lane
+//     chain: its stores are 42 consecutive dwords, and with a column stride of 26 words the tile reads of lanes
+//     0..31 fall on 32 different banks (16 g + row); the other half is 2-way on ten banks (three accesses to a bank
+//     are forced by the 8 + 8 + 5 split);
+//   * chain lanes: row s of 16 lanes = slot s; position 0 / 8 run the x / y tail, 1..4 and 9..12 the eight lane
+//     chains.  Phase 1 (terms 0..43): every chain lane reads its own terms (11 ds_read_b128).  Phase 2 (terms
+//     44..104: tails only): the EIGHT lanes of a half row each fetch four terms of their tail per read and the
+//     tail lane adds them through the DPP network (v_add_f32 row_shl:f) -- two reads instead of sixteen: 13
+//     wide reads per wave-iteration instead of 27, every one of them conflict-free;
+//   * A: five lanes per slot (four SSE lanes + the tail), each carrying A11, A12, A22 at once: two SDWA
+//     conversions, one v_pk_fma_f32 and one v_fma_f32 per term (a product of two patch values is < 2^24, exact
+//     in float, so the fused form rounds exactly as _mm_mul_ps + _mm_add_ps do), three independent chains a lane;
+//   * tiles: 26 columns x 26 words (margin 2 around the J window): 20 176 B of LDS per wave, EIGHT waves per CU --
+//     two per SIMD, so a dependent chain of one wave issues beside the other's.
 // Everything else -- tiles as row-pair column words, packed Scharr on the fly, weights, control flow, the circular
 // chain of four calls, the keep predicate -- is lk.hip's, and so are the fixed-point pixel values (integers: exact).
-//
-// One wave per workgroup (no barrier anywhere): 22 KB of LDS per wave (13 KB tiles + 9 KB chain staging), seven
-// waves per CU.  Costs about twice the exact kernel per iteration.
 #include "lk_common.h"
 
 namespace svo {
 
-// b staging of one slot (dwords): 8 lane chains S[c][t], c = 2 k + (x|y), t = 2 row + group (42 terms, stride 44),
-// then 2 tail chains T[x|y][t], t = 5 row + i (105 terms, stride 108).  The A staging (per level, before the
-// iterations) reuses the area: patch words (Ix | Iy << 16) W[q][t], t = 5 row + (x >> 2) (105 words, stride 108),
-// then the 21 tail words (x = 20).
-constexpr int kSStride = 44, kTStride = 108, kTBase = 8 * kSStride, kStageDw = kTBase + 2 * kTStride;   // 568
-constexpr int kAqStride = 108, kAtBase = 4 * kAqStride;                                                 // 432 + 21 <= 568
-constexpr int kLdsDwSse2 = kLdsDwPerWave + kSlots * kStageDw;                                           // 5520 dwords
-constexpr int kDumpB = 43, kDumpA = 105;     // entries no chain adds: padding of S chain 0 / of every W[q]
-static_assert(kStageDw % 4 == 0 && kSStride % 4 == 0 && kTStride % 4 == 0 && kTBase % 4 == 0 && kLdsDwPerWave % 4 == 0,
+// ---- LDS plan of one wave (dwords) ----------------------------------------------------------------------------
+// tiles: four slots x 26 columns x 26 words, column-major (I: 23 row pairs x 24 columns from image column ipx - 1 --
+// fetched unaligned, so no alignment slack --, J: 25 pairs x 26 columns = window + margin 2 on every side);
+// a staged source dword carries four columns, so the seventh dword of a row spills two columns past the tile: into
+// the next slot's first two columns (which that slot's own stores, issued later, overwrite) or, behind slot 3, into
+// the pad.  A re-stage of one slot during the iterations masks those two stores instead (tile_store_j2<true>).
+constexpr int kCS2 = 26, kJMargin2 = 2;
+constexpr int kQPairs2 = 23, kJPairs2 = kWin + 2 * kJMargin2;                       // 23, 25 (<= kCS2)
+constexpr int kTileDw2 = 26 * kCS2, kTilePadDw = 2 * kCS2;                         // 676, 52
+constexpr int kTilesDw = kSlots * kTileDw2 + kTilePadDw;                           // 2756
+// chain staging of one slot.  b (per iteration): lane chain c = 2 k + (x|y) at c * 44 (42 terms + 2 the chain reads
+// but does not use), tail x at 356, tail y at 464 (105 terms, 108 read).  The offsets put the five 16-byte reads of
+// a half row (tail + four lane chains) on five different bank quads.  A (per level, same area): patch words
+// Ix | Iy << 16 of SSE lane q at q * 108, term 5 row + (x >> 2); the tail's 21 words (x = 20) at 432.
+constexpr int kSStride = 44, kTailX = 8 * kSStride + 4, kTStride = 108, kTailY = kTailX + kTStride, kStageDw = kTailY + kTStride;   // 572
+constexpr int kAqStride = 108, kAtBase = 4 * kAqStride;
+constexpr int kLdsDwSse2 = kTilesDw + kSlots * kStageDw;                           // 5044 dwords = 20 176 B
+constexpr int kDumpB = 43, kDumpA = 105;     // entries no chain uses: padding of lane chain 0 / of W[0]
+static_assert(kStageDw % 4 == 0 && kSStride % 4 == 0 && kTailX % 4 == 0 && kTailY % 4 == 0 && kTilesDw % 4 == 0 && kAqStride % 4 == 0,
               "chain reads are 16-byte loads");
+static_assert(kAtBase + 24 <= kStageDw && kJPairs2 <= kCS2 && kQPairs2 <= kCS2, "staging / tile geometry");
+static_assert(kLdsDwSse2 * 4 <= 20480, "eight single-wave workgroups per CU");
 
 typedef uint32_t __attribute__((address_space(3))) lds_u32;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const f32x4 __attribute__((address_space(3))) lds_cf32x4;
 typedef const u32x4 __attribute__((address_space(3))) lds_cu32x4;
 
-// per-lane constants: the pixel role (row, seg) and the chain role (c = lane & 15 of row `slot`)
+// per-lane constants: the pixel role and the chain role (position lane & 15 of row `slot`)
 struct Sse2Lane {
-    int row, seg;
+    int row, x0;            // window row, first window column (0, 8: the SSE groups; 16: the tail)
     uint32_t onmask;        // all ones in the 63 pixel lanes
-    uint32_t pmask;         // mask of the patch pairs m = 1..3: seg 2 owns pixels 0..4 only (high halves = pixels 5..7 vanish)
-    bool seg2;
-    uint32_t qoff;          // byte offset of the lane's first I-tile word inside a slot tile
-    uint32_t joff;          // ... of its first J-tile word
+    uint32_t pmask;         // mask of the patch pairs m = 1..3: a tail lane owns pixels 0..4 only (high halves = pixels 5..7 vanish)
+    bool tail;
+    uint32_t qoff;          // byte offset of the lane's first tile word inside a slot tile (I and J tiles share the layout)
     uint32_t wb[10];        // b term j of slot 0 goes to LDS byte address wb[j]
     uint32_t wa_lo, wa_hi[4];   // patch word i < 4 goes to wa_lo + (i * kAqStride) * 4, word 4 + i to wa_hi[i]
-    uint32_t cb, ca;        // chain read addresses (b, A) of this lane's chain, the lane's slot included
-    uint32_t cb2, ca2;      // ... past the part every chain has (b: term 44, A: word 24): own chain or the idle lanes' common address
-    uint32_t selA;          // v_perm selector that puts the two factors of this lane's A sum side by side
-    bool b_tail, a_tail;    // lane c of a row runs a tail chain (b: c = 8, 9; A: c = 12..14)
+    uint32_t cb, cbA, cbB;  // b chain reads: own terms 0..43; the half row's tail terms 44 + 4 f.., 76 + 4 f.. (f = lane & 7)
+    uint32_t ca;            // A chain read address
+    bool b_tail, a_tail;    // position 0 / 8 runs a b tail; position 4 the A tail
 };
 
 __device__ __forceinline__ void lds_store(uint32_t byte_addr, uint32_t v) { *(lds_u32 *)(size_t)byte_addr = v; }
@@ -67,70 +90,106 @@ __device__ __forceinline__ void lds_store(uint32_t byte_addr, uint32_t v) { *(ld
 __device__ __forceinline__ Sse2Lane make_lane(int lane, uint32_t lds_base)
 {
     Sse2Lane L;
-    L.row = min(lane / 3, kWin - 1); L.seg = lane - (lane / 3) * 3;
-    const bool on = lane < 63;
+    const bool group = lane < 42, on = lane < 63;
+    L.tail = on && !group;
+    L.row = group ? lane >> 1 : (L.tail ? lane - 42 : kWin - 1);
+    L.x0 = group ? 8 * (lane & 1) : 16;
     L.onmask = on ? ~0u : 0u;
-    L.seg2 = L.seg == 2;
-    L.pmask = L.seg2 ? 0x0000FFFFu : ~0u;
-    L.qoff = (uint32_t)((L.seg * 8 * kQColDw + L.row) * 4);
-    L.joff = (uint32_t)((L.seg * 8 * kJColDw + L.row) * 4);
-    const uint32_t stage0 = lds_base + kLdsDwPerWave * 4;
+    L.pmask = group ? ~0u : 0x0000FFFFu;
+    L.qoff = (uint32_t)((L.x0 * kCS2 + L.row) * 4);
+    const uint32_t stage0 = lds_base + kTilesDw * 4;
 #pragma unroll
     for (int j = 0; j < 10; j++) {
         int e = kDumpB;
-        if (on && !L.seg2 && j < 8) e = j * kSStride + 2 * L.row + L.seg;
-        if (on && L.seg2) e = kTBase + (j & 1) * kTStride + 5 * L.row + (j >> 1);
+        if (group && j < 8) e = j * kSStride + lane;                                   // lane chain j, term t = lane
+        if (L.tail) e = ((j & 1) ? kTailY : kTailX) + 5 * L.row + (j >> 1);             // tail x | y, term 5 row + i
         L.wb[j] = stage0 + (uint32_t)e * 4;
     }
-    // patch words: pixel i (x = 8 seg + i) -> W[x & 3][5 row + (x >> 2)];  x = 20 -> tail word `row`;  x > 20: nowhere
-    L.wa_lo = stage0 + (uint32_t)(on ? 5 * L.row + 2 * L.seg : kDumpA) * 4;
+    // patch words: pixel i (x = x0 + i) -> W[x & 3][5 row + (x >> 2)];  x = 20 -> tail word `row`;  x > 20: nowhere
+    L.wa_lo = stage0 + (uint32_t)(on ? 5 * L.row + (L.x0 >> 2) : kDumpA) * 4;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         int e = kDumpA;
-        if (on && !L.seg2) e = i * kAqStride + 5 * L.row + 2 * L.seg + 1;
-        if (on && L.seg2 && i == 0) e = kAtBase + L.row;
+        if (group) e = i * kAqStride + 5 * L.row + (L.x0 >> 2) + 1;
+        if (L.tail && i == 0) e = kAtBase + L.row;
         L.wa_hi[i] = stage0 + (uint32_t)e * 4;
     }
-    const int c = lane & 15;
+    const int p = lane & 15, f = p & 7;
     const uint32_t stage_s = stage0 + (uint32_t)((lane >> 4) * kStageDw) * 4;
-    L.b_tail = c == 8 || c == 9;
-    L.cb = c < 8 ? stage_s + (uint32_t)(c * kSStride) * 4 : (L.b_tail ? stage_s + (uint32_t)(kTBase + (c - 8) * kTStride) * 4 : stage0);
-    L.cb2 = L.b_tail ? L.cb : stage0;
-    L.a_tail = c >= 12;
-    L.ca = c < 12 ? stage_s + (uint32_t)((c & 3) * kAqStride) * 4 : (c < 15 ? stage_s + (uint32_t)kAtBase * 4 : stage0);
-    L.ca2 = c < 12 ? L.ca : stage0;
-    const int type = c < 12 ? c >> 2 : (c - 12) % 3;          // 0: Ix Ix, 1: Ix Iy, 2: Iy Iy
-    L.selA = type == 0 ? 0x01000100u : (type == 1 ? 0x03020100u : 0x03020302u);
+    const int tail_dw = (p & 8) ? kTailY : kTailX;
+    L.b_tail = f == 0;
+    // positions 1..4: lane chains 0, 4, 2, 6 (the x sums); 9..12: chains 1, 5, 3, 7 (the y sums); the idle positions read
+    // what their half row's tail lane reads (one broadcast access)
+    const int cmap = ((f - 1) & 1) * 4 + ((f - 1) >> 1) * 2 + (p >> 3);
+    L.cb = stage_s + (uint32_t)((f >= 1 && f <= 4) ? cmap * kSStride : tail_dw) * 4;
+    L.cbA = stage_s + (uint32_t)(tail_dw + 44 + 4 * f) * 4;
+    L.cbB = L.cbA + 32 * 4;
+    L.a_tail = p == 4;
+    L.ca = stage_s + (uint32_t)(p < 4 ? p * kAqStride : (p == 4 ? kAtBase : 0)) * 4;
     return L;
 }
 
-// DPP inside a row of 16: the value of the lane N above (row_shl) ...
+// DPP inside a row of 16: the value of the lane N above (row_shl; lanes past the row's end read 0)
 template <int N>
 __device__ __forceinline__ float row_shl(float v)
 {
+    if (N == 0) return v;
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xF, 0xF, true));
 }
-// ... and lane Q (0..3) of the row's first quad in every lane of the row: two masked row shifts carry quad 0 to the
-// other three quads, a quad broadcast picks the lane
-template <int Q>
+// lane 0 of the row in every lane of the row: two masked row shifts carry quad 0 to the other three quads, a quad
+// broadcast picks the lane
 __device__ __forceinline__ float row_first(float v)
 {
     int x = __float_as_int(v);
     x = __builtin_amdgcn_update_dpp(x, x, 0x114, 0xF, 0x2, false);      // row_shr:4 into bank 1 (lanes 4..7)
     x = __builtin_amdgcn_update_dpp(x, x, 0x118, 0xF, 0xC, false);      // row_shr:8 into banks 2, 3 (lanes 8..15)
-    return __int_as_float(quad_bcast<Q>(x));
+    return __int_as_float(quad_bcast<0>(x));
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c)       // two fused multiply-adds in one instruction
+{
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
-// value of lane `j` of this lane's row of 16
-__device__ __forceinline__ float row_lane(float v, int lane, int j)
+// A staged source dword pair's four column words into an I tile (cf. lk.hip); the seventh dword's last two columns
+// land past the tile (see the LDS plan)
+__device__ __forceinline__ void tile_store_i2(uint32_t *tile, const uint32_t (&r)[3][2], const int (&q_dst)[3], int lane)
 {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 48) + j) * 4, __float_as_int(v)));
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        if (lane + 64 * t < kQPairs2 * 7) {
+            const uint32_t top = r[t][0], bot = r[t][1];
+            uint32_t *d = tile + q_dst[t];
+#pragma unroll
+            for (int c = 0; c < 4; c++) d[c * kCS2] = perm_b32(bot, top, 0x0c040c00u + 0x00010001u * c);
+        }
+    }
+}
+// ... into a J tile (samples as pixel << 7, lk_common.h).  MASKED: the re-stage of ONE slot beside live tiles keeps the
+// two columns past the tile away from its neighbour.
+template <bool MASKED>
+__device__ __forceinline__ void tile_store_j2(uint32_t *tile, const uint32_t (&r)[3][2], const int (&q_dst)[3], const int (&q_dc4)[3], int lane)
+{
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        if (lane + 64 * t < kJPairs2 * 7) {
+            const uint32_t top = r[t][0], bot = r[t][1];
+            uint32_t *d = tile + q_dst[t];
+            const u16x2 one = {1, 1};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (MASKED && c >= 2 && q_dc4[t] == 24) continue;
+                d[c * kCS2] = as_u32(as_u16x2(perm_b32(bot, top, 0x040c000cu + 0x01000100u * c)) >> one);
+            }
+        }
+    }
 }
 
 // ---- phase A for one slot: the lane's 8 patch pixels from the staged I tile (cf. patch_slot in lk.hip) ------------
-// Tile bytes j = 0..10 of the lane = image columns ipx - 1 + 8 seg + j.  Outputs: the patch packed as madd pairs
+// Tile bytes j = 0..10 of the lane = image columns ipx - 1 + x0 + j.  Outputs: the patch packed as madd pairs
 // (pixel m | pixel m + 4 << 16, m = 0..3) -- I with 5 fractional bits, Ix, Iy -- and the 8 patch words Ix | Iy << 16
-// of the A chains.  Pixels right of column 20 (seg 2, i > 4) are computed from whatever lies beside the tile and
+// of the A chains.  Pixels right of column 20 (tail lanes, i > 4) are computed from whatever lies beside the tile and
 // masked out of the pairs; their patch words go to a dump entry.
 template <bool EDGE>
 __device__ __forceinline__ void patch_slot8(uint32_t tile_addr, const Sse2Lane &L, uint32_t Wau, uint32_t Wbu, int ipx,
@@ -142,7 +201,7 @@ __device__ __forceinline__ void patch_slot8(uint32_t tile_addr, const Sse2Lane &
     {
         lds_cu32 *q0 = (lds_cu32 *)(size_t)(tile_addr + L.qoff);
 #pragma unroll
-        for (int j = 0; j < 11; j++) { Q01[j] = q0[j * kQColDw]; Q12[j] = q0[j * kQColDw + 1]; Q23[j] = q0[j * kQColDw + 2]; }
+        for (int j = 0; j < 11; j++) { Q01[j] = q0[j * kCS2]; Q12[j] = q0[j * kCS2 + 1]; Q23[j] = q0[j * kCS2 + 2]; }
     }
     uint32_t T0[11], T1[11];
     const u16x2 k12 = {12, 12}, k40 = {40, 40};
@@ -162,7 +221,7 @@ __device__ __forceinline__ void patch_slot8(uint32_t tile_addr, const Sse2Lane &
         const uint32_t rows = ((gyA >= 0 && gyA < h) ? 0x0000FFFFu : 0u) | ((gyB >= 0 && gyB < h) ? 0xFFFF0000u : 0u);
 #pragma unroll
         for (int c = 0; c < 9; c++) {
-            const int gx = ipx + L.seg * 8 + c;
+            const int gx = ipx + L.x0 + c;
             const uint32_t mk = (gx >= 0 && gx < w) ? rows : 0u;
             DX[c] &= mk; DY[c] &= mk;
         }
@@ -186,11 +245,11 @@ __device__ __forceinline__ void patch_slot8(uint32_t tile_addr, const Sse2Lane &
 }
 
 // ---- one iteration's pixel work for one slot: the lane's ten b terms as floats -----------------------------------
-// seg 0, 1:  v[2 k + xy] = (float)(diff_k I_k + diff_k+4 I_k+4)  -- the int32 lanes of _mm_madd_epi16, converted as
-//            _mm_cvtepi32_ps does (round to nearest even);  v[8], v[9] unused
-// seg 2:     v[2 i + xy] = (float)(diff_i I_i) for the tail pixels i = 0..3 (x = 16..19), v[8 + xy] for i = 4 (x = 20)
+// group lanes:  v[2 k + xy] = (float)(diff_k I_k + diff_k+4 I_k+4)  -- the int32 lanes of _mm_madd_epi16, converted as
+//               _mm_cvtepi32_ps does (round to nearest even);  v[8], v[9] unused
+// tail lanes:   v[2 i + xy] = (float)(diff_i I_i) for the tail pixels i = 0..3 (x = 16..19), v[8 + xy] for i = 4 (x = 20)
 __device__ __forceinline__ void mismatch_slot8(const uint32_t (&C)[9], uint32_t Wa, uint32_t Wb, const uint32_t (&IvP)[4],
-                                               const uint32_t (&IxP)[4], const uint32_t (&IyP)[4], int vround, bool seg2,
+                                               const uint32_t (&IxP)[4], const uint32_t (&IyP)[4], int vround, bool tail,
                                                float (&v)[10])
 {
     int d[8];
@@ -204,55 +263,101 @@ __device__ __forceinline__ void mismatch_slot8(const uint32_t (&C)[9], uint32_t 
         tx[m] = dot2_0(df[m], IxP[m]);
         ty[m] = dot2_0(df[m], IyP[m]);
     }
-    const uint32_t d0 = df[0] & 0xFFFFu;         // pixel 0 alone (seg 2: x = 16), pixel 4 = pair - pixel 0 (x = 20)
+    const uint32_t d0 = df[0] & 0xFFFFu;         // pixel 0 alone (tail: x = 16), pixel 4 = pair - pixel 0 (x = 20)
     const int lx = dot2_0(d0, IxP[0]), ly = dot2_0(d0, IyP[0]);
-    v[0] = (float)(seg2 ? lx : tx[0]); v[1] = (float)(seg2 ? ly : ty[0]);
+    v[0] = (float)(tail ? lx : tx[0]); v[1] = (float)(tail ? ly : ty[0]);
 #pragma unroll
     for (int m = 1; m < 4; m++) { v[2 * m] = (float)tx[m]; v[2 * m + 1] = (float)ty[m]; }
     v[8] = (float)(tx[0] - lx); v[9] = (float)(ty[0] - ly);
 }
 
 // ---- the serial sums: every chain lane adds its chain's terms in order -------------------------------------------
-// b: lanes c = 0..7 of a row run the 42-term lane chains, c = 8, 9 the 105-term tails (the other lanes add garbage)
+// b.  Phase 1: terms 0..43 of the lane's own chain (a lane chain has 42; its sum is taken before the two padding terms).
+// Phase 2: the tails' terms 44..104 -- the eight lanes of a half row hold four consecutive terms each (two reads), and the
+// tail lane at the head of the half row adds them in order over the DPP network; the other lanes add garbage.
+template <int F>
+__device__ __forceinline__ void tail_adds(float &acc, const f32x4 &q, int first_term)
+{
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+        if (first_term + 4 * F + e < 105) acc += row_shl<F>(q[e]);
+}
 __device__ __forceinline__ float chain_b(const Sse2Lane &L)
 {
-    // Straight-line code for all 64 lanes (every read is issued before the first add needs it).  The LDS pipeline is as
-    // busy as the vector unit in this kernel, so a lane that has nothing to read reads the SAME address as all the
-    // other idle lanes (one broadcast access): past term 42 only the two tail lanes of a row fetch their own data.
-    lds_cf32x4 *p = (lds_cf32x4 *)(size_t)L.cb, *p2 = (lds_cf32x4 *)(size_t)L.cb2;
+    lds_cf32x4 *p = (lds_cf32x4 *)(size_t)L.cb;
+    const f32x4 qa = *(lds_cf32x4 *)(size_t)L.cbA, qb = *(lds_cf32x4 *)(size_t)L.cbB;
     float acc = 0.f, acc42 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 27; t++) {
-        const f32x4 q = t < 11 ? p[t] : p2[t];
+    for (int t = 0; t < 11; t++) {
+        const f32x4 q = p[t];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const int idx = 4 * t + e;
-            if (idx == 42) acc42 = acc;
-            if (idx < 105) acc += q[e];
+            if (4 * t + e == 42) acc42 = acc;
+            acc += q[e];
         }
     }
+    tail_adds<0>(acc, qa, 44); tail_adds<1>(acc, qa, 44); tail_adds<2>(acc, qa, 44); tail_adds<3>(acc, qa, 44);
+    tail_adds<4>(acc, qa, 44); tail_adds<5>(acc, qa, 44); tail_adds<6>(acc, qa, 44); tail_adds<7>(acc, qa, 44);
+    tail_adds<0>(acc, qb, 76); tail_adds<1>(acc, qb, 76); tail_adds<2>(acc, qb, 76); tail_adds<3>(acc, qb, 76);
+    tail_adds<4>(acc, qb, 76); tail_adds<5>(acc, qb, 76); tail_adds<6>(acc, qb, 76); tail_adds<7>(acc, qb, 76);
     return L.b_tail ? acc : acc42;
 }
-// A: lanes c = 0..11 = (sum type c >> 2, SSE lane c & 3) 105 terms, c = 12..14 the 21-term tails.  A term is the
-// product of two 16-bit patch values: exact in float (< 2^24), so _mm_mul_ps(fx, fy) and (float)(ix * iy) coincide.
-__device__ __forceinline__ float chain_a(const Sse2Lane &L)
+// A: positions 0..3 of a row = the SSE lanes q (105 terms), position 4 = the scalar tail (21 terms); every lane carries
+// all three sums.  A term is the product of two 16-bit patch values, < 2^24: exact in float, so fma(fx, fy, acc) rounds
+// once exactly where _mm_add_ps(acc, _mm_mul_ps(fx, fy)) / iA += (float)(ix * iy) round.
+// terms first..last-1 of a block of three reads (twelve patch words Ix | Iy << 16)
+__device__ __forceinline__ void a_terms(f32x2 &d, float &m, const u32x4 (&q)[3], int first, int last)
 {
-    lds_cu32x4 *p = (lds_cu32x4 *)(size_t)L.ca, *p2 = (lds_cu32x4 *)(size_t)L.ca2;      // ca2: the tails read nothing past word 23
-    float acc = 0.f, acc21 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 27; t++) {
-        const u32x4 q = t < 6 ? p[t] : p2[t];
+    for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int idx = 4 * t + e;
-            if (idx == 21) acc21 = acc;
-            if (idx < 105) {
-                const uint32_t f = perm_b32(q[e], q[e], L.selA);
-                acc += (float)(int)(short)(f & 0xFFFFu) * (float)((int)f >> 16);
+        for (int e = 0; e < 4; e++)
+            if (4 * i + e >= first && 4 * i + e < last) {
+                const f32x2 f = {(float)(short)(q[i][e] & 0xFFFFu), (float)((int)q[i][e] >> 16)};
+                d = pk_fma(f, f, d);
+                m = __builtin_fmaf(f.x, f.y, m);
             }
-        }
+}
+__device__ __forceinline__ void chain_a(const Sse2Lane &L, float &s11, float &s12, float &s22)
+{
+    lds_cu32x4 *p = (lds_cu32x4 *)(size_t)L.ca;
+    f32x2 d = {0.f, 0.f}, d21;                  // (A11, A22)
+    float m = 0.f, m21;                         // A12
+    // Three reads (twelve terms) a block, the next block requested before this one is added.  The middle of the chain is
+    // a real loop of two blocks a turn: fully unrolled, the function crossed a size at which the register allocator gave
+    // up on the kernel (150 spilled registers, the next level's tile requests among them).
+    u32x4 q[3], n[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) q[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) n[i] = p[3 + i];
+    asm volatile("" ::: "memory");
+    a_terms(d, m, q, 0, 12);                    // terms 0..11
+#pragma unroll
+    for (int i = 0; i < 3; i++) q[i] = p[6 + i];
+    asm volatile("" ::: "memory");
+    a_terms(d, m, n, 0, 9);                     // 12..20: the tail's sums end here
+    d21 = d; m21 = m;
+    a_terms(d, m, n, 9, 12);                    // 21..23
+#pragma nounroll
+    for (int turn = 0; turn < 3; turn++, p += 6) {     // q = terms 24 + 24 turn ..; read ahead by one block
+#pragma unroll
+        for (int i = 0; i < 3; i++) n[i] = p[9 + i];
+        asm volatile("" ::: "memory");
+        a_terms(d, m, q, 0, 12);
+#pragma unroll
+        for (int i = 0; i < 3; i++) q[i] = p[12 + i];
+        asm volatile("" ::: "memory");
+        a_terms(d, m, n, 0, 12);
     }
-    return L.a_tail ? acc21 : acc;
+    a_terms(d, m, q, 0, 9);                     // 96..104
+    s11 = L.a_tail ? d21.x : d.x; s12 = L.a_tail ? m21 : m; s22 = L.a_tail ? d21.y : d.y;
+}
+// tail + (((q0 + q1) + q2) + q3) at position 0 of the row, handed to the whole row
+__device__ __forceinline__ float combine_a(float r)
+{
+    const float u = ((r + row_shl<1>(r)) + row_shl<2>(r)) + row_shl<3>(r);
+    return row_first(row_shl<4>(r) + u);
 }
 
 // One cv::calcOpticalFlowPyrLK call for the wave's four points (cf. lk_call4 in lk.hip; control values are per
@@ -264,11 +369,11 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
     const float half = 10.f;                     // (winSize - 1) * 0.5
     const float FLT_SCALE = 1.f / (1 << 20);
     uint32_t IvP[kSlots][4], IxP[kSlots][4], IyP[kSlots][4];
-    int q_pr[3], q_dc4[3], jq_dst[3];            // staging item lane + 64 t = row pair * 7 + dword column
+    int q_pr[3], q_dc4[3], q_dst[3];             // staging item lane + 64 t = row pair * 7 + dword column
 #pragma unroll
     for (int t = 0; t < 3; t++) {
         const int i = lane + 64 * t;
-        q_pr[t] = i / 7; q_dc4[t] = 4 * (i - q_pr[t] * 7); jq_dst[t] = q_dc4[t] * kJColDw + q_pr[t];
+        q_pr[t] = i / 7; q_dc4[t] = 4 * (i - q_pr[t] * 7); q_dst[t] = q_dc4[t] * kCS2 + q_pr[t];
     }
     const uint32_t lds_base = (uint32_t)(size_t)(lds_cu32 *)lds;
     int vround = 1 << (W_BITS - 5 - 1 + 7);
@@ -281,7 +386,7 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
         const float lscale = 1.f / (float)(1 << level);
         const int ipx = cv_floor(prevPt.x * lscale - half), ipy = cv_floor(prevPt.y * lscale - half);
         const unsigned long long m = __ballot(live && !window_oob(ipx, ipy, w, h));
-        const int x0 = (ipx - 1) & ~3;
+        const int x0 = ipx - 1;                  // unaligned, like the J tiles: the patch needs exactly 24 columns from here
         uint32_t src[3];
 #pragma unroll
         for (int t = 0; t < 3; t++) src[t] = (uint32_t)(q_pr[t] * pitch + q_dc4[t]);
@@ -289,7 +394,7 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
         for (int s = 0; s < kSlots; s++) {
             if (!((m >> (16 * s)) & 1ull)) continue;
             const int x0s = __builtin_amdgcn_readlane(x0, 16 * s), ipys = __builtin_amdgcn_readlane(ipy, 16 * s);
-            tile_loads(rI[s], slotI, slotI + pitch, (uint32_t)(g.origin[level] + (ipys - 1) * pitch + x0s), src, lane, kQPairs * 7);
+            tile_loads(rI[s], slotI, slotI + pitch, (uint32_t)(g.origin[level] + (ipys - 1) * pitch + x0s), src, lane, kQPairs2 * 7);
         }
     };
     request_I(g.nlevels - 1);
@@ -306,13 +411,11 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
         bool lvl_on = live && !oob;
         const PackedWeights wt = bilinear_weights(px - (float)ipx, py - (float)ipy);
         const uint32_t WIa = wt.Wa, WIb = wt.Wb;
-        const int x0 = (ipx - 1) & ~3;
-        const int offI = (ipx - 1) - x0;
         float qx = nx - half, qy = ny - half;       // nextPt - halfWin
         int tx0 = -(1 << 20), ty0 = 0;              // no J tile staged
         {
             const int inx = cv_floor(qx), iny = cv_floor(qy);
-            if (lvl_on && !window_oob(inx, iny, w, h)) { tx0 = inx - kJMargin; ty0 = iny - kJMargin; }
+            if (lvl_on && !window_oob(inx, iny, w, h)) { tx0 = inx - kJMargin2; ty0 = iny - kJMargin2; }
         }
         const unsigned long long m_on = __ballot(lvl_on), m_j = __ballot(tx0 != -(1 << 20));
         uint32_t q_src[3];
@@ -323,29 +426,20 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
 #pragma unroll
         for (int s = 0; s < kSlots; s++) {
             if (!((m_on >> (16 * s)) & 1ull)) continue;
-            uint32_t *qt = lds + s * kQTileDw;
-#pragma unroll
-            for (int t = 0; t < 3; t++) {
-                if (lane + 64 * t < kQPairs * 7) {
-                    const uint32_t top = rI[s][t][0], bot = rI[s][t][1];
-                    uint32_t *d = qt + jq_dst[t];
-#pragma unroll
-                    for (int c = 0; c < 4; c++) d[c * kQColDw] = perm_b32(bot, top, 0x0c040c00u + 0x00010001u * c);
-                }
-            }
+            tile_store_i2(lds + s * kTileDw2, rI[s], q_dst, lane);
         }
 #pragma unroll
         for (int s = 0; s < kSlots; s++) {
             if (!((m_j >> (16 * s)) & 1ull)) continue;
             const int tx0s = __builtin_amdgcn_readlane(tx0, 16 * s), ty0s = __builtin_amdgcn_readlane(ty0, 16 * s);
-            tile_loads(rJ[s], slotJ, slotJ + pitch, (uint32_t)(g.origin[level] + ty0s * pitch + tx0s), q_src, lane, kJPairs * 7);
+            tile_loads(rJ[s], slotJ, slotJ + pitch, (uint32_t)(g.origin[level] + ty0s * pitch + tx0s), q_src, lane, kJPairs2 * 7);
         }
         wave_lds_fence();
         // ---- patches; their words Ix | Iy << 16 go to the chain staging in the order of the A chains
 #pragma unroll
         for (int s = 0; s < kSlots; s++) {
             if (!((m_on >> (16 * s)) & 1ull)) continue;
-            const uint32_t qaddr = lds_base + (uint32_t)((s * kQTileDw + __builtin_amdgcn_readlane(offI, 16 * s) * kQColDw) * 4);
+            const uint32_t qaddr = lds_base + (uint32_t)(s * kTileDw2 * 4);
             const uint32_t W01s = __builtin_amdgcn_readlane(WIa, 16 * s), W23s = __builtin_amdgcn_readlane(WIb, 16 * s);
             const int ipxs = __builtin_amdgcn_readlane(ipx, 16 * s), ipys = __builtin_amdgcn_readlane(ipy, 16 * s);
             uint32_t Aw[8];
@@ -364,18 +458,16 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
 #pragma unroll
         for (int s = 0; s < kSlots; s++) {
             if (!((m_j >> (16 * s)) & 1ull)) continue;
-            tile_store_j(lds + s * kJTileDw, rJ[s], jq_dst, lane);
+            tile_store_j2<false>(lds + s * kTileDw2, rJ[s], q_dst, q_dc4, lane);
         }
         float A11, A12, A22, D;
         {
-            const float r = chain_a(L);
-            float q[15];
-#pragma unroll
-            for (int j = 0; j < 15; j++) q[j] = row_lane(r, lane, j);
+            float r11, r12, r22;
+            chain_a(L, r11, r12, r22);
             // iA += A_buf[0] + A_buf[1] + A_buf[2] + A_buf[3] after the scalar tail went into iA
-            A11 = (q[12] + (((q[0] + q[1]) + q[2]) + q[3])) * FLT_SCALE;
-            A12 = (q[13] + (((q[4] + q[5]) + q[6]) + q[7])) * FLT_SCALE;
-            A22 = (q[14] + (((q[8] + q[9]) + q[10]) + q[11])) * FLT_SCALE;
+            A11 = combine_a(r11) * FLT_SCALE;
+            A12 = combine_a(r12) * FLT_SCALE;
+            A22 = combine_a(r22) * FLT_SCALE;
         }
         wave_lds_fence();                        // the iterations' b terms overwrite the patch words
         D = A11 * A22 - A12 * A12;
@@ -399,9 +491,9 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
             const PackedWeights wj = bilinear_weights(qx - (float)inx, qy - (float)iny);
             const uint32_t Wa = wj.Wa, Wb = wj.Wb;
             int cx = inx - tx0, cy = iny - ty0;
-            const bool restage = it_on && ((unsigned)cx > (unsigned)(2 * kJMargin) || (unsigned)cy > (unsigned)(2 * kJMargin));
-            if (restage) { tx0 = inx - kJMargin; ty0 = iny - kJMargin; cx = kJMargin; cy = kJMargin; }
-            const int joff = ((int)__umul24((unsigned)cx, kJColDw) + cy + (lane >> 4) * kJTileDw) * 4;
+            const bool restage = it_on && ((unsigned)cx > (unsigned)(2 * kJMargin2) || (unsigned)cy > (unsigned)(2 * kJMargin2));
+            if (restage) { tx0 = inx - kJMargin2; ty0 = iny - kJMargin2; cx = kJMargin2; cy = kJMargin2; }
+            const int joff = ((int)__umul24((unsigned)cx, kCS2) + cy + (lane >> 4) * kTileDw2) * 4;
             const unsigned long long m_it = __ballot(it_on), m_rs = __ballot(restage);
             if (__builtin_expect(m_rs != 0, 0)) {     // a window drifted out of its tile
 #pragma unroll
@@ -409,8 +501,8 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
                     if (!((m_rs >> (16 * s)) & 1ull)) continue;
                     const int tx0s = __builtin_amdgcn_readlane(tx0, 16 * s), ty0s = __builtin_amdgcn_readlane(ty0, 16 * s);
                     uint32_t r[3][2];
-                    tile_loads(r, slotJ, slotJ + pitch, (uint32_t)(g.origin[level] + ty0s * pitch + tx0s), q_src, lane, kJPairs * 7);
-                    tile_store_j(lds + s * kJTileDw, r, jq_dst, lane);
+                    tile_loads(r, slotJ, slotJ + pitch, (uint32_t)(g.origin[level] + ty0s * pitch + tx0s), q_src, lane, kJPairs2 * 7);
+                    tile_store_j2<true>(lds + s * kTileDw2, r, q_dst, q_dc4, lane);
                 }
                 wave_lds_fence();
             }
@@ -419,12 +511,12 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
                 if (!((m_it >> (16 * s)) & 1ull)) continue;
                 const int joffs = __builtin_amdgcn_readlane(joff, 16 * s);
                 const uint32_t Was = __builtin_amdgcn_readlane(Wa, 16 * s), Wbs = __builtin_amdgcn_readlane(Wb, 16 * s);
-                lds_cu32 *pj = (lds_cu32 *)(size_t)(lds_base + (uint32_t)joffs + L.joff);
+                lds_cu32 *pj = (lds_cu32 *)(size_t)(lds_base + (uint32_t)joffs + L.qoff);
                 uint32_t C[9];
 #pragma unroll
-                for (int k = 0; k < 9; k++) C[k] = pj[k * kJColDw];
+                for (int k = 0; k < 9; k++) C[k] = pj[k * kCS2];
                 float v[10];
-                mismatch_slot8(C, Was, Wbs, IvP[s], IxP[s], IyP[s], vround, L.seg2, v);
+                mismatch_slot8(C, Was, Wbs, IvP[s], IxP[s], IyP[s], vround, L.tail, v);
                 const uint32_t so = (uint32_t)(s * kStageDw * 4);
 #pragma unroll
                 for (int t = 0; t < 10; t++) lds_store(L.wb[t] + so, __float_as_uint(v[t]));
@@ -434,13 +526,13 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
             {
                 const float r = chain_b(L);
                 // bbuf = qb0 + qb1; ib1 += bbuf[0] + bbuf[2]; ib2 += bbuf[1] + bbuf[3]  (the tails are already in ib), on the
-                // DPP network inside the row: lane c of the row adds lane c + 4 (bb_c, c < 4), then lane c + 2 (c < 2),
-                // then the tail of lane c + 8; lanes 0 and 1 hold b1 and b2, handed to the whole row
-                const float bb = r + row_shl<4>(r);
+                // DPP network inside the row.  Positions: 0 tail x | 1..4 chains 0, 4, 2, 6 | 8 tail y | 9..12 chains 1, 5, 3, 7:
+                // position 1 + 2 = bb0, 3 + 4 = bb2 (9.. : bb1, bb3), then their sum, then the tail at the head of the half row
+                const float bb = r + row_shl<1>(r);
                 const float u = bb + row_shl<2>(bb);
-                const float f = row_shl<8>(r) + u;
-                b1f = row_first<0>(f) * FLT_SCALE;
-                b2f = row_first<1>(f) * FLT_SCALE;
+                const float f = r + row_shl<1>(u);
+                b1f = row_first(f) * FLT_SCALE;
+                b2f = row_first(row_shl<8>(f)) * FLT_SCALE;
             }
             wave_lds_fence();                    // the next iteration's terms overwrite these
             const float dlx = (A12 * b2f - A22 * b1f) * D;
@@ -534,8 +626,8 @@ void launch_lk_sse2(const LkArgs &a0, int batch, int max_pts, hipStream_t st)
     LkArgs a = a0;
     a.gx = waves < 768 ? waves : 768;
     a.spread = 0;
-    if (batch < 4) {                             // latency shape: seven single-wave workgroups per CU are resident
-        const int room = 1792 / batch;
+    if (batch < 4) {                             // latency shape: eight single-wave workgroups per CU are resident
+        const int room = 2048 / batch;
         a.gx = max_pts < room ? max_pts : room;
         a.spread = 1;
     }
