@@ -62,7 +62,9 @@ def parse():
     ap.add_argument("--e2e-frames", type=int, default=1025, help="frames of the end-to-end leg (run_kitti_stereo from PGM and PNG "
                     "files on disk, process start included; 0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the m1 / online legs (value, roofline, cpu_baseline only)")
-    ap.add_argument("--no-self-check", action="store_true", help="skip the oracle comparison of 8 random pairs of the last step")
+    ap.add_argument("--no-self-check", action="store_true", help="skip the oracle comparison of the last step's pairs")
+    ap.add_argument("--self-check-pairs", type=int, default=256, help="pairs of the LAST timed step compared with the oracle in the main "
+                    "measurement and the lk_accum_sse2 leg (256 = every pair of a default step; the orb and hd legs check an eighth, at least 32)")
     ap.add_argument("--self-check-sabotage", action="store_true",
                     help="(test of the test) run the main self-check's oracle in the OTHER accumulation order: it must fail and "
                          "bench.py must exit with 3")
@@ -241,8 +243,8 @@ def run_leg(pkg, torch, dev, L, R, width, height, B, steps, warmup, ctx_kw):
     return ctx, el, stage_ms, recs, ((steps - 1) % NC) * B
 
 
-def self_check(pkg, O, ctx, recs, L, R, width, f0, P1, P2, mode="lk", sse2=False, keep=0, n_check=8, seed=20261004):
-    """After the timing: `n_check` random pairs of the LAST step against the CPU oracle on the same frames -- fail_stage,
+def self_check(pkg, O, ctx, recs, L, R, width, f0, P1, P2, mode="lk", sse2=False, keep=0, n_check=256, seed=20261004):
+    """After the timing: `n_check` pairs of the LAST step (all of them when n_check >= the step) against the CPU oracle on the same frames -- fail_stage,
     keypoint / track / inlier counts, RANSAC and LM iteration numbers, every matched track and the inlier mask byte for
     byte, the relative motion to 1e-9.  A mismatch makes bench.py exit non-zero: a throughput number for wrong results
     is not a number."""
@@ -300,9 +302,9 @@ def self_check(pkg, O, ctx, recs, L, R, width, f0, P1, P2, mode="lk", sse2=False
             e = float(np.linalg.norm(g["T_rel_inv"].reshape(4, 4) - r["T_rel_inv"]) / np.linalg.norm(r["T_rel_inv"]))
             if not e <= 1e-9:
                 bad.append(f"pair {p}: T_rel_inv off by {e:.2e}")
-    return {"pairs": len(pairs), "ok": not bad, "compared": "fail_stage, counts, ransac_iters, lm_iters, tracks + inlier mask "
+    return {"pairs": len(pairs), "pairs_of_step": len(recs), "ok": not bad, "compared": "fail_stage, counts, ransac_iters, lm_iters, tracks + inlier mask "
             "(bytes), T_rel_inv (1e-9) vs oracle/ on the same frames" + (", oracle in SSE2 accumulation order" if sse2 else ""),
-            "which_pairs_of_last_step": pairs, **({"mismatches": bad[:12]} if bad else {})}
+            "which_pairs_of_last_step": ("all" if len(pairs) == len(recs) else pairs), **({"mismatches": bad[:12]} if bad else {})}
 
 
 def cpu_orb(O, L, R, width, P1, P2, n1, n_all):
@@ -749,7 +751,8 @@ def main():
             O.build()
             # the context still holds the last step's tracks and masks (B pairs, overlap on, chunks cycled)
             out["self_check"] = self_check(pkg, O, ctx, res, L, R, W, ((steps - 1) % NC) * B, P1, P2, mode=args.mode,
-                                           sse2=(args.lk_accum == "sse2") != args.self_check_sabotage)
+                                           sse2=(args.lk_accum == "sse2") != args.self_check_sabotage,
+                                           n_check=args.self_check_pairs if args.mode == "lk" else max(32, args.self_check_pairs // 8))
 
     # ---- secondary legs (N = 1): M1 with H2D inside the timed region, and the online path ---------
     if world == 1 and not args.no_secondary and not args.config5:
@@ -843,7 +846,7 @@ def main():
                         "roofline": roofline_lk(st_ms, int(round(float(recs["n_prev_kps"].mean()) * B)), B, sse2=True) if st_ms.get("lk") else None,
                         "lk_ms_per_step": round(st_ms.get("lk", 0.0), 4),
                         "lk_ms_per_step_exact": round(stage_ms.get("lk", 0.0), 4) if stage_ms.get("lk") else None},
-                       dict(mode="lk", sse2=True))
+                       dict(mode="lk", sse2=True, n_check=args.self_check_pairs))
             if args.mode == "lk":
                 # (2) BASELINE config #3: the ORB extractor + descriptor-match path on the same frames
                 lctx, el, st_ms, recs, f0 = run_leg(pkg, torch, dev, L, R, W, H, B, leg_steps, leg_warm,
@@ -853,7 +856,7 @@ def main():
                 if O is not None and args.cpu_pairs > 0:
                     n1 = max(4, min(args.cpu_pairs // 4, B))
                     extra["cpu_baseline"] = cpu_orb(O, L, R, W, P1, P2, n1, min(max(4 * n1, 2 * usable_cores()), B))
-                finish("orb", lctx, el, st_ms, recs, f0, leg_steps, B, extra, dict(mode="orb"))
+                finish("orb", lctx, el, st_ms, recs, f0, leg_steps, B, extra, dict(mode="orb", n_check=max(32, args.self_check_pairs // 8)))
             if args.mode == "lk" and args.hd_batch > 0:
                 # (3) BASELINE config #4: 1920x1080, EXACTLY the 2000 highest-response FAST corners per frame
                 Bh, Wh, Hh, Ph = args.hd_batch, 1920, 1080, 1920
@@ -883,7 +886,7 @@ def main():
                     extra["cpu_baseline"] = {"value": round(v1, 3), "unit": "stereo pairs/s", "cores": 1, "kind": "port",
                                              "sample": f"first {n1} pairs of the same 1920x1080 frames, oracle/ (FAST, selection of the 2000 "
                                                        f"strongest, LK step), 1 thread"}
-                finish("hd", lctx, el, st_ms, recs, f0, leg_steps, Bh, extra, dict(mode="lk", keep=2000, n_check=4),
+                finish("hd", lctx, el, st_ms, recs, f0, leg_steps, Bh, extra, dict(mode="lk", keep=2000, n_check=max(32, args.self_check_pairs // 8)),
                        frames=(Lh, Rh, Wh), proj=(P1h, P2h))
                 del Lh, Rh
 

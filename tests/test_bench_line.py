@@ -25,10 +25,11 @@ def test_default_line_carries_the_legs_and_a_green_self_check():
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0
-    assert out["self_check"]["ok"] and out["self_check"]["pairs"] == 8
+    assert out["self_check"]["ok"] and out["self_check"]["pairs"] == 12 and out["self_check"]["which_pairs_of_last_step"] == "all"
     for leg, stage in (("lk_accum_sse2", "lk"), ("orb", "orb_cellfast"), ("hd", "lk")):
         d = out[leg]
         assert d["value"] > 0 and d["self_check"]["ok"] and d["stage_ms_per_step"][stage] > 0, leg
+        assert d["self_check"]["pairs"] == d["self_check"]["pairs_of_step"], leg          # small batches are checked whole
     assert out["lk_accum_sse2"]["lk_ms_per_step"] > out["lk_accum_sse2"]["lk_ms_per_step_exact"] > 0
     assert out["orb"]["roofline"]["frac"] > 0 and out["orb"]["cpu_baseline"]["value"] > 0
     assert out["hd"]["mean_keypoints_per_pair"] == 2000.0 and out["hd"]["roofline"]["frac"] > 0

@@ -276,3 +276,21 @@ def test_hd_whole_step_on_exactly_2000_strongest_corners(pkg, oracle, tc, synth)
         assert rc >= 0
         assert relfro(pose_g, pose_r) <= POSE_TOL and relfro(pose_g, pose_r) <= TIGHT * 10
     c.close()
+
+
+def test_lk_1024_consecutive_pairs_every_pair_compared(pkg, oracle, tc, synth):
+    """Sequence length (BASELINE config #2 is a whole sequence): 1024 consecutive S0 pairs in four batches of 256 -- the
+    size bench.py times -- with the pose chain carried from batch to batch; EVERY pair against the oracle (counts, iteration
+    numbers, tracks and inlier masks byte for byte, relative motion 1e-9, chained pose 1e-4 with the observed bound
+    asserted).  The rare paths of the kernels (J-tile re-stage, the f64 re-check of a borderline convergence test, second
+    RANSAC phase, SVD refit) have probabilities of the order of 1e-3 per pair: a sample of this size meets them.
+    tools/parity_sequence.py runs the same comparison on all 4540 pairs in both accumulation orders
+    (profiles/r05_parity_4541.json)."""
+    import sys
+    sys.path.insert(0, os.path.join(conftest.ROOT, "tools"))
+    import parity_sequence
+    rep = parity_sequence.run(pkg, oracle, tc, synth, 1024, "exact", batch=256)
+    assert rep["pairs"] == 1024 and rep["pairs_ok"] >= 1020, rep
+    assert all(v == 0 for v in rep["mismatches"].values()), (rep["mismatches"], rep["mismatching_pairs_listed"])
+    assert rep["max_chained_pose_error_rel_fro"] <= 1e-8, rep["max_chained_pose_error_rel_fro"]
+    print(f"1024 pairs: chained pose max rel. Frobenius {rep['max_chained_pose_error_rel_fro']:.2e}, oracle {rep['oracle_s']} s")

@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Sequence-length parity, HIP vs the CPU oracle: N consecutive pairs of the S0 stand-in sequence (BASELINE config #2
+is "KITTI-00 full seq": 4541 frames, reference loop src/System.cpp:31-43) tracked in batches through the C-ABI
+(svo_track_batch, the pose chain continued from batch to batch) and, pair by pair, by the oracle on a thread pool.
+
+Compared at EVERY pair: ok, fail_stage, n_prev_kps, n_cur_kps, n_tracked, n_inliers, ransac_iters, lm_iters (equal), the
+matched tracks and the RANSAC inlier mask (bytes), the relative motion (1e-9) and the chained pose (1e-4 required by
+north_star; the observed maximum is reported).  Modes: exact (lk_kernel vs oracle mode 0), sse2 (lk_sse2_kernel vs oracle
+mode 2), orb (ORB extractor + matcher).
+
+usage (GPU box): python3 tools/parity_sequence.py --pairs 4540 --modes exact,sse2 --orb-pairs 512 --out gpurun_out/parity.json
+The frames are rendered chunk by chunk (a 4541-frame sequence is 4 GB of images)."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+
+def relfro(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b))
+
+
+def workers():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 64))
+
+
+def run(pkg, O, torch, synth, n_pairs, mode="exact", batch=256, seed=20200710, width=1241, height=376, progress=None):
+    """Returns the report dict of one mode; raises nothing: every mismatch is counted and the first few are listed."""
+    dev = torch.device("cuda", 0)
+    seq = synth.StereoSequence(width=width, height=height, n_frames=n_pairs + 1, seed=seed, device=dev)
+    P1, P2 = seq.proj()
+    K = np.asarray(P1, np.float64).reshape(3, 4)[:, :3].copy()
+    kw = {}
+    if mode == "sse2":
+        kw["lk_accum"] = pkg.LK_ACCUM_SSE2
+    if mode == "orb":
+        kw.update(track_mode=pkg.MODE_ORB, min_move2=0.05 ** 2, max_move2=10.0 ** 2)
+    B = min(batch, n_pairs)
+    ctx = pkg.Context(width, height, device=0, P1=P1, P2=P2, max_batch=B, **kw)
+    prm = O.make_params(P1, P2, **({"min_t2": 0.05 ** 2, "max_t2": 10.0 ** 2} if mode == "orb" else {}))
+    old = O.set_lk_accum(O.LK_ACCUM_FLOAT_SSE if mode == "sse2" else O.LK_ACCUM_EXACT)
+    fields = ("ok", "fail_stage", "n_prev_kps", "n_cur_kps", "n_tracked", "n_inliers")
+    mism = {k: 0 for k in fields + ("ransac_iters", "lm_iters", "tracks", "inlier_mask", "T_rel_inv_gt_1e-9", "pose_gt_1e-4")}
+    examples = []
+    pose_gpu = np.eye(4)
+    pose_ref = np.eye(4)
+    worst_pose = worst_rel = 0.0
+    n_ok = tracked = 0
+    t_gpu = t_cpu = 0.0
+    L = torch.zeros((B + 1, height, width), dtype=torch.uint8, device=dev)
+    R = torch.zeros_like(L)
+    last = None
+    try:
+        for p0 in range(0, n_pairs, B):
+            nb = min(B, n_pairs - p0)
+            for f in range(nb + 1):                         # frames p0 .. p0 + nb (the first one is the previous chunk's last)
+                if f == 0 and last is not None:
+                    L[0], R[0] = last
+                else:
+                    L[f], R[f] = seq.render(p0 + f)
+            last = (L[nb].clone(), R[nb].clone())
+            t0 = time.perf_counter()
+            res = ctx.track_batch(L[:nb + 1], R[:nb + 1], pose0=pose_gpu)
+            t_gpu += time.perf_counter() - t0
+            fl = L[:nb + 1].cpu().numpy()
+            fr = R[:nb + 1].cpu().numpy()
+
+            def one_lk(t):
+                kps = O.fast(fl[t])
+                r, _, _ = O.lk_track_step(prm, fl[t], fr[t], fl[t + 1], fr[t + 1], kps, np.eye(4), want_tracks=True, threads=1)
+                tr = r["tracks"]
+                pnp = O.pnp_ransac(O.triangulate(P1, P2, tr[0], tr[1]), tr[3], K) if r["n_tracked"] >= 5 else None
+                return r, [tr[0], tr[1], tr[2], tr[3]], pnp
+
+            def one_orb(t):
+                (kL, dL), (kR, dR), (k2, d2) = (O.orb_extract(im)[:2] for im in (fl[t], fr[t], fl[t + 1]))
+                r, _ = O.orb_track_step(prm, kL, dL, kR, dR, k2, d2, np.eye(4))
+                t2l, t1l, t1r = O.orb_robust_match(kL, dL, kR, dR, k2, d2)
+                pnp = O.pnp_ransac(O.triangulate(P1, P2, t1l, t1r), t2l, K) if len(t1l) >= 5 else None
+                return r, [t1l, t1r, None, t2l], pnp
+
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=workers()) as ex:
+                refs = list(ex.map(one_orb if mode == "orb" else one_lk, range(nb)))
+            t_cpu += time.perf_counter() - t0
+            for t, (r, tr, pnp) in enumerate(refs):
+                g = res[t]
+                p = p0 + t
+                bad = []
+                for k in fields:
+                    if int(g[k]) != int(r[k]):
+                        mism[k] += 1; bad.append(k)
+                got = ctx.batch_tracks(t)
+                if any(tr[k] is not None and got[k].tobytes() != np.ascontiguousarray(tr[k]).tobytes() for k in range(4)):
+                    mism["tracks"] += 1; bad.append("tracks")
+                if pnp is not None:
+                    for k in ("ransac_iters", "lm_iters"):
+                        if int(g[k]) != int(pnp[k]):
+                            mism[k] += 1; bad.append(k)
+                    if got[4].tobytes() != pnp["mask"].tobytes():
+                        mism["inlier_mask"] += 1; bad.append("inlier_mask")
+                if r["ok"]:
+                    n_ok += 1
+                    pose_ref = pose_ref @ r["T_rel_inv"]          # frame_pose_ = frame_pose_ * T.inv()  (src/tracking.cpp:318)
+                    e = relfro(g["T_rel_inv"].reshape(4, 4), r["T_rel_inv"])
+                    worst_rel = max(worst_rel, e)
+                    if not e <= 1e-9:
+                        mism["T_rel_inv_gt_1e-9"] += 1; bad.append("T_rel_inv")
+                tracked += int(r["n_tracked"])
+                e = relfro(g["pose"].reshape(4, 4), pose_ref)
+                worst_pose = max(worst_pose, e)
+                if not e <= 1e-4:
+                    mism["pose_gt_1e-4"] += 1; bad.append("pose")
+                if bad and len(examples) < 12:
+                    examples.append({"pair": p, "fields": bad})
+            pose_gpu = res[nb - 1]["pose"].reshape(4, 4).copy()
+            if progress:
+                progress(f"{mode}: {p0 + nb}/{n_pairs} pairs, mismatching pairs so far {len(examples)}")
+    finally:
+        O.set_lk_accum(old)
+        ctx.close()
+    return {"mode": mode, "pairs": n_pairs, "frame_size": f"{width}x{height}", "seed": seed, "batch": B, "pairs_ok": n_ok,
+            "point_chains_tracked": tracked, "mismatches": mism, "mismatching_pairs_listed": examples,
+            "max_relative_motion_error_rel_fro": worst_rel, "max_chained_pose_error_rel_fro": worst_pose,
+            "gpu_track_batch_s": round(t_gpu, 3), "oracle_s": round(t_cpu, 3), "oracle_worker_threads": workers()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=4540)
+    ap.add_argument("--modes", default="exact,sse2")
+    ap.add_argument("--orb-pairs", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    import torch
+    pkg = entry.load_package()
+    O = entry.load_oracle()
+    O.build()
+    synth = importlib.import_module(entry.PKG_NAME + ".synth")
+    say = lambda m: print(m, file=sys.stderr, flush=True)     # a line a minute keeps the GPU box's watchdog quiet
+    rep = {"what": "HIP (C-ABI, svo_track_batch) vs oracle/ on consecutive S0 pairs, every pair compared (tools/parity_sequence.py)",
+           "kernel_sources_sha256_16": {"lk": _hash(False), "lk_sse2": _hash(True)}, "runs": []}
+    for m in [x for x in a.modes.split(",") if x]:
+        rep["runs"].append(run(pkg, O, torch, synth, a.pairs, m, a.batch, progress=say))
+    if a.orb_pairs > 0:
+        rep["runs"].append(run(pkg, O, torch, synth, a.orb_pairs, "orb", a.batch, progress=say))
+    rep["all_zero"] = all(v == 0 for r in rep["runs"] for v in r["mismatches"].values())
+    txt = json.dumps(rep, indent=1)
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write(txt + "\n")
+    print(txt)
+    sys.exit(0 if rep["all_zero"] else 3)
+
+
+def _hash(sse2):
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("lk.hip", "lk_common.h", "svo_device.h", "svo_kernels.h") + (("lk_sse2.hip",) if sse2 else ()):
+        with open(os.path.join(entry.PKG_DIR, "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+if __name__ == "__main__":
+    main()
