@@ -13,8 +13,12 @@
  *    > 0 soft "tracking failed" reason mirroring the reference's failure exits); nothing throws
  *    or aborts across the boundary; svo_last_error() gives a message for the last hard error.
  *  - `mem` says where the caller's buffers live: SVO_MEM_HOST (copied H2D/D2H by the call) or
- *    SVO_MEM_DEVICE (HBM pointers, e.g. a torch tensor's data_ptr(); no copies, results are
- *    ordered on the context's stream -- call svo_sync() before reading them from another stream).
+ *    SVO_MEM_DEVICE (HBM pointers, e.g. a torch tensor's data_ptr(); no copies).  STREAM ORDER of device buffers: every
+ *    kernel of a call runs on the context's stream (svo_set_stream) -- the pose stage of an overlap-mode batch on the
+ *    context's side stream --, and the library orders nothing against other streams by itself.  A caller that produces
+ *    inputs or (zero-)fills outputs on ANOTHER stream calls svo_wait_stream(ctx, that_stream) before the entry point, and
+ *    svo_signal_stream(ctx, consumer_stream) -- or svo_sync() -- before it reads device-resident results from another
+ *    stream (ABI v7; both are event waits on the device, no host synchronisation).
  *  - one context per (thread, GPU); calls on a context are serialised by the caller.
  *  - images are 8-bit grayscale, row-major, `pitch` bytes per row.
  */
@@ -27,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 6
+#define SVO_ABI_VERSION 7
 
 /* status codes */
 #define SVO_OK                 0
@@ -83,10 +87,15 @@ typedef struct {
        (src/tracking.cpp:593-618), the one place where upstream's result depends on the build's SIMD width:
        SVO_LK_ACCUM_EXACT (default): exact integer sums converted to float once -- upstream's acctype = int64
            variant, independent of any order (canonical choice C0);
-       SVO_LK_ACCUM_SSE2: float accumulation in the lane order of upstream's CV_SSE2 block, i.e. what an x86
-           OpenCV 3 build computes (four lanes over x = 0..19 + scalar tail for A, _mm_madd_epi16 pairs over
-           x = 0..15 + scalar tail for b).  Bit-identical to oracle/lk.c's accumulation mode 2; about 2x the
-           LK kernel time.  YAML key `lk_accum: exact | sse2`. */
+       SVO_LK_ACCUM_SSE2: float accumulation in a lane order of upstream's x86 SIMD code AS RESTATED in oracle/lk.c
+           mode 2 (four lanes over x = 0..19 + scalar tail for A, madd pairs (k, k + 4) over x = 0..15 + scalar tail
+           for b) -- recalled from lkpyramid.cpp, NOT validated against an OpenCV binary (none exists in the build
+           environment; tests/test_cv_crosscheck.py is the check for a box that has one).  Bit-identical to that
+           oracle mode; about 1.9x the LK kernel time;
+       SVO_LK_ACCUM_SIMD128 (ABI v7): the universal-intrinsic (CV_SIMD128) block restated whole = oracle mode 4: b
+           as above, A in groups of eight pixels (four lanes over x = 0..15 + scalar tail x = 16..20).  Same cost.
+           (The legacy CV_SSE2 block with one float add per pixel product is oracle mode 3; no kernel: DESIGN.md 2.)
+       YAML key `lk_accum: exact | sse2 | simd128`. */
     int32_t lk_accum;
     /* ABI v6.  LK mode, fused entry points only (svo_add_frame / svo_track_*): 0 = track every cv::FAST corner, as
        the reference does (src/tracking.cpp:94-113); N > 0 = keep the N highest-response corners of every left image
@@ -99,6 +108,7 @@ typedef struct {
 #define SVO_MODE_ORB 1
 #define SVO_LK_ACCUM_EXACT 0
 #define SVO_LK_ACCUM_SSE2  1
+#define SVO_LK_ACCUM_SIMD128 2
 
 typedef struct {                    /* solvePnPRansac + Rodrigues outcome */
     double rvec[3], tvec[3], R[9];
@@ -127,6 +137,12 @@ void        svo_destroy(svo_ctx *ctx);
 const char *svo_last_error(const svo_ctx *ctx);
 int         svo_set_stream(svo_ctx *ctx, void *hip_stream);   /* NULL -> context's own stream */
 int         svo_sync(svo_ctx *ctx);
+/* ABI v7.  svo_wait_stream: everything queued on `hip_stream` so far happens-before whatever this context launches next
+ * (an event recorded on hip_stream, waited for by the context's stream).  svo_signal_stream: everything this context has
+ * launched so far -- the side-stream pose stage of an overlap-mode svo_track_batch included -- happens-before whatever is
+ * queued on `hip_stream` next.  NULL = the legacy default stream.  Device-side waits only. */
+int         svo_wait_stream(svo_ctx *ctx, void *hip_stream);
+int         svo_signal_stream(svo_ctx *ctx, void *hip_stream);
 int         svo_num_levels(const svo_ctx *ctx);               /* LK pyramid levels actually built */
 
 /* ---- stage API: one call per OpenCV call site of the reference ---------------------------- */

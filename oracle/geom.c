@@ -166,24 +166,49 @@ void orc_svd_invert(const double *A, int n, double *Ainv)
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Version forks of the restated OpenCV callees (tests only).  The reference asks for
+ * "OpenCV 3" (CMakeLists.txt:17; the ROS build for 3.1) without pinning a patch release, and the callees changed
+ * inside the 3.x line.  Knob 0 of every fork is the CANONICAL choice the HIP path is held to; the other values
+ * restate what other releases compute, as recalled -- nothing here is checked against a binary (no OpenCV in this
+ * image; tests/test_cv_crosscheck.py is the pin for the day one exists).
+ * ---------------------------------------------------------------------------------------- */
+static int g_compat[ORC_COMPAT_KNOBS];
+void orc_set_opencv_compat(int knob, int value)
+{
+    if (knob == ORC_COMPAT_LK_LANES) { orc_lk_set_accum(value); return; }
+    if (knob >= 0 && knob < ORC_COMPAT_KNOBS) g_compat[knob] = value;
+}
+int orc_get_opencv_compat(int knob)
+{
+    if (knob == ORC_COMPAT_LK_LANES) return orc_lk_get_accum();
+    return (knob >= 0 && knob < ORC_COMPAT_KNOBS) ? g_compat[knob] : -1;
+}
+
+/* ------------------------------------------------------------------------------------------
  * cv::triangulatePoints(P1, P2, x1, x2) -> 4xN float; convertPointsFromHomogeneous -> Nx3 float
+ * C8: ORC_COMPAT_TRIANGULATE = 0 (CANONICAL): the 4 x 4 system x P[2] - P[0], y P[2] - P[1] of both views (3.4's
+ * cvTriangulatePoints as restated in round 1); = 1: the older 6 x 4 system with a third row x P[1] - y P[0] per view
+ * (2.4 .. 3.3 as recalled: "matrA_dat[(j*3+2)*4+k] = x * P[1][k] - y * P[0][k]") -- the same null vector on exact data,
+ * a slightly different least-squares point when the two rays do not meet.
  * ---------------------------------------------------------------------------------------- */
 void orc_triangulate(const double P1[12], const double P2[12], const orc_pt2f *x1,
                      const orc_pt2f *x2, int n, orc_pt3f *out, float *out4)
 {
     int i, k;
+    const int rows_per_view = g_compat[ORC_COMPAT_TRIANGULATE] == 1 ? 3 : 2, m = 2 * rows_per_view;
     for (i = 0; i < n; i++) {
-        double A[16], At[16], W[4], Vt[16];
+        double A[24], At[24], W[4], Vt[16];
         const double *P[2] = {P1, P2};
         double xs[2] = {(double)x1[i].x, (double)x2[i].x}, ys[2] = {(double)x1[i].y, (double)x2[i].y};
         int j;
         for (j = 0; j < 2; j++)
             for (k = 0; k < 4; k++) {
-                A[(j * 2 + 0) * 4 + k] = xs[j] * P[j][8 + k] - P[j][k];
-                A[(j * 2 + 1) * 4 + k] = ys[j] * P[j][8 + k] - P[j][4 + k];
+                A[(j * rows_per_view + 0) * 4 + k] = xs[j] * P[j][8 + k] - P[j][k];
+                A[(j * rows_per_view + 1) * 4 + k] = ys[j] * P[j][8 + k] - P[j][4 + k];
+                if (rows_per_view == 3) A[(j * 3 + 2) * 4 + k] = xs[j] * P[j][4 + k] - ys[j] * P[j][k];
             }
-        for (j = 0; j < 4; j++) for (k = 0; k < 4; k++) At[k * 4 + j] = A[j * 4 + k];
-        orc_jacobi_svd(At, 4, 4, W, Vt);
+        for (j = 0; j < m; j++) for (k = 0; k < 4; k++) At[k * m + j] = A[j * 4 + k];
+        orc_jacobi_svd(At, m, 4, W, Vt);
         float X4[4];
         for (k = 0; k < 4; k++) X4[k] = (float)Vt[12 + k];     /* last row of V^T, stored as f32 */
         if (out4) for (k = 0; k < 4; k++) out4[(size_t)k * n + i] = X4[k];

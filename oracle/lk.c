@@ -149,8 +149,16 @@ static int32_t *g_iter_log = NULL;
 static _Thread_local int g_iter_pt = 0;
 void orc_lk_set_iter_log(int32_t *log) { g_iter_log = log; }
 
-static int g_lk_accum = 0;      /* 0 exact int64 (CANONICAL), 1 float raster order, 2 float SSE2 lane order */
-void orc_lk_set_accum(int mode) { g_lk_accum = (mode == 1 || mode == 2) ? mode : 0; }
+/* 0 exact int64 (CANONICAL); float accumulation: 1 raster order (the scalar loop), 2 the round-4 restatement (A: four
+ * lanes over x = 0..19, b: madd pairs over x = 0..15 -- the parity target of lk_sse2_kernel), and the two upstream SIMD
+ * blocks as recalled WHOLE (C11): 3 the legacy CV_SSE2 block (2.4 .. early 3.4: A as in mode 2;
+ * b from _mm_mullo/_mm_mulhi_epi16 products, every pixel its own float add -- qb0 lanes [bx0 by0 bx1 by1] then
+ * [bx4 by4 bx5 by5], qb1 [bx2 by2 bx3 by3] then [bx6 by6 bx7 by7]), 4 the universal-intrinsic CV_SIMD128 block (later
+ * 3.4 / 4.x: A over x = 0..15 in groups of eight with v_muladd -- exact products, so fused or not is the same float --,
+ * tail x = 16..20; b = v_dotprod pairs (k, k + 4) as in mode 2).  Mode 2 mixes the A loop of one with the b loop of the
+ * other; it stays because the HIP kernel and its committed evidence are held to it. */
+static int g_lk_accum = 0;
+void orc_lk_set_accum(int mode) { g_lk_accum = (mode >= 1 && mode <= 4) ? mode : 0; }
 int orc_lk_get_accum(void) { return g_lk_accum; }
 
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
@@ -192,7 +200,7 @@ static void lk_point_level(const uint8_t *I, int pitchI, const int16_t *dI, int 
     int64_t iA11 = 0, iA12 = 0, iA22 = 0;
     float fA11 = 0.f, fA12 = 0.f, fA22 = 0.f;              /* upstream's float accumulators (sensitivity modes) */
     float qA11[4] = {0.f, 0.f, 0.f, 0.f}, qA12[4] = {0.f, 0.f, 0.f, 0.f}, qA22[4] = {0.f, 0.f, 0.f, 0.f};
-    const int simdA = accum == 2 ? (win / 4) * 4 : 0;      /* x < simdA rides the four SSE lanes */
+    const int simdA = (accum == 2 || accum == 3) ? (win / 4) * 4 : (accum == 4 ? (win / 8) * 8 : 0);   /* x < simdA rides the four SSE lanes */
     int x, y;
     for (y = 0; y < win; y++) {
         const uint8_t *src = I + (ptrdiff_t)(y + ipy) * pitchI + ipx;
@@ -226,7 +234,7 @@ static void lk_point_level(const uint8_t *I, int pitchI, const int16_t *dI, int 
     }
     float A11, A12, A22;
     if (accum) {
-        if (accum == 2) {                                  /* iA11 += A11buf[0] + A11buf[1] + A11buf[2] + A11buf[3] */
+        if (accum >= 2) {                                  /* iA11 += A11buf[0] + A11buf[1] + A11buf[2] + A11buf[3] */
             fA11 += qA11[0] + qA11[1] + qA11[2] + qA11[3];
             fA12 += qA12[0] + qA12[1] + qA12[2] + qA12[3];
             fA22 += qA22[0] + qA22[1] + qA22[2] + qA22[3];
@@ -261,7 +269,7 @@ static void lk_point_level(const uint8_t *I, int pitchI, const int16_t *dI, int 
         int64_t ib1 = 0, ib2 = 0;
         float fb1 = 0.f, fb2 = 0.f;
         float qb0[4] = {0.f, 0.f, 0.f, 0.f}, qb1[4] = {0.f, 0.f, 0.f, 0.f};
-        const int simdB = accum == 2 ? (win / 8) * 8 : 0;
+        const int simdB = accum >= 2 ? (win / 8) * 8 : 0;
         for (y = 0; y < win; y++) {
             const uint8_t *Jp = J + (ptrdiff_t)(y + iny) * pitchJ + inx;
             const int16_t *Ip = Ibuf + y * win, *dIp = dIbuf + y * win * 2;
@@ -274,6 +282,13 @@ static void lk_point_level(const uint8_t *I, int pitchI, const int16_t *dI, int 
                 if (accum && x >= simdB) {                 /* ib1 += (itemtype)(diff*dIptr[0]) */
                     fb1 += (float)(diff * dIp[2 * x]);
                     fb2 += (float)(diff * dIp[2 * x + 1]);
+                } else if (accum == 3) {
+                    /* legacy CV_SSE2: mullo / mulhi products of (It_k It_k) x (Ix_k Iy_k), converted and added pixel by
+                     * pixel: pixels 0, 1 (then 4, 5) of a group of eight to qb0, 2, 3 (then 6, 7) to qb1 */
+                    const int k = x & 7;
+                    float *q = (k & 2) ? qb1 : qb0;
+                    q[(k & 1) * 2] += (float)(diff * dIp[2 * x]);
+                    q[(k & 1) * 2 + 1] += (float)(diff * dIp[2 * x + 1]);
                 } else if (accum) {
                     dgrp[x & 7] = diff;
                     if ((x & 7) == 7) {
@@ -294,7 +309,7 @@ static void lk_point_level(const uint8_t *I, int pitchI, const int16_t *dI, int 
         }
         float b1, b2;
         if (accum) {
-            if (accum == 2) {                              /* bbuf = qb0 + qb1; ib1 += bbuf[0] + bbuf[2]; ib2 += bbuf[1] + bbuf[3] */
+            if (accum >= 2) {                              /* bbuf = qb0 + qb1; ib1 += bbuf[0] + bbuf[2]; ib2 += bbuf[1] + bbuf[3] */
                 float bb0 = qb0[0] + qb1[0], bb1 = qb0[1] + qb1[1], bb2 = qb0[2] + qb1[2], bb3 = qb0[3] + qb1[3];
                 fb1 += bb0 + bb2;
                 fb2 += bb1 + bb3;

@@ -123,7 +123,17 @@ def lk_track(prev, nxt, pts, win=21, max_level=3, max_iter=30, eps=0.01, min_eig
     return out, st
 
 
-LK_ACCUM_EXACT, LK_ACCUM_FLOAT_RASTER, LK_ACCUM_FLOAT_SSE = 0, 1, 2
+LK_ACCUM_EXACT, LK_ACCUM_FLOAT_RASTER, LK_ACCUM_FLOAT_SSE, LK_ACCUM_LEGACY_SSE2, LK_ACCUM_SIMD128 = 0, 1, 2, 3, 4
+COMPAT_TRIANGULATE, COMPAT_PNP_REFIT, COMPAT_PNP_MINIMAL, COMPAT_LK_LANES = 0, 1, 2, 3
+
+
+def set_opencv_compat(knob, value):
+    """Version forks of the restated OpenCV callees (oracle/geom.c; process-wide, tests only).
+    Returns the previous value; 0 is the canonical choice the HIP path is compared with."""
+    old = lib().orc_get_opencv_compat(int(knob))
+    lib().orc_set_opencv_compat(int(knob), int(value))
+    return old
+
 
 
 def set_lk_accum(mode):

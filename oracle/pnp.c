@@ -15,7 +15,10 @@
  *     borderline inliers.
  *  C2 the final Levenberg-Marquardt refit on the inlier set starts from the BEST hypothesis
  *     (3.1-3.3 restart from DLT, 3.4 from the last evaluated hypothesis; all converge to the same
- *     minimiser of the reprojection error over the inlier set).
+ *     minimiser of the reprojection error over the inlier set).  orc_set_opencv_compat(ORC_COMPAT_PNP_REFIT, v)
+ *     switches the start (C9: 1 = no refit at all, as before 3.3; 2 = the LAST evaluated hypothesis, 3.4's shared
+ *     rvec / tvec; 3 = the caller's zero guess), ORC_COMPAT_PNP_MINIMAL the npoints == 5 case (C10: 1 = 3.4's
+ *     early return of the kernel's EPnP pose with every point an inlier).  Tests only; value 0 is the parity target.
  *  C3 lambda = 10^k comes from an exact table instead of exp(k*log(10)).
  *  C4 J^T J and J^T e are summed sequentially in point order (upstream: blocked gemm order).
  */
@@ -498,9 +501,12 @@ int orc_pnp_ransac(const orc_pt3f *obj, const orc_pt2f *img, int n, const double
     res->best_iter = -1;
     res->R[0] = res->R[4] = res->R[8] = 1;      /* rvec = 0 -> Rodrigues gives I */
     if (n < model_points) return 0;             /* npoints == 4 would take the P3P kernel: out of scope */
+    const int refit_mode = orc_get_opencv_compat(ORC_COMPAT_PNP_REFIT);
+    const int minimal_direct = orc_get_opencv_compat(ORC_COMPAT_PNP_MINIMAL) == 1 && n == model_points;
 
     uint8_t *mask = (uint8_t *)malloc(n), *best_mask = (uint8_t *)calloc(n, 1);
     double bestR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, bestt[3] = {0, 0, 0};
+    double lastR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, lastt[3] = {0, 0, 0};
     int max_good = 0, niters = iterations > 1 ? iterations : 1;
     const float thr2 = (float)((double)reproj_err * (double)reproj_err);
     uint64_t rng = (uint64_t)-1;
@@ -534,6 +540,7 @@ int orc_pnp_ransac(const orc_pt3f *obj, const orc_pt2f *img, int n, const double
             us[2 * i + 1] = (double)yn * fy + cy;
         }
         orc_epnp(pws, us, model_points, fx, fy, cx, cy, R, t);
+        memcpy(lastR, R, sizeof(lastR)); memcpy(lastt, t, sizeof(lastt));
 
         int good = 0;
         if (n > model_points) {
@@ -575,9 +582,12 @@ int orc_pnp_ransac(const orc_pt3f *obj, const orc_pt2f *img, int n, const double
             M++;
         }
     double param[6];
-    orc_rodrigues_mat2vec(bestR, param);
-    param[3] = bestt[0]; param[4] = bestt[1]; param[5] = bestt[2];
-    res->lm_iters = lm_refine(param, Xw, mm, M, fx, fy, cx, cy);
+    orc_rodrigues_mat2vec(refit_mode == 2 ? lastR : bestR, param);
+    if (refit_mode == 2) { param[3] = lastt[0]; param[4] = lastt[1]; param[5] = lastt[2]; }
+    else { param[3] = bestt[0]; param[4] = bestt[1]; param[5] = bestt[2]; }
+    if (refit_mode == 3) memset(param, 0, sizeof(param));
+    /* C9 = 1 / C10 = 1: the model the kernel produced IS the answer (rvec through Rodrigues, as the callback stores it) */
+    res->lm_iters = (refit_mode == 1 || minimal_direct) ? 0 : lm_refine(param, Xw, mm, M, fx, fy, cx, cy);
     memcpy(res->rvec, param, sizeof(double) * 3);
     memcpy(res->tvec, param + 3, sizeof(double) * 3);
     orc_rodrigues_vec2mat(res->rvec, res->R, NULL);

@@ -65,6 +65,15 @@ void orc_pyr_down(const uint8_t *src, int w, int h, int spitch, uint8_t *dst, in
  * float accumulation in raster order, 2 = in the lane order of upstream's SSE2 block.  Process-wide. */
 void orc_lk_set_accum(int mode);
 int orc_lk_get_accum(void);
+/* Version forks of the restated OpenCV callees (tests only; geom.c).  Value 0 = CANONICAL. */
+enum { ORC_COMPAT_TRIANGULATE = 0,   /* 0: 4 x 4 system (3.4); 1: 6 x 4 system with the x P[1] - y P[0] rows (<= 3.3) */
+       ORC_COMPAT_PNP_REFIT = 1,     /* 0: LM refit from the best hypothesis; 1: no refit (<= 3.2); 2: from the LAST evaluated
+                                        hypothesis (3.4's shared rvec / tvec); 3: from the caller's zeros (DLT start-up skipped) */
+       ORC_COMPAT_PNP_MINIMAL = 2,   /* npoints == 5: 0: one RANSAC round + LM; 1: 3.4's direct return of the kernel's EPnP pose */
+       ORC_COMPAT_LK_LANES = 3,      /* = orc_lk_set_accum: 0 exact, 1 raster, 2 round-4 hybrid, 3 legacy CV_SSE2 block, 4 CV_SIMD128 block */
+       ORC_COMPAT_KNOBS = 4 };
+void orc_set_opencv_compat(int knob, int value);
+int orc_get_opencv_compat(int knob);
 void orc_lk_set_iter_log(int32_t *log);      /* tools only: iterations per (point, level) of the next orc_lk_track calls */
 int orc_lk_track(const orc_pyramid *prev, const orc_pyramid *next,
                  const orc_pt2f *prev_pts, int n, orc_pt2f *next_pts, uint8_t *status,

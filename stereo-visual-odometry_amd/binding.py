@@ -32,7 +32,7 @@ class Config(C.Structure):
 
 
 MODE_LK, MODE_ORB = 0, 1
-LK_ACCUM_EXACT, LK_ACCUM_SSE2 = 0, 1          # svo_config.lk_accum
+LK_ACCUM_EXACT, LK_ACCUM_SSE2, LK_ACCUM_SIMD128 = 0, 1, 2          # svo_config.lk_accum
 
 
 class PnPResult(C.Structure):
@@ -141,14 +141,6 @@ def _ptr(a):
     return C.c_void_p(a.data_ptr()), (MEM_DEVICE if a.is_cuda else MEM_HOST)
 
 
-def _torch_ready(t):
-    """The library runs on the context's own stream: outputs this binding has just allocated with torch (their
-    zero fill is a kernel on TORCH's current stream) and inputs torch has just produced must be complete before
-    a library kernel touches them.  Only the stage wrappers that allocate call this; track_batch does not."""
-    import torch
-    torch.cuda.current_stream(t.device).synchronize()
-
-
 class Context:
     """One svo_ctx: owns every device buffer of the hot path on one GPU."""
 
@@ -184,6 +176,28 @@ class Context:
 
     def set_stream(self, stream_handle):
         self._check(self.lib.svo_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def wait_stream(self, stream_handle):
+        """The context's stream waits ON THE DEVICE for everything queued on `stream_handle` so far (svo_wait_stream, ABI v7):
+        call it before handing the library a device buffer another stream is still filling."""
+        self._check(self.lib.svo_wait_stream(self.h, C.c_void_p(stream_handle)))
+
+    def signal_stream(self, stream_handle):
+        """`stream_handle` waits ON THE DEVICE for everything the context has queued so far, the side-stream pose stage of
+        an overlap-mode batch included (svo_signal_stream): what a consumer of device-resident results on another stream
+        calls instead of svo_sync()."""
+        self._check(self.lib.svo_signal_stream(self.h, C.c_void_p(stream_handle)))
+
+    def _order_in(self, t):
+        """Tensors torch has just produced (an output's zero fill is a kernel on TORCH's current stream; an input may still
+        be being written there) are ordered before the library's kernels on the device -- no host synchronisation."""
+        import torch
+        self.wait_stream(torch.cuda.current_stream(t.device).cuda_stream)
+
+    def _order_out(self, t):
+        """... and what the library wrote into them before whatever torch's current stream does next."""
+        import torch
+        self.signal_stream(torch.cuda.current_stream(t.device).cuda_stream)
 
     @property
     def num_levels(self):
@@ -249,13 +263,13 @@ class Context:
             n = pts.shape[0]
             out = torch.zeros((n, 2), dtype=torch.float32, device=pts.device)
             st = torch.zeros(n, dtype=torch.uint8, device=pts.device)
-            _torch_ready(st)
+            self._order_in(st)
         pi, mem = _ptr(pts)
         po, _ = _ptr(out)
         ps, _ = _ptr(st)
         self._check(self.lib.svo_lk_track(self.h, slot_prev, slot_next, pi, n, po, ps, mem))
         if mem == MEM_DEVICE:
-            self.sync()
+            self._order_out(st)
         return out, st
 
     def circular_match(self, slots, t1_left):
@@ -268,7 +282,7 @@ class Context:
             import torch
             n = t1_left.shape[0]
             outs = [torch.zeros((max(n, 1), 2), dtype=torch.float32, device=t1_left.device) for _ in range(4)]
-            _torch_ready(outs[0])
+            self._order_in(outs[0])
         pi, mem = _ptr(t1_left)
         m = C.c_int(0)
         self._check(self.lib.svo_circular_match(self.h, *[int(s) for s in slots], pi, n,
@@ -285,13 +299,13 @@ class Context:
         else:
             import torch
             out = torch.zeros((x1.shape[0], 3), dtype=torch.float32, device=x1.device)
-            _torch_ready(out)
+            self._order_in(out)
         p1, mem = _ptr(x1)
         p2, _ = _ptr(x2)
         self._check(self.lib.svo_triangulate(self.h, C.c_void_p(P1.ctypes.data), C.c_void_p(P2.ctypes.data),
                                              p1, p2, x1.shape[0], _ptr(out)[0], mem))
         if mem == MEM_DEVICE:
-            self.sync()
+            self._order_out(out)
         return out
 
     def pnp_ransac(self, obj, img, K, iterations=500, reproj_err=0.5, confidence=0.99):
@@ -303,7 +317,7 @@ class Context:
         else:
             import torch
             mask = torch.zeros(max(obj.shape[0], 1), dtype=torch.uint8, device=obj.device)
-            _torch_ready(mask)
+            self._order_in(mask)
         n = obj.shape[0]
         res = PnPResult()
         po, mem = _ptr(obj)
@@ -312,7 +326,7 @@ class Context:
                                             int(iterations), C.c_float(reproj_err), C.c_double(conf),
                                             C.byref(res), _ptr(mask)[0], mem))
         if mem == MEM_DEVICE:
-            self.sync()
+            self._order_out(mask)
             mask = mask.cpu().numpy()
         return dict(ok=res.ok, rvec=np.array(res.rvec), tvec=np.array(res.tvec),
                     R=np.array(res.R).reshape(3, 3), n_inliers=res.n_inliers,
@@ -355,12 +369,12 @@ class Context:
             import torch
             idx = torch.zeros(max(len(query), 1), dtype=torch.int32, device=query.device)
             dist = torch.zeros(max(len(query), 1), dtype=torch.float32, device=query.device)
-            _torch_ready(dist)
+            self._order_in(dist)
         pq, mem = _ptr(query)
         self._check(self.lib.svo_match_hamming(self.h, pq, len(query), _ptr(train)[0], len(train), _ptr(idx)[0],
                                                _ptr(dist)[0], mem))
         if mem == MEM_DEVICE:
-            self.sync()
+            self._order_out(dist)
         return idx[:len(query)], dist[:len(query)]
 
     # ---- fused API --------------------------------------------------------------------------
@@ -482,10 +496,12 @@ class Context:
             okc = ok.to(torch.int32).contiguous()
             assert T.is_cuda and okc.is_cuda and T.dtype == torch.float64
             out = torch.zeros_like(T)
-            _torch_ready(out)
+            self._order_in(out)
             tp, op_, up, mem = C.c_void_p(T.data_ptr()), C.c_void_p(okc.data_ptr()), C.c_void_p(out.data_ptr()), MEM_DEVICE
         self._check(self.lib.svo_chain_relative(self.h, tp, op_, int(T.shape[0]), p0, up, mem))
-        return out                      # device tensors: complete in stream order on the context's stream
+        if mem == MEM_DEVICE:
+            self._order_out(out)        # device tensors: complete in stream order, for torch's current stream too
+        return out
 
     def frame_keypoints(self, side=0, with_descriptors=False, cap=65536):
         """Keypoints detected on the frame last given to add_frame (svo_get_frame_keypoints)."""

@@ -57,17 +57,22 @@ constexpr int kTilesDw = kSlots * kTileDw2;                                     
 // in four groups of sixteen lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- on 64 banks
 // (MI355X_MICROARCH.md, LDS): with these offsets, a slot stride of 9 x 64 words and the chain lanes placed as in
 // make_lane, the eleven reads of phase 1 and the two of phase 2 are conflict-free in every group (found by search over
-// the orders: tools/model/lds_chain_layout.py).  A (per level, same area): patch words Ix | Iy << 16 of SSE lane q at
-// 52 + q * 108, term 5 row + (x >> 2); the tail's 21 words (x = 20) at 484.
+// the orders: tools/model/lds_chain_layout.py).  A (per level, same area, behind the 52 words a tile may spill into):
+// patch words Ix | Iy << 16 in the order of the A chains (below).
 constexpr int kStageDw = 576;
 constexpr int kTailY = 0, kTailX = 416;
 __device__ constexpr int kChainOff[8] = {108, 196, 372, 284, 328, 240, 524, 152};
-constexpr int kAq0 = kTileSpill, kAqStride = 108, kAtBase = kAq0 + 4 * kAqStride;  // 52, 484
+// A staging: SSE lane q at kAq0 + q * stride, the scalar tail behind the four lanes.  SSE2 order (a.accum = 1): four lanes
+// over x = 0..19 (105 words a lane, stride 108), tail x = 20 (21 words); SIMD128 order (a.accum = 2: the universal-intrinsic
+// block works in groups of EIGHT pixels): four lanes over x = 0..15 (84 words, stride 84), tail x = 16..20 (105 words).
+constexpr int kAq0 = kTileSpill;
+__host__ __device__ constexpr int a_stride(bool simd128) { return simd128 ? 84 : 108; }
+__host__ __device__ constexpr int a_tail_base(bool simd128) { return kAq0 + 4 * a_stride(simd128); }                   // 484 | 388
 constexpr int kLdsDwSse2 = kTilesDw + kSlots * kStageDw + 16;                      // 5024 dwords = 20 096 B (16: the A tail lane reads on past its words)
-constexpr int kDumpB = kChainOff[0] + 43, kDumpA = kAq0 + 105;                     // entries no chain uses: padding of lane chain 0 / of W[0]
-static_assert(kStageDw % 64 == 0 && kTailX % 4 == 0 && kTailY % 4 == 0 && kTilesDw % 4 == 0 && kAq0 % 4 == 0 && kAqStride % 4 == 0,
+constexpr int kDumpB = kChainOff[0] + 43, kDumpA = kStageDw - 1;                    // entries no chain uses: padding of lane chain 0 / the last word of the area
+static_assert(kStageDw % 64 == 0 && kTailX % 4 == 0 && kTailY % 4 == 0 && kTilesDw % 4 == 0 && kAq0 % 4 == 0 && a_stride(false) % 4 == 0 && a_stride(true) % 4 == 0,
               "chain reads are 16-byte loads; the conflict-free order assumes a slot stride of whole bank rounds");
-static_assert(kAtBase + 24 <= kStageDw && kJPairs2 <= kCS2 && kQPairs2 <= kCS2, "staging / tile geometry");
+static_assert(a_tail_base(false) + 24 < kStageDw && a_tail_base(true) + 108 < kStageDw && kJPairs2 <= kCS2 && kQPairs2 <= kCS2, "staging / tile geometry");
 static_assert(kLdsDwSse2 * 4 <= 20480, "eight single-wave workgroups per CU");
 
 typedef uint32_t __attribute__((address_space(3))) lds_u32;
@@ -85,15 +90,16 @@ struct Sse2Lane {
     uint32_t t4mask;        // tail lanes: the high half of pair 0 (pixel 4, x = 20) as a patch pair of its own; group lanes: 0
     uint32_t qoff;          // byte offset of the lane's first tile word inside a slot tile (I and J tiles share the layout)
     uint32_t wb[10];        // b term j of slot 0 goes to LDS byte address wb[j]
-    uint32_t wa_lo, wa_hi[4];   // patch word i < 4 goes to wa_lo + (i * kAqStride) * 4, word 4 + i to wa_hi[i]
+    uint32_t wa[8];         // patch word i (pixel x0 + i) of slot 0 goes to LDS byte address wa[i]
     uint32_t cb, cbA, cbB;  // b chain reads: own terms 0..43; the half row's tail terms 44 + 4 f.., 76 + 4 f.. (f = lane & 7)
     uint32_t ca;            // A chain read address
-    bool b_tail, a_tail;    // position 0 / 8 runs a b tail; position 4 the A tail
+    bool b_tail;            // position 0 / 8 runs a b tail
+    int a_sel;              // which running A sums this lane hands over: after 21, 84 or all 105 terms (0 / 1 / 2)
 };
 
 __device__ __forceinline__ void lds_store(uint32_t byte_addr, uint32_t v) { *(lds_u32 *)(size_t)byte_addr = v; }
 
-__device__ __forceinline__ Sse2Lane make_lane(int lane, uint32_t lds_base)
+__device__ __forceinline__ Sse2Lane make_lane(int lane, uint32_t lds_base, bool simd128)
 {
     Sse2Lane L;
     const bool group = lane < 42, on = lane < 63, tail = on && !group;
@@ -111,14 +117,17 @@ __device__ __forceinline__ Sse2Lane make_lane(int lane, uint32_t lds_base)
         if (tail) e = ((j & 1) ? kTailY : kTailX) + 5 * L.row + (j >> 1);               // tail x | y, term 5 row + i
         L.wb[j] = stage0 + (uint32_t)e * 4;
     }
-    // patch words: pixel i (x = x0 + i) -> W[x & 3][5 row + (x >> 2)];  x = 20 -> tail word `row`;  x > 20: nowhere
-    L.wa_lo = stage0 + (uint32_t)(on ? kAq0 + 5 * L.row + (L.x0 >> 2) : kDumpA) * 4;
+    // patch words.  SSE2 order: pixel x -> W[x & 3][5 row + (x >> 2)] for x < 20, tail word `row` for x = 20.
+    // SIMD128 order: W[x & 3][4 row + (x >> 2)] for x < 16, tail word 5 row + (x - 16) for x = 16..20.  x > 20: nowhere.
+    const int aq = a_stride(simd128), at = a_tail_base(simd128), per_row = simd128 ? 4 : 5;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 8; i++) {
+        const int x = L.x0 + i;
         int e = kDumpA;
-        if (group) e = kAq0 + i * kAqStride + 5 * L.row + (L.x0 >> 2) + 1;
-        if (tail && i == 0) e = kAtBase + L.row;
-        L.wa_hi[i] = stage0 + (uint32_t)e * 4;
+        if (group || (tail && !simd128 && i < 4)) e = kAq0 + (x & 3) * aq + per_row * L.row + (x >> 2);
+        if (tail && !simd128 && i == 4) e = at + L.row;
+        if (tail && simd128 && i < 5) e = at + 5 * L.row + i;
+        L.wa[i] = stage0 + (uint32_t)e * 4;
     }
     // chain roles.  Positions 0 / 8: the x / y tail; 1..4: lane chains 0, 4, 2, 6 (the x sums); 9..12: chains 1, 5, 3, 7;
     // an idle position reads what a busy lane of ITS read group reads (one broadcast access): 5..7 follow position 4,
@@ -132,9 +141,9 @@ __device__ __forceinline__ Sse2Lane make_lane(int lane, uint32_t lds_base)
     L.cb = stage_s + (uint32_t)(fc == 0 ? tail_dw : kChainOff[fc == 0 ? 0 : cmap]) * 4;
     L.cbA = stage_s + (uint32_t)(tail_dw + 44 + 4 * f) * 4;
     L.cbB = L.cbA + 32 * 4;
-    L.a_tail = p == 4;
     // A: positions 0..3 the SSE lanes, 4 the tail; 5..11 follow position 4, 12..15 position 0
-    L.ca = stage_s + (uint32_t)(p < 4 ? kAq0 + p * kAqStride : (p < 12 ? kAtBase : kAq0)) * 4;
+    L.a_sel = simd128 ? (p == 4 ? 2 : 1) : (p == 4 ? 0 : 2);
+    L.ca = stage_s + (uint32_t)(p < 4 ? kAq0 + p * aq : (p < 12 ? at : kAq0)) * 4;
     return L;
 }
 
@@ -327,11 +336,13 @@ __device__ __forceinline__ void a_terms(f32x2 &d, float &m, const u32x4 (&q)[3],
 __device__ __forceinline__ void chain_a(const Sse2Lane &L, float &s11, float &s12, float &s22)
 {
     lds_cu32x4 *p = (lds_cu32x4 *)(size_t)L.ca;
-    f32x2 d = {0.f, 0.f}, d21;                  // (A11, A22)
-    float m = 0.f, m21;                         // A12
+    f32x2 d = {0.f, 0.f}, d21, d84 = {0.f, 0.f};    // (A11, A22)
+    float m = 0.f, m21, m84 = 0.f;                   // A12
     // Three reads (twelve terms) a block, the next block requested before this one is added.  The middle of the chain is
     // a real loop of two blocks a turn: fully unrolled, the function crossed a size at which the register allocator gave
-    // up on the kernel (150 spilled registers, the next level's tile requests among them).
+    // up on the kernel (150 spilled registers, the next level's tile requests among them).  Every lane runs all 105 terms;
+    // which running sum it hands over depends on its chain: 21 terms (the SSE2 order's tail), 84 (the SIMD128 order's
+    // four lanes) or all of them.
     u32x4 q[3], n[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) q[i] = p[i];
@@ -342,7 +353,7 @@ __device__ __forceinline__ void chain_a(const Sse2Lane &L, float &s11, float &s1
 #pragma unroll
     for (int i = 0; i < 3; i++) q[i] = p[6 + i];
     asm volatile("" ::: "memory");
-    a_terms(d, m, n, 0, 9);                     // 12..20: the tail's sums end here
+    a_terms(d, m, n, 0, 9);                     // 12..20
     d21 = d; m21 = m;
     a_terms(d, m, n, 9, 12);                    // 21..23
 #pragma nounroll
@@ -351,13 +362,16 @@ __device__ __forceinline__ void chain_a(const Sse2Lane &L, float &s11, float &s1
         for (int i = 0; i < 3; i++) n[i] = p[9 + i];
         asm volatile("" ::: "memory");
         a_terms(d, m, q, 0, 12);
+        if (turn == 2) { d84 = d; m84 = m; }    // terms 0..83
 #pragma unroll
         for (int i = 0; i < 3; i++) q[i] = p[12 + i];
         asm volatile("" ::: "memory");
         a_terms(d, m, n, 0, 12);
     }
     a_terms(d, m, q, 0, 9);                     // 96..104
-    s11 = L.a_tail ? d21.x : d.x; s12 = L.a_tail ? m21 : m; s22 = L.a_tail ? d21.y : d.y;
+    s11 = L.a_sel == 0 ? d21.x : (L.a_sel == 1 ? d84.x : d.x);
+    s12 = L.a_sel == 0 ? m21 : (L.a_sel == 1 ? m84 : m);
+    s22 = L.a_sel == 0 ? d21.y : (L.a_sel == 1 ? d84.y : d.y);
 }
 // tail + (((q0 + q1) + q2) + q3) at position 0 of the row, handed to the whole row
 __device__ __forceinline__ float combine_a(float r)
@@ -455,10 +469,7 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
                 patch_slot8<false>(qaddr, L, W01s, W23s, ipxs, ipys, w, h, IvP[s], IxP[s], IyP[s], Ix4[s], Iy4[s], Aw);
             const uint32_t so = (uint32_t)(s * kStageDw * 4);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                lds_store(L.wa_lo + so + (uint32_t)(i * kAqStride * 4), Aw[i]);
-                lds_store(L.wa_hi[i] + so, Aw[4 + i]);
-            }
+            for (int i = 0; i < 8; i++) lds_store(L.wa[i] + so, Aw[i]);
         }
         wave_lds_fence();                        // the patch words are complete; the J tiles reuse the I tiles' LDS
 #pragma unroll
@@ -586,7 +597,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int slot = lane >> 4;
     int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
     n = min(n, a.cap);
-    const Sse2Lane L = make_lane(lane, (uint32_t)(size_t)(lds_cu32 *)lds);
+    const Sse2Lane L = make_lane(lane, (uint32_t)(size_t)(lds_cu32 *)lds, a.accum == 2);
     int spw = kSlots;
     if (a.spread) spw = min(kSlots, max(1, (n + a.gx - 1) / a.gx));
     for (int first = wv * spw; first < n; first += a.gx * spw) {

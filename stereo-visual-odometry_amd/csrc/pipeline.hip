@@ -212,7 +212,10 @@ int pipeline_track_batch(svo_ctx *ctx, const uint8_t *left_frames, const uint8_t
     const int n_pairs = n_frames - 1;
     // carry_first: frame 0 of this batch IS the last frame of the previous batch on this context (a stream's halo frame):
     // its features are carried over instead of being computed again
-    const int carry_from = carry_first && ctx->last_batch_pairs > 0 ? ctx->last_batch_pairs : 0;
+    SVO_ARG(!carry_first || ctx->carry_slot > 0, "SVO_CONTINUE_CARRY_FRAME: frame slot of the previous async batch's last frame is no longer valid "
+                                                 "(no such batch, a failed launch, or svo_add_frame / a synchronous batch ran in between)");
+    const int carry_from = carry_first ? ctx->carry_slot : 0;
+    ctx->carry_slot = -1;                        // whatever happens below overwrites frame slots
     ctx->last_batch_pairs = n_pairs;
     mark(ctx, kT0);
     int rc;
@@ -263,6 +266,7 @@ int pipeline_add_frame(svo_ctx *ctx, const uint8_t *left, const uint8_t *right, 
     SVO_ARG(pitch >= ctx->cfg.width, "pitch < width");
     SVO_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE, "bad mem");
     SVO_HIP(hipSetDevice(ctx->device));
+    ctx->carry_slot = -1;                        // the online ring lives in frame slots 0 / 1
     const uint8_t *dL = left, *dR = right;
     int dp = pitch;
     if (mem == SVO_MEM_HOST) {

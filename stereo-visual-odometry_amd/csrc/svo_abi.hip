@@ -145,6 +145,7 @@ static void free_all(svo_ctx *c)
     dev_release(c);                                   // every device buffer: the arena + the lazy extras
     if (c->ev_front) (void)hipEventDestroy(c->ev_front);
     if (c->ev_back) (void)hipEventDestroy(c->ev_back);
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     for (int k = 0; k < 2; k++) {
         if (c->ev_up[k]) (void)hipEventDestroy(c->ev_up[k]);
@@ -179,8 +180,8 @@ extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
     if (cfg->width < 32 || cfg->height < 32 || cfg->max_keypoints < 64 || cfg->max_batch < 1 ||
         cfg->num_slots < 4 || cfg->width > 16384 || cfg->height > 16384)
         return SVO_ERR_ARG;
-    if (cfg->lk_accum != SVO_LK_ACCUM_EXACT && cfg->lk_accum != SVO_LK_ACCUM_SSE2) {
-        fprintf(stderr, "svo_create: lk_accum = %d is neither SVO_LK_ACCUM_EXACT nor SVO_LK_ACCUM_SSE2\n", cfg->lk_accum);
+    if (cfg->lk_accum != SVO_LK_ACCUM_EXACT && cfg->lk_accum != SVO_LK_ACCUM_SSE2 && cfg->lk_accum != SVO_LK_ACCUM_SIMD128) {
+        fprintf(stderr, "svo_create: lk_accum = %d is none of SVO_LK_ACCUM_EXACT / _SSE2 / _SIMD128\n", cfg->lk_accum);
         return SVO_ERR_ARG;
     }
     if (cfg->fast_keep_strongest < 0) return SVO_ERR_ARG;
@@ -339,6 +340,33 @@ extern "C" int svo_wait_results(svo_ctx *ctx)
         SVO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_back, 0));
         ctx->back_pending = false;
     }
+    return SVO_OK;
+}
+
+// ABI v7: ordering against work on OTHER streams on the device, without a host synchronisation.
+extern "C" int svo_wait_stream(svo_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    hipStream_t other = (hipStream_t)hip_stream;
+    if (other == ctx->stream) return SVO_OK;                     // same queue: already ordered
+    SVO_HIP(hipSetDevice(ctx->device));
+    if (!ctx->ev_order) SVO_HIP(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+    SVO_HIP(hipEventRecord(ctx->ev_order, other));
+    SVO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_order, 0));
+    return SVO_OK;
+}
+
+extern "C" int svo_signal_stream(svo_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    hipStream_t other = (hipStream_t)hip_stream;
+    SVO_HIP(hipSetDevice(ctx->device));
+    // the pose stage of an overlap-mode batch ends on the side stream: its event first (kept pending for the context's own waits)
+    if (ctx->back_pending && other != ctx->side_stream) SVO_HIP(hipStreamWaitEvent(other, ctx->ev_back, 0));
+    if (other == ctx->stream) return SVO_OK;
+    if (!ctx->ev_order) SVO_HIP(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+    SVO_HIP(hipEventRecord(ctx->ev_order, ctx->stream));
+    SVO_HIP(hipStreamWaitEvent(other, ctx->ev_order, 0));
     return SVO_OK;
 }
 
@@ -775,10 +803,12 @@ static int frame_buffers(svo_ctx *ctx)
 {
     if (ctx->copy_stream) return SVO_OK;
     const size_t per_cam = (size_t)ctx->stage_pitch * ctx->cfg.height * (size_t)(ctx->cfg.max_batch + 1);
+    // every resource behind its own guard: a call that failed half way leaves what it made for the next attempt
+    // (copy_stream, made last, is what marks the set complete)
     for (int k = 0; k < 2; k++) {
-        if (dev_alloc(ctx, &ctx->fb[k], 2 * per_cam) != SVO_OK) return SVO_ERR_HIP;
-        SVO_HIP(hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming));
-        SVO_HIP(hipEventCreateWithFlags(&ctx->ev_fb_free[k], hipEventDisableTiming));
+        if (!ctx->fb[k] && dev_alloc(ctx, &ctx->fb[k], 2 * per_cam) != SVO_OK) return SVO_ERR_HIP;
+        if (!ctx->ev_up[k]) SVO_HIP(hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming));
+        if (!ctx->ev_fb_free[k]) SVO_HIP(hipEventCreateWithFlags(&ctx->ev_fb_free[k], hipEventDisableTiming));
     }
     SVO_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     return SVO_OK;
@@ -857,6 +887,9 @@ extern "C" int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, con
         if (!ctx->fetch_stream) SVO_HIP(hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking));
         ctx->async_ready = true;
     }
+    SVO_ARG((continue_chain & ~(SVO_CONTINUE_CHAIN | SVO_CONTINUE_CARRY_FRAME)) == 0, "unknown continue_chain bits");
+    SVO_ARG(!(continue_chain & SVO_CONTINUE_CARRY_FRAME) || (continue_chain & SVO_CONTINUE_CHAIN),
+            "SVO_CONTINUE_CARRY_FRAME without SVO_CONTINUE_CHAIN: the carried frame belongs to the chain being continued");
     if (continue_chain) {
         SVO_ARG(ctx->async_tail > 0, "continue_chain needs a previous async batch");
         const int pr = r ^ 1;
@@ -877,6 +910,7 @@ extern "C" int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, con
     ctx->async_n[r] = n_pairs;
     ctx->async_last_pairs = n_pairs;
     ctx->async_tail++;
+    ctx->carry_slot = n_pairs;                   // frame slot n_pairs now holds this batch's last frame
     return rc;
 }
 

@@ -60,6 +60,9 @@ struct svo_ctx {
     int online_frames = 0;            // frames fed since reset
     int online_cur = 0;               // which half of the 2-frame ring holds the latest frame
     int last_batch_pairs = 0;         // pairs of the most recent batch launch (svo_get_batch_tracks)
+    int carry_slot = -1;              // frame slot that still holds the LAST frame of the previous async batch (its pyramids /
+                                      // keypoints / descriptors): set only by a successful svo_track_uploaded_async, dropped by
+                                      // every other entry point that writes frame slots (SVO_CONTINUE_CARRY_FRAME needs it)
     int online_tracked = 0;           // tracks of the last svo_add_frame pair (0 when it stopped before matching)
     double pose[16];
     // ---- ORB path (allocated on first use: orb_alloc)
@@ -97,6 +100,7 @@ struct svo_ctx {
     hipStream_t fetch_stream = nullptr;
     bool async_ready = false;                 // d_async / ev_async / fetch_stream all exist (set after the last of them succeeded)
     hipEvent_t ev_front = nullptr, ev_back = nullptr;
+    hipEvent_t ev_order = nullptr;    // svo_wait_stream / svo_signal_stream (made on first use)
     bool back_pending = false;
     int *kp_n_snap = nullptr;         // n_prev / n_cur (/ ORB capacity flags) of the batch the pose stage works on: 3 x max_batch
     // ---- timing

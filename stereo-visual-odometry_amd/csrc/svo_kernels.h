@@ -48,7 +48,7 @@ struct LkArgs {
     uint8_t *status[kMaxChain];
     uint8_t *keep;                                // ncalls == 4: deleteBadmatchFeatures predicate
     float match_err_f; double match_err;          // feature_match_error
-    int accum;                                    // svo_config.lk_accum: SVO_LK_ACCUM_EXACT (lk.hip) or _SSE2 (lk_sse2.hip)
+    int accum;                                    // svo_config.lk_accum: SVO_LK_ACCUM_EXACT (lk.hip), _SSE2 or _SIMD128 (lk_sse2.hip)
     int gx, batch, spread;                                // filled by launch_lk: workgroups (sse2: waves) per item, items
 };
 void launch_lk(const LkArgs &a, int batch, int max_pts, hipStream_t st);

@@ -81,7 +81,7 @@ private:
     int device_ = 0;
     long max_keypoints_key_ = 0;                             // additive YAML key max_keypoints, read once (0 = absent)
     int fast_keep_strongest_ = 0;                            // additive YAML key fast_keep_strongest (0 = every corner)
-    int lk_accum_ = SVO_LK_ACCUM_EXACT;                      // additive YAML key lk_accum: exact (default) | sse2
+    int lk_accum_ = SVO_LK_ACCUM_EXACT;                      // additive YAML key lk_accum: exact (default) | sse2 | simd128
     int ctx_w_ = 0, ctx_h_ = 0, ctx_batch_ = 0;
     int async_pairs_[2] = {0, 0};
     unsigned async_head_ = 0, async_tail_ = 0;

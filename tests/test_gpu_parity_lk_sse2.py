@@ -1,7 +1,8 @@
-"""svo_config.lk_accum = SVO_LK_ACCUM_SSE2 (-m gpu): the HIP LK kernel that accumulates A11, A12, A22, b1, b2 in
-float in the lane order of upstream's CV_SSE2 block (csrc/lk_sse2.hip) against the oracle in the same mode
-(oracle/lk.c, orc_lk_set_accum(2)) -- what an x86 OpenCV 3 computes inside the reference's four
-cv::calcOpticalFlowPyrLK calls (src/tracking.cpp:593-618).  Same bars as the exact mode: points, status bytes,
+"""svo_config.lk_accum = SVO_LK_ACCUM_SSE2 / _SIMD128 (-m gpu): the HIP LK kernel that accumulates A11, A12, A22, b1, b2 in
+float in a lane order of upstream's x86 SIMD code (csrc/lk_sse2.hip) against the oracle in the same mode
+(oracle/lk.c, orc_lk_set_accum(2) / (4)) -- the orders restated from lkpyramid.cpp for the reference's four
+cv::calcOpticalFlowPyrLK calls (src/tracking.cpp:593-618; not validated against an OpenCV binary: tests/test_cv_crosscheck.py
+does that where cv2 exists).  Same bars as the exact mode: points, status bytes,
 tracks, RANSAC masks and iteration numbers bit for bit, the chained pose within 1e-4 (north_star) and within the
 observed 1e-9.  Stage level (random images, window over the edge, one to thousands of points), BASELINE
 config #1's 100 S0 pairs (batched and online), a second seed, and config #4's 1920x1080 step on exactly the
@@ -28,6 +29,15 @@ def tc():
 @contextlib.contextmanager
 def sse2_oracle(oracle):
     old = oracle.set_lk_accum(oracle.LK_ACCUM_FLOAT_SSE)
+    try:
+        yield
+    finally:
+        oracle.set_lk_accum(old)
+
+
+@contextlib.contextmanager
+def accum_oracle(oracle, mode):
+    old = oracle.set_lk_accum(mode)
     try:
         yield
     finally:
@@ -190,3 +200,33 @@ def test_hd_sse2_whole_step_on_exactly_2000_strongest_corners(pkg, oracle, tc, s
         rc, pose_g, _ = oracle.gate_and_accumulate(sg["R"], sg["tvec"], pose_g)
         assert rc >= 0 and relfro(pose_g, pose_r) <= POSE_TOL and relfro(pose_g, pose_r) <= TIGHT * 10
     c.close()
+
+
+# ---- SVO_LK_ACCUM_SIMD128 (ABI v7): the universal-intrinsic block restated whole = oracle mode 4 ----------------------------
+@pytest.mark.parametrize("w,h,n,seed", [(416, 128, 5, 4), (333, 201, 700, 5), (1241, 376, 3000, 6)])
+def test_lk_track_simd128_points_and_status(pkg, oracle, w, h, n, seed):
+    prev, nxt = _shifted_pair(h, w, seed)
+    rng = np.random.default_rng(seed)
+    pts = np.stack([rng.uniform(-3, w + 3, n), rng.uniform(-3, h + 3, n)], 1).astype(np.float32)
+    pts[: n // 4] = np.round(pts[: n // 4])
+    c = pkg.Context(w, h, device=0, max_keypoints=max(n, 64), lk_accum=pkg.LK_ACCUM_SIMD128)
+    c.build_pyramid(0, prev)
+    c.build_pyramid(1, nxt)
+    got, st = c.lk_track(0, 1, pts)
+    c.close()
+    with accum_oracle(oracle, oracle.LK_ACCUM_SIMD128):
+        want, wst = oracle.lk_track(prev, nxt, pts)
+    with sse2_oracle(oracle):
+        other, _ = oracle.lk_track(prev, nxt, pts)
+    assert st.tobytes() == wst.tobytes() and got.tobytes() == want.tobytes()
+    if n >= 700:
+        assert want.tobytes() != other.tobytes()                 # the A order does change bits against the sse2 mode
+
+
+def test_lk_simd128_24_pairs_batched_and_online(pkg, oracle, tc, synth):
+    seq, frames = _render(synth, tc, 1241, 376, 25, 20200710)
+    with accum_oracle(oracle, oracle.LK_ACCUM_SIMD128):
+        ref = _oracle_lk_sequence(oracle, seq, frames)
+    assert all(r["ok"] for r, _, _, _ in ref)
+    _check_batch(pkg, tc, seq, frames, ref, lk_accum=pkg.LK_ACCUM_SIMD128)
+    _check_online(pkg, seq, frames[:9], ref[:8], lk_accum=pkg.LK_ACCUM_SIMD128)
