@@ -53,6 +53,15 @@ public:
     // additive: the HIP device this System's context lives on (before the first frame; default 0), and the
     // sequence it will read: the dataset directory and the number of consecutive stereo frames found there
     void SetDevice(int device) { tracking_->SetDevice(device); }
+    // additive (SURVEY.md 8e granularity 2 / 8f rank 1, RunSplitPairs below): this System tracks only the frames
+    // first .. last of its sequence -- a contiguous chunk of frame pairs with its one-frame halo -- through the batched
+    // runner, and hands the step records (relative motions) to `sink` instead of writing pose rows
+    void SetFrameRange(int first, int last) { frame_base_ = first; frame_last_ = last; }
+    void SetRecordSink(std::vector<svo_step_result> *sink) { record_sink_ = sink; }
+    void SetBatchSize(int b) { batch_size_ = b; }
+    int BatchSize() const { return batch_size_; }
+    bool Failed() const { return run_failed_; }
+    void CloseOutputs();                                     // flushes and closes the pose / tracks files, waits for the device (fast exit)              // a stream / batch submission failed: the pose file is short
     const std::string &DatasetPath() const { return dataset_path_; }
     int CountFrames() const;
 
@@ -78,6 +87,9 @@ private:
     // another System may have loaded ITS file by the time Run() is called)
     int batch_size_ = 1, decode_threads_ = 0;
     double loop_seconds_ = 0;
+    int frame_base_ = 0, frame_last_ = -1;                   // SetFrameRange (last < 0: to the end of the sequence)
+    std::vector<svo_step_result> *record_sink_ = nullptr;
+    bool run_failed_ = false;
     // RunBatched's page-locked chunk buffers: kept for the next run of this System, released with it (un-pinning half a
     // gigabyte is a fifth of a short run's wall time, and a process about to exit need not do it)
     uint8_t *batch_pin_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
@@ -112,6 +124,17 @@ bool ReadImageGrayInto(const std::string &path, uint8_t *dst, int pitch, int w, 
 struct SequenceReport { std::string yaml; int device = 0, worker = 0, frames = 0; double seconds = 0; bool ok = false; };
 int RunSequences(const std::vector<std::string> &yamls, const std::vector<std::string> &pose_files, int n_devices,
                  std::vector<SequenceReport> *report);
+
+// additive (SURVEY.md 8e granularity 2 / 8f rank 1): ONE sequence cut into `n_parts` contiguous chunks of frame pairs with a
+// one-frame halo (chunk c needs the frame before its first pair), chunk c -> its own worker thread, System and context on
+// device c % n_devices; every chunk is tracked by the batched runner from the identity, its relative motions
+// (svo_step_result.T_rel_inv, ok) are gathered and chained ONCE by svo_chain_relative -- the `frame_pose_ *= T.inv()`
+// recurrence of reference src/tracking.cpp:318 --, and the pose file is byte for byte what the single-context run
+// writes.  What `bench.py --shard pairs` does with one process per GPU; removes the sequence-length imbalance of
+// RunSequences (KITTI 00-07 on 8 devices: max / mean 2.28).  `run_kitti_stereo cfg.yaml [poses] --split-pairs N [--devices D]`.
+// Returns 0 on success; report (may be null) gets one entry per chunk.
+int RunSplitPairs(const std::string &yaml, const std::string &pose_file, int n_parts, int n_devices,
+                  std::vector<SequenceReport> *report);
 
 }  // namespace lzb_vio
 #endif

@@ -265,6 +265,9 @@ System::System(std::string &config_path) : config_file_path_(config_path)
     batch_size_ = Config::Has("batch_size") ? Config::Get<int>("batch_size") : 1;
     decode_threads_ = Config::Has("decode_threads") ? Config::Get<int>("decode_threads") : 0;    // 0: the usable cores
     stream_depth_ = Config::Has("stream_depth") ? Config::Get<int>("stream_depth") : 0;           // 0: Step_ros is synchronous
+    if (stream_depth_ > 0 && tracks_file_)
+        LZB_LOG("WARNING", "tracks_file is set together with stream_depth: the pipelined stream keeps poses only, the tracks file "
+                           "will hold its header and nothing else (use the per-frame loop or batch_size for track dumps)");
 }
 
 System::~System()
@@ -359,9 +362,13 @@ void System::Run()
             Frame::Ptr f = NextFrame_kitti();
             if (f == nullptr || !Step_ros(f)) break;
         }
+        // whatever was launched is collected even when a later push or submission failed (its poses are complete on the
+        // GPU); the failure is kept for the caller's exit code
         std::vector<Pose4x4> poses;
-        if (StreamFlush()) StreamPoll(poses, true);
+        if (!StreamFlush()) run_failed_ = true;
+        StreamPoll(poses, true);
         for (const auto &P : poses) WritePoseRow(P.m);
+        if (stream_.failed) run_failed_ = true;
         Shutdown();
         return;
     }
@@ -440,7 +447,7 @@ Frame::Ptr System::NextFrame_kitti()
 void System::RunBatched(int B, int decode_threads)
 {
     cv::Mat l0, r0;
-    if (!ReadStereo(0, l0, r0)) { LZB_LOG("WARNING", "cannot find images at index %d", 0); return; }
+    if (!ReadStereo(frame_base_, l0, r0)) { LZB_LOG("WARNING", "cannot find images at index %d", frame_base_); return; }
     const int w = l0.cols, h = l0.rows;
     if (r0.cols != w || r0.rows != h) { LZB_LOG("ERROR", "left/right size mismatch at index %d", 0); return; }
     LZB_PHASE("first frame read (size known)");
@@ -471,6 +478,9 @@ void System::RunBatched(int B, int decode_threads)
     // decodes frames first .. first+count-1 into slots slot0.. of buffer k; returns how many
     // consecutive frames (from `first`) were read
     auto decode = [&](int k, int slot0, int first, int count) -> int {
+        first += frame_base_;                               // SetFrameRange: this System's frame 0 is the sequence's frame_base_
+        if (frame_last_ >= 0 && first + count - 1 > frame_last_) count = frame_last_ - first + 1;
+        if (count <= 0) return 0;
         std::vector<char> ok((size_t)count * 2, 0);
         std::atomic<int> next_item(0);
         auto work = [&]() {
@@ -531,13 +541,16 @@ void System::RunBatched(int B, int decode_threads)
     int k = 0, next = 0;
     next = cur_n;
     current_image_index_ = cur_n > 0 ? 1 : 0;
-    if (cur_n > 0) WritePose();                             // frame 0: StereoInit_f2f, pose = identity
+    if (cur_n > 0 && !record_sink_) WritePose();            // frame 0: StereoInit_f2f, pose = identity
     std::vector<svo_step_result> recs;
     auto flush = [&](double seconds, int pairs) {           // the oldest outstanding chunk's records -> pose file
         recs.clear();
         if (!tracking_->CollectUploaded(recs)) return false;
         if (getenv("LZB_VIO_VERBOSE")) LZB_LOG("INFO", "VO cost time: %f seconds for %d pairs", seconds, pairs);
-        for (const auto &r : recs) { WritePoseRow(r.pose); current_image_index_++; }
+        for (const auto &r : recs) {
+            if (record_sink_) record_sink_->push_back(r); else WritePoseRow(r.pose);
+            current_image_index_++;
+        }
         return true;
     };
     bool ok = cur_n >= 2 && upload(0, cur_n);
@@ -575,6 +588,7 @@ void System::RunBatched(int B, int decode_threads)
         chunk++;
     }
     while (ok && outstanding > 0) { ok = flush(0.0, 0); outstanding--; }
+    if (!ok && cur_n >= 2) run_failed_ = true;              // an upload / launch / collect failed: the caller must not report success
     svo_sync(ctx);
     loop_seconds_ = decode0_seconds + std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
     LZB_PHASE("loop done (last pose row written)");
@@ -670,6 +684,7 @@ bool System::StreamPush(Frame::Ptr frame)
 int System::StreamPoll(std::vector<Pose4x4> &poses, bool wait)
 {
     while (StreamCollect(false)) {}
+    // wait: drain every outstanding micro-batch, also after a failed push / submission (a failed COLLECT ends it)
     if (wait) while (tracking_->Outstanding() > 0 && StreamCollect(true)) {}
     const int n = (int)stream_.done.size();
     poses.insert(poses.end(), stream_.done.begin(), stream_.done.end());
@@ -681,6 +696,13 @@ bool System::StreamFlush()
 {
     if (!stream_.active || stream_.failed) return stream_.active && !stream_.failed;
     return StreamSubmit();
+}
+
+void System::CloseOutputs()
+{
+    if (pose_file_) { fclose(pose_file_); pose_file_ = nullptr; }
+    if (tracks_file_) { fclose(tracks_file_); tracks_file_ = nullptr; }
+    if (tracking_ && tracking_->Context()) svo_sync(tracking_->Context());
 }
 
 void System::Shutdown() {}
@@ -755,6 +777,87 @@ int RunSequences(const std::vector<std::string> &yamls, const std::vector<std::s
     for (const auto &r : rep) failed += r.ok ? 0 : 1;
     if (report) *report = rep;
     return failed;
+}
+
+// ---- one sequence, frame pairs dealt to several contexts ------------------------------------------------
+int RunSplitPairs(const std::string &yaml, const std::string &pose_file, int n_parts, int n_devices,
+                  std::vector<SequenceReport> *report)
+{
+    if (n_devices <= 0 && (svo_device_count(&n_devices) != SVO_OK || n_devices <= 0)) {
+        LZB_LOG("ERROR", "no HIP device: %s not run (there is no CPU path)", yaml.c_str());
+        return 1;
+    }
+    std::string path = yaml;
+    std::unique_ptr<System> probe(new System(path));
+    const int n_frames = probe->CountFrames();
+    const int n_pairs = n_frames - 1;
+    const int default_batch = probe->BatchSize() > 1 ? probe->BatchSize() : 256;
+    probe.reset();
+    if (n_pairs < 1) { LZB_LOG("ERROR", "%s: fewer than two stereo frames", yaml.c_str()); return 1; }
+    if (n_parts < 1) n_parts = 1;
+    if (n_parts > n_pairs) n_parts = n_pairs;
+    FILE *out = nullptr;
+    if (!pose_file.empty() && !(out = fopen(pose_file.c_str(), "w"))) {
+        LZB_LOG("ERROR", "cannot open %s for writing", pose_file.c_str());
+        return 1;
+    }
+    // contiguous chunks, sizes differing by at most one (multigpu.shard_pairs); chunk c = pairs first[c] .. first[c] + n[c] - 1
+    // = frames first[c] .. first[c] + n[c]
+    std::vector<std::unique_ptr<System>> sys((size_t)n_parts);
+    std::vector<std::vector<svo_step_result>> recs((size_t)n_parts);
+    std::vector<int> first((size_t)n_parts), cnt((size_t)n_parts);
+    const int base = n_pairs / n_parts, extra = n_pairs % n_parts;
+    for (int c = 0; c < n_parts; c++) {
+        first[(size_t)c] = c * base + (c < extra ? c : extra);
+        cnt[(size_t)c] = base + (c < extra ? 1 : 0);
+        std::string p = yaml;
+        sys[(size_t)c].reset(new System(p));             // built one after the other: Config is process-wide
+        sys[(size_t)c]->SetFrameRange(first[(size_t)c], first[(size_t)c] + cnt[(size_t)c]);
+        sys[(size_t)c]->SetRecordSink(&recs[(size_t)c]);
+        sys[(size_t)c]->SetBatchSize(default_batch < cnt[(size_t)c] ? default_batch : (cnt[(size_t)c] > 1 ? cnt[(size_t)c] : 2));
+        sys[(size_t)c]->SetDevice(c % n_devices);
+    }
+    std::vector<SequenceReport> rep((size_t)n_parts);
+    std::vector<std::thread> pool;
+    for (int c = 0; c < n_parts; c++)
+        pool.emplace_back([&, c]() {
+            SequenceReport &r = rep[(size_t)c];
+            r.yaml = yaml; r.device = c % n_devices; r.worker = c;
+            const auto t0 = std::chrono::steady_clock::now();
+            sys[(size_t)c]->Run();
+            r.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            r.frames = (int)recs[(size_t)c].size() + 1;
+            r.ok = (int)recs[(size_t)c].size() == cnt[(size_t)c] && !sys[(size_t)c]->Failed();
+        });
+    for (auto &th : pool) th.join();
+    int failed = 0;
+    for (int c = 0; c < n_parts; c++) {
+        fprintf(stderr, "chunk %d (device %d): frames %d..%d, %d pairs, %.3f s%s\n", c, rep[(size_t)c].device, first[(size_t)c],
+                first[(size_t)c] + cnt[(size_t)c], cnt[(size_t)c], rep[(size_t)c].seconds, rep[(size_t)c].ok ? "" : "  [FAILED]");
+        failed += rep[(size_t)c].ok ? 0 : 1;
+    }
+    if (report) *report = rep;
+    if (failed) { if (out) fclose(out); return failed; }
+    // the gather (17 doubles a pair) and the one serial step: the prefix product, on chunk 0's context
+    std::vector<double> T((size_t)n_pairs * 16), poses((size_t)n_pairs * 16);
+    std::vector<int32_t> okv((size_t)n_pairs);
+    size_t p = 0;
+    for (int c = 0; c < n_parts; c++)
+        for (const auto &r : recs[(size_t)c]) { memcpy(&T[p * 16], r.T_rel_inv, sizeof(double) * 16); okv[p] = r.ok; p++; }
+    svo_ctx *ctx = sys[0]->GetTracking()->Context();
+    if (!ctx || svo_chain_relative(ctx, T.data(), okv.data(), n_pairs, nullptr, poses.data(), SVO_MEM_HOST) != SVO_OK) {
+        LZB_LOG("ERROR", "svo_chain_relative: %s", ctx ? svo_last_error(ctx) : "no context");
+        if (out) fclose(out);
+        return 1;
+    }
+    if (out) {
+        const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        for (int i = 0; i < 12; i++) fprintf(out, "%.9e%c", I[i], i == 11 ? '\n' : ' ');
+        for (int q = 0; q < n_pairs; q++)
+            for (int i = 0; i < 12; i++) fprintf(out, "%.9e%c", poses[(size_t)q * 16 + i], i == 11 ? '\n' : ' ');
+        fclose(out);
+    }
+    return 0;
 }
 
 }  // namespace lzb_vio

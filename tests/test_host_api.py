@@ -487,3 +487,44 @@ def test_run_kitti_stereo_multi_sequence(host_built, synth, tmp_path):
     # a pose file that cannot be opened: that sequence is not run and counts as failed (exit code 1), not silently dropped
     r = subprocess.run([exe, yamls[0], yamls[1], "--poses-dir", str(tmp_path / "no_such_dir")], capture_output=True, timeout=300)
     assert r.returncode == 1 and r.stderr.decode().count("[FAILED]") == 2 and "is not run" in r.stderr.decode()
+
+
+@pytest.mark.gpu
+def test_run_kitti_stereo_split_pairs(host_built, synth, tmp_path):
+    """`run_kitti_stereo cfg.yaml poses --split-pairs N` (lzb_vio::RunSplitPairs, SURVEY.md 8e granularity 2 / 8f rank 1):
+    ONE sequence cut into N chunks of frame pairs with a one-frame halo, a context per chunk (here all on the one card),
+    the relative motions chained once -- the pose file equals the single-context run's byte for byte, in both modes and
+    for chunk counts that do and do not divide the pairs; the orderly-teardown exit (the default) and the fast one agree."""
+    exe = os.path.join(host_built, "run_kitti_stereo")
+    for name, n, seed, mode in (("lk", 14, 31, "LK_stereof2f_pnp"), ("orb", 9, 32, "ORB_stereof2f_pnp")):
+        seq = synth.StereoSequence(width=416, height=128, n_frames=n, seed=seed)
+        d = tmp_path / name
+        for cam in (0, 1):
+            os.makedirs(d / f"image_{cam}")
+        for t in range(n):
+            L, R = (x.numpy() for x in seq.render(t))
+            _write_pgm(d / "image_0" / f"{t:06d}.pgm", L)
+            _write_pgm(d / "image_1" / f"{t:06d}.pgm", R)
+        y = tmp_path / f"{name}.yaml"
+        _write_yaml(y, str(d), fx=seq.fx, fy=seq.fy, cx=seq.cx, cy=seq.cy, mode=mode)
+        with open(y, "a", encoding="utf-8") as f:
+            f.write("batch_size: 4\n")
+        r = subprocess.run([exe, str(y), str(y) + ".single.txt"], capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        want = open(str(y) + ".single.txt", "rb").read()
+        assert len(want.splitlines()) == n
+        r = subprocess.run([exe, str(y), str(y) + ".fast.txt"], capture_output=True, timeout=300, env=dict(os.environ, LZB_VIO_FAST_EXIT="1"))
+        assert r.returncode == 0 and open(str(y) + ".fast.txt", "rb").read() == want
+        for parts in (2, 3, 5):
+            out = str(y) + f".split{parts}.txt"
+            r = subprocess.run([exe, str(y), out, "--split-pairs", str(parts)], capture_output=True, timeout=300)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            assert r.stderr.decode().count("chunk ") == parts
+            assert open(out, "rb").read() == want, (name, parts)
+    # more chunks than pairs: clamped; a sequence that cannot be read: exit code 1
+    r = subprocess.run([exe, str(y), str(y) + ".many.txt", "--split-pairs", "64"], capture_output=True, timeout=300)
+    assert r.returncode == 0 and open(str(y) + ".many.txt", "rb").read() == want
+    bad = tmp_path / "bad.yaml"
+    _write_yaml(bad, str(tmp_path / "nowhere"))
+    r = subprocess.run([exe, str(bad), str(tmp_path / "bad.txt"), "--split-pairs", "2"], capture_output=True, timeout=300)
+    assert r.returncode == 1

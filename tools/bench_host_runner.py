@@ -49,7 +49,7 @@ def main():
         poses = {}
         for name in (("batched",) if os.environ.get("SVO_SKIP_ONLINE") else ("online", "batched")):
             t0 = time.perf_counter()
-            r = subprocess.run([os.path.join(host, "run_kitti_stereo"), os.path.join(d, name + ".yaml"),
+            r = subprocess.run([os.path.join(host, "run_kitti_stereo"), os.path.join(d, name + ".yaml"),  # (orderly teardown: the default)
                                 os.path.join(d, name + ".txt")], capture_output=True)
             el = time.perf_counter() - t0
             assert r.returncode == 0, r.stderr.decode()
