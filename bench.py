@@ -152,6 +152,15 @@ def kernel_source_hash(sse2=False):
     return h.hexdigest()[:16]
 
 
+def orb_source_hash():
+    """sha256 over the sources of the ORB kernels (tools/gpu/orb_pmc_json.py writes the same into its profile)."""
+    h = hashlib.sha256()
+    for f in ("orb.hip", "orb_pattern.h", "svo_device.h", "svo_kernels.h"):
+        with open(os.path.join(entry.PKG_DIR, "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def newest_profile(name, src_hash=None):
     """profiles/rNN_<name>_pmc.json of the highest round (whose source hash matches, when one is given)."""
     import glob
@@ -163,7 +172,7 @@ def newest_profile(name, src_hash=None):
     return None
 
 
-def roofline_lk(stage_ms, pts_total, B, sse2=False):
+def roofline_lk(stage_ms, pts_total, B, sse2=False, profile=None):
     """The LK launch of a mean step against the HBM roof (4257 algorithmic bytes per point per call,
     4 fused calls per launch) and against the VALU issue roof it actually sits under; the profile-derived fields
     (PMC traffic, instruction count) are valid only for the kernel source they were measured on."""
@@ -172,7 +181,9 @@ def roofline_lk(stage_ms, pts_total, B, sse2=False):
     alg_bytes = pts_total * 4 * LK_BYTES_PER_POINT_CALL
     achieved = alg_bytes / (lk_ms * 1e-3) / 1e9
     traffic, valu = None, None
-    prof = newest_profile("lk_sse2" if sse2 else "lk", src_hash) if B == 256 else None
+    # profile-derived fields belong to ONE workload: the 256-pair S0 step (profiles/rNN_lk[_sse2]_pmc.json) or, for the hd leg
+    # (profile = "hd_lk"), the 128-pair 1920x1080 step on 2000 corners (tools/gpu/prof_hd.sh)
+    prof = newest_profile(profile, src_hash) if profile else (newest_profile("lk_sse2" if sse2 else "lk", src_hash) if B == 256 else None)
     if prof:
         traffic = prof.get("traffic_bytes")
         n_valu = prof.get("valu_wave_instructions")
@@ -203,7 +214,7 @@ def roofline_orb(stage_ms, B, w, h):
     cf_ms = stage_ms["orb_cellfast"]
     alg_bytes = int(3.09 * w * h * 2 * (B + 1))
     achieved = alg_bytes / (cf_ms * 1e-3) / 1e9
-    oprof = newest_profile("orb") if B == 256 else None
+    oprof = newest_profile("orb", orb_source_hash()) if B == 256 else None      # only a profile of THESE kernel sources
     return {"bound": "hbm", "kernel": "orb_cellfast_kernel (one launch per step over all pyramid levels)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": (oprof or {}).get("cellfast_traffic_bytes"), "profile": (oprof or {}).get("_file"),
@@ -881,7 +892,7 @@ def main():
                 pts = int(round(float(recs["n_prev_kps"].mean()) * Bh))
                 extra = {"definition": "BASELINE config #4: synthetic 1920x1080 stereo stream, fast_keep_strongest = 2000 (the 2000 "
                                        "highest-response FAST(20) corners of every frame, ties by raster order), FAST+LK",
-                         "roofline": roofline_lk(st_ms, pts, Bh) if st_ms.get("lk") else None}
+                         "roofline": roofline_lk(st_ms, pts, Bh, profile="hd_lk" if Bh == 128 else None) if st_ms.get("lk") else None}
                 if O is not None and args.cpu_pairs > 0:
                     n1 = max(2, min(args.cpu_pairs // 12, Bh))
                     prm = O.make_params(P1h, P2h)

@@ -247,6 +247,11 @@ int svo_host_alloc(svo_ctx *ctx, size_t bytes, void **out);   /* ctx may be NULL
 int svo_host_free(svo_ctx *ctx, void *p);
 int svo_upload_frames(svo_ctx *ctx, int buf, const uint8_t *left_frames, const uint8_t *right_frames,
                       int pitch, int64_t frame_stride, int n_frames);
+/* ABI v7: the same into frame slots first_slot .. first_slot + n_frames - 1 of the buffer (svo_upload_frames = first_slot 0).
+ * A stream's micro-batch whose frame 0 is CARRIED on the device (SVO_CONTINUE_CARRY_FRAME) uploads its new frames only:
+ * first_slot = 1; slot 0 is then never read. */
+int svo_upload_frames_at(svo_ctx *ctx, int buf, int first_slot, const uint8_t *left_frames, const uint8_t *right_frames,
+                         int pitch, int64_t frame_stride, int n_frames);
 int svo_wait_upload(svo_ctx *ctx, int buf);
 int svo_track_uploaded(svo_ctx *ctx, int buf, int n_frames, const double *pose0,
                        svo_step_result *results, int results_mem);

@@ -99,6 +99,9 @@ def load_library():
     lib.svo_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
     lib.svo_host_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.svo_upload_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]
+    lib.svo_upload_frames_at.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]
+    lib.svo_wait_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.svo_signal_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.svo_wait_upload.argtypes = [C.c_void_p, C.c_int]
     lib.svo_track_uploaded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     lib.svo_track_uploaded_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -434,11 +437,14 @@ class Context:
         p = self._pinned.pop(view.ctypes.data)
         self._check(self.lib.svo_host_free(self.h, p))
 
-    def upload_frames(self, buf, left, right):
-        """left/right: (F, height, pitch) uint8 host arrays (ideally from host_frames); asynchronous."""
+    def upload_frames(self, buf, left, right, first_slot=0):
+        """left/right: (F, height, pitch) uint8 host arrays (ideally from host_frames); asynchronous.  first_slot: the frame
+        slot of the device buffer the first of them goes to (svo_upload_frames_at: a stream whose halo frame is carried on
+        the device uploads its new frames into slots 1..)."""
         assert left.shape == right.shape and left.strides == right.strides and left.strides[2] == 1
-        self._check(self.lib.svo_upload_frames(self.h, int(buf), C.c_void_p(left.ctypes.data), C.c_void_p(right.ctypes.data),
-                                               int(left.strides[1]), int(left.strides[0]), int(left.shape[0])))
+        self._check(self.lib.svo_upload_frames_at(self.h, int(buf), int(first_slot), C.c_void_p(left.ctypes.data),
+                                                  C.c_void_p(right.ctypes.data), int(left.strides[1]), int(left.strides[0]),
+                                                  int(left.shape[0])))
 
     def wait_upload(self, buf):
         self._check(self.lib.svo_wait_upload(self.h, int(buf)))

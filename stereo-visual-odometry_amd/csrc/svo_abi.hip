@@ -814,13 +814,21 @@ static int frame_buffers(svo_ctx *ctx)
     return SVO_OK;
 }
 
+extern "C" int svo_upload_frames_at(svo_ctx *ctx, int buf, int first_slot, const uint8_t *left_frames, const uint8_t *right_frames,
+                                    int pitch, int64_t frame_stride, int n_frames);
 extern "C" int svo_upload_frames(svo_ctx *ctx, int buf, const uint8_t *left_frames, const uint8_t *right_frames,
                                  int pitch, int64_t frame_stride, int n_frames)
+{
+    return svo_upload_frames_at(ctx, buf, 0, left_frames, right_frames, pitch, frame_stride, n_frames);
+}
+
+extern "C" int svo_upload_frames_at(svo_ctx *ctx, int buf, int first_slot, const uint8_t *left_frames, const uint8_t *right_frames,
+                                    int pitch, int64_t frame_stride, int n_frames)
 {
     if (!ctx) return SVO_ERR_ARG;
     SVO_ARG(buf == 0 || buf == 1, "buf must be 0 or 1");
     SVO_ARG(left_frames && right_frames, "null frames");
-    SVO_ARG(n_frames >= 1 && n_frames <= ctx->cfg.max_batch + 1, "n_frames must be in [1, max_batch + 1]");
+    SVO_ARG(first_slot >= 0 && n_frames >= 1 && first_slot + n_frames <= ctx->cfg.max_batch + 1, "first_slot + n_frames must be in [1, max_batch + 1]");
     SVO_ARG(pitch >= ctx->cfg.width && frame_stride >= (int64_t)pitch * ctx->cfg.height, "bad pitch / frame_stride");
     SVO_HIP(hipSetDevice(ctx->device));
     int rc = frame_buffers(ctx);
@@ -831,7 +839,7 @@ extern "C" int svo_upload_frames(svo_ctx *ctx, int buf, const uint8_t *left_fram
     if (ctx->fb_used[buf]) SVO_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_fb_free[buf], 0));
     const uint8_t *src[2] = {left_frames, right_frames};
     for (int cam = 0; cam < 2; cam++) {
-        uint8_t *dst = ctx->fb[buf] + cam * per_cam;
+        uint8_t *dst = ctx->fb[buf] + cam * per_cam + (size_t)first_slot * fbytes;
         if (pitch == sp && frame_stride == (int64_t)fbytes) {
             SVO_HIP(hipMemcpyAsync(dst, src[cam], fbytes * (size_t)n_frames, hipMemcpyHostToDevice, ctx->copy_stream));
         } else {
@@ -841,7 +849,7 @@ extern "C" int svo_upload_frames(svo_ctx *ctx, int buf, const uint8_t *left_fram
         }
     }
     SVO_HIP(hipEventRecord(ctx->ev_up[buf], ctx->copy_stream));
-    ctx->fb_frames[buf] = n_frames;
+    ctx->fb_frames[buf] = first_slot + n_frames;
     return SVO_OK;
 }
 

@@ -36,6 +36,11 @@ public:
     //                 last call; wait = true blocks until everything submitted so far is there
     //   StreamFlush : submits the partial micro-batch, if any; follow it with StreamPoll(poses, true)
     bool StreamPush(Frame::Ptr frame);
+    //   StreamAcquire / StreamCommit : StreamPush without its copy, for a producer that can write the images where they
+    //                 are uploaded from (a camera driver, a decoder): Acquire hands out the page-locked rows of the NEXT
+    //                 frame (`pitch` bytes apart, width x height), Commit says they are complete
+    bool StreamAcquire(int width, int height, uint8_t **left, uint8_t **right, int *pitch);
+    bool StreamCommit();
     int StreamPoll(std::vector<Pose4x4> &poses, bool wait = false);
     bool StreamFlush();
     int StreamDepth() const { return stream_depth_; }

@@ -624,35 +624,34 @@ bool System::StreamSubmit()
     svo_ctx *ctx = tracking_->Context();
     if (s.n < 2) return true;
     if (tracking_->Outstanding() == 2 && !StreamCollect(true)) return false;     // at most two in flight
-    if (svo_upload_frames(ctx, s.buf, s.pin[s.buf][0], s.pin[s.buf][1], s.pitch, (int64_t)s.fbytes, s.n) != SVO_OK) {
-        LZB_LOG("ERROR", "svo_upload_frames: %s", svo_last_error(ctx));
+    // after the first micro-batch the halo frame (slot 0) is carried ON THE DEVICE (Tracking::TrackUploadedAsync asks for
+    // SVO_CONTINUE_CARRY_FRAME with the chain): it is neither copied on the host nor uploaded again
+    const int s0 = s.chunk > 0 ? 1 : 0;
+    if (svo_upload_frames_at(ctx, s.buf, s0, s.pin[s.buf][0] + (size_t)s0 * s.fbytes, s.pin[s.buf][1] + (size_t)s0 * s.fbytes, s.pitch,
+                             (int64_t)s.fbytes, s.n - s0) != SVO_OK) {
+        LZB_LOG("ERROR", "svo_upload_frames_at: %s", svo_last_error(ctx));
         return false;
     }
     s.uploaded[s.buf] = true;
     if (!tracking_->TrackUploadedAsync(s.buf, s.n, s.chunk > 0)) return false;
     s.chunk++;
-    // the other buffer takes over: its own upload (two submissions ago) must have left the page-locked memory, and the
-    // last frame of this micro-batch is the halo of the next one
+    // the other buffer takes over: its own upload (two submissions ago) must have left the page-locked memory
     const int nb = s.buf ^ 1;
     if (s.uploaded[nb] && svo_wait_upload(ctx, nb) != SVO_OK) return false;
-    for (int cam = 0; cam < 2; cam++)
-        memcpy(s.pin[nb][cam], s.pin[s.buf][cam] + (size_t)(s.n - 1) * s.fbytes, s.fbytes);
     s.buf = nb;
     s.n = 1;
     return true;
 }
 
-bool System::StreamPush(Frame::Ptr frame)
+bool System::StreamAcquire(int width, int height, uint8_t **left, uint8_t **right, int *pitch)
 {
     StreamState &s = stream_;
-    if (frame == nullptr || s.failed) return false;
-    const cv::Mat &L = frame->left_img_, &R = frame->right_img_;
-    if (L.empty() || R.empty() || L.cols != R.cols || L.rows != R.rows) return false;
+    if (s.failed || width <= 0 || height <= 0 || !left || !right || !pitch) return false;
     const int k = stream_depth_ > 0 ? stream_depth_ : 1;
     if (!s.active) {
-        if (!tracking_->EnsureBatchContext(L.cols, L.rows, k)) return false;
+        if (!tracking_->EnsureBatchContext(width, height, k)) return false;
         svo_ctx *ctx = tracking_->Context();
-        s.w = L.cols; s.h = L.rows;
+        s.w = width; s.h = height;
         s.pitch = (s.w + 255) / 256 * 256;
         s.fbytes = (size_t)s.pitch * s.h;
         for (int q = 0; q < 2; q++)
@@ -667,18 +666,38 @@ bool System::StreamPush(Frame::Ptr frame)
         Pose4x4 I = tracking_->GetPose();                   // frame 0: StereoInit_f2f only, the pose it starts from
         s.done.push_back(I);
     }
-    if (L.cols != s.w || L.rows != s.h) {
-        LZB_LOG("ERROR", "stream: frame size changed from %dx%d to %dx%d", s.w, s.h, L.cols, L.rows);
+    if (width != s.w || height != s.h) {
+        LZB_LOG("ERROR", "stream: frame size changed from %dx%d to %dx%d", s.w, s.h, width, height);
         return false;
     }
-    const cv::Mat *img[2] = {&L, &R};
-    for (int cam = 0; cam < 2; cam++) {
-        uint8_t *dst = s.pin[s.buf][cam] + (size_t)s.n * s.fbytes;
-        for (int y = 0; y < s.h; y++) memcpy(dst + (size_t)y * s.pitch, img[cam]->ptr(y), (size_t)s.w);
-    }
+    *left = s.pin[s.buf][0] + (size_t)s.n * s.fbytes;
+    *right = s.pin[s.buf][1] + (size_t)s.n * s.fbytes;
+    *pitch = s.pitch;
+    return true;
+}
+
+bool System::StreamCommit()
+{
+    StreamState &s = stream_;
+    if (!s.active || s.failed) return false;
+    const int k = stream_depth_ > 0 ? stream_depth_ : 1;
     s.n++;
     if (s.n == k + 1 && !StreamSubmit()) { s.failed = true; return false; }
     return true;
+}
+
+bool System::StreamPush(Frame::Ptr frame)
+{
+    if (frame == nullptr || stream_.failed) return false;
+    const cv::Mat &L = frame->left_img_, &R = frame->right_img_;
+    if (L.empty() || R.empty() || L.cols != R.cols || L.rows != R.rows) return false;
+    uint8_t *dst[2];
+    int pitch = 0;
+    if (!StreamAcquire(L.cols, L.rows, &dst[0], &dst[1], &pitch)) return false;
+    const cv::Mat *img[2] = {&L, &R};
+    for (int cam = 0; cam < 2; cam++)
+        for (int y = 0; y < L.rows; y++) memcpy(dst[cam] + (size_t)y * pitch, img[cam]->ptr(y), (size_t)L.cols);
+    return StreamCommit();
 }
 
 int System::StreamPoll(std::vector<Pose4x4> &poses, bool wait)

@@ -41,16 +41,18 @@ class FrameStream:
         if len(self.outstanding) == 2:
             done.append(self._collect())
         b = self.buf
-        self.ctx.upload_frames(b, self.pin[b][0][:self.n], self.pin[b][1][:self.n])
+        # after the first micro-batch the halo frame (slot 0) is CARRIED on the device -- pyramids, keypoints, descriptors
+        # of the previous batch's last frame --: it is neither copied on the host nor sent over PCIe again
+        carry = self.chunk > 0
+        s0 = 1 if carry else 0
+        self.ctx.upload_frames(b, self.pin[b][0][s0:self.n], self.pin[b][1][s0:self.n], first_slot=s0)
         self.uploaded[b] = True
-        self.ctx.track_uploaded_async(b, self.n, continue_chain=self.chunk > 0, carry_frame=self.chunk > 0)
+        self.ctx.track_uploaded_async(b, self.n, continue_chain=carry, carry_frame=carry)
         self.outstanding.append(self.n - 1)
         self.chunk += 1
         nb = b ^ 1
         if self.uploaded[nb]:
             self.ctx.wait_upload(nb)       # its page-locked memory is written next
-        for cam in range(2):
-            self.pin[nb][cam][0] = self.pin[b][cam][self.n - 1]       # the halo frame of the next micro-batch
         self.buf, self.n = nb, 1
         return done
 
@@ -65,6 +67,16 @@ class FrameStream:
         """Hands one stereo frame over (the images are copied).  Returns the records completed meanwhile."""
         self.pin[self.buf][0][self.n, :, :self.w] = left
         self.pin[self.buf][1][self.n, :, :self.w] = right
+        return self.commit()
+
+    def next_slot(self):
+        """The page-locked rows the NEXT frame goes to, (left, right) views of shape (height, width): a producer that can
+        write there directly (a camera driver, a decoder -- RunBatched's decoder threads do) saves push()'s copy; follow
+        it with commit()."""
+        return self.pin[self.buf][0][self.n, :, :self.w], self.pin[self.buf][1][self.n, :, :self.w]
+
+    def commit(self):
+        """The frame written into next_slot() is complete.  Returns the records completed meanwhile."""
         self.n += 1
         done = self._submit() if self.n == self.depth + 1 else []
         return done + self.poll()

@@ -129,3 +129,32 @@ def test_run_kitti_stereo_stream_depth(pkg, frames11, tmp_path):
             outs[name] = open(out, "rb").read()
         assert len(outs["loop"].splitlines()) == 11
         assert outs["k1"] == outs["loop"] and outs["k4"] == outs["loop"] and outs["k16"] == outs["loop"], mode
+
+
+def test_frame_stream_in_place_producer(pkg, frames11):
+    """next_slot() / commit(): a producer that writes the frame where it is uploaded from -- same records as push(); and the
+    halo frame of a micro-batch is carried on the device (never uploaded again): the slot-0 rows of the later micro-batches
+    are poisoned on the host to prove nothing reads them."""
+    stream = importlib.import_module(conftest.entry.PKG_NAME + ".stream")
+    seq, frames = frames11
+    P1, P2 = seq.proj()
+    want = _online(pkg, seq, frames)
+    c = pkg.Context(416, 128, device=0, P1=P1, P2=P2, max_batch=3)
+    fs = stream.FrameStream(c, 3)
+    got = []
+    for t, (L, R) in enumerate(frames):
+        l, r = fs.next_slot()
+        l[:], r[:] = L, R
+        if fs.n == 1 and fs.chunk > 0:                    # first new frame of a later micro-batch: slot 0 is the carried halo
+            fs.pin[fs.buf][0][0] = 0x5A
+            fs.pin[fs.buf][1][0] = 0xA5
+        for chunk in fs.commit():
+            got.extend(chunk)
+    for chunk in fs.flush():
+        got.extend(chunk)
+    fs.close()
+    c.close()
+    assert len(got) == len(want) == 10
+    for p, (g, w) in enumerate(zip(got, want)):
+        assert int(g["ok"]) == int(w["ok"]) == 1 and int(g["n_tracked"]) == int(w["n_tracked"]), p
+        assert g["T_rel_inv"].tobytes() == w["T_rel_inv"].tobytes() and g["pose"].tobytes() == w["pose"].tobytes(), p

@@ -12,6 +12,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 KERNEL = sys.argv[3] if len(sys.argv) > 3 else "lk_kernel"          # or lk_sse2_kernel (bench.py --lk-accum sse2)
+COMMAND = sys.argv[4] if len(sys.argv) > 4 else ("tools/gpu/prof.sh: rocprofv3 --pmc <one group per run> --kernel-include-regex svo:: -- python3 bench.py --steps 2 "
+                                                 "--warmup 1 --cpu-pairs 0 --no-secondary --no-timing-marks --no-overlap (256 S0 pairs per launch)")
 vals = {}
 for line in open(sys.argv[1]):
     if KERNEL not in line:
@@ -33,8 +35,7 @@ for f in ("lk.hip", "lk_common.h", "svo_device.h", "svo_kernels.h") + (("lk_sse2
 fetch_kb, write_kb = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
 out = {
     "kernel": "svo::" + KERNEL,
-    "command": "tools/gpu/prof.sh: rocprofv3 --pmc <one group per run> --kernel-include-regex svo:: -- python3 bench.py --steps 2 "
-               "--warmup 1 --cpu-pairs 0 --no-secondary --no-timing-marks --no-overlap (256 S0 pairs per launch)",
+    "command": COMMAND,
     "source_sha256_16": h.hexdigest()[:16],
     "kernel_trace_avg_launch_ms": round(avg_ns * 1e-6, 4) if avg_ns else None,
     "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,

@@ -5,9 +5,12 @@ MI355X_MICROARCH.md prescribes (FETCH_SIZE / WRITE_SIZE in KiB, gfx950's FETCH_S
 counts and the launch time; `cellfast_traffic_bytes` is the figure of bench.py's roofline object."""
 import collections
 import csv
+import hashlib
 import json
 import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 vals = collections.defaultdict(dict)
 for line in open(sys.argv[1]):
@@ -36,6 +39,10 @@ for k, v in sorted(vals.items()):
          "lds_bank_conflict_cycles": v.get("SQ_LDS_BANK_CONFLICT"), "lds_idx_active_cycles": v.get("SQ_LDS_IDX_ACTIVE"),
          "tcc_hit": v.get("TCC_HIT_sum"), "tcc_miss": v.get("TCC_MISS_sum"), "grbm_gui_active": v.get("GRBM_GUI_ACTIVE")}
     out["kernels"][k] = e
+h = hashlib.sha256()
+for f in ("orb.hip", "orb_pattern.h", "svo_device.h", "svo_kernels.h"):             # what the ORB kernels are built from (bench.py orb_source_hash)
+    h.update(open(os.path.join(ROOT, "stereo-visual-odometry_amd", "csrc", f), "rb").read())
+out["source_sha256_16"] = h.hexdigest()[:16]
 cf = out["kernels"].get("orb_cellfast_kernel", {})
 out["cellfast_traffic_bytes"] = cf.get("traffic_bytes")
 print(json.dumps(out, indent=1))
