@@ -378,10 +378,24 @@ __device__ __forceinline__ void lk_call4(const PyrGeom &g, const uint8_t *slotI,
             LK_AT(6);                            // 5 -> 6: slot pixel work: J reads, bilinear + mismatch dot products
             float b1f, b2f;
             {
+                int r;
+#ifdef SVO_LK_SINGLE_SLOT
+                // EXPERIMENT (round 5, off by default: measured SLOWER, 13.24 against 12.86 ms per 256 pairs, same box, two runs
+                // each, bit-identical results): one slot left (a third of the wave-iterations: its partners have converged) --
+                // its two sums alone through reduce_pair_all (13 cross-lane operations with two row swaps instead of 22 with
+                // six).  The instruction arithmetic said -2.5 %; the extra scalar branch splits the iteration's one basic block
+                // and costs the scheduler more overlap than the shorter reduction returns.  DESIGN.md section 6.
+                if (m_it != 0 && (m_it & (m_it - 1)) == 0) {
+                    // (the idle slots' partial sums are zeros: the live slot's values are the sums over the slots)
+                    r = reduce_pair_all((pb[0][0] + pb[1][0]) + (pb[2][0] + pb[3][0]), (pb[0][1] + pb[1][1]) + (pb[2][1] + pb[3][1]), lane);
+                } else
+#endif
+                {
                 int v[8];
 #pragma unroll
                 for (int s = 0; s < kSlots; s++) { v[2 * s] = pb[s][0]; v[2 * s + 1] = pb[s][1]; }
-                const int r = reduce_scatter8_rows(v, lane);       // row s: {b1.lo, b2.lo, b1.hi, b2.hi} of slot s in every quad
+                r = reduce_scatter8_rows(v, lane);                 // row s: {b1.lo, b2.lo, b1.hi, b2.hi} of slot s in every quad
+                }
                 b1f = wide_to_f32(quad_bcast<2>(r), quad_bcast<0>(r)) * FLT_SCALE;
                 b2f = wide_to_f32(quad_bcast<3>(r), quad_bcast<1>(r)) * FLT_SCALE;
             }

@@ -146,6 +146,19 @@ __device__ inline int reduce_scatter8_rows(const int (&v)[8], int lane)
     return e;
 }
 
+// The same result layout for ONE slot's two values (each |v| < 2^28) summed over all 64 lanes: {t0.lo, t1.lo, t0.hi, t1.hi}
+// in every quad of EVERY row.  A third of lk_kernel's wave-iterations serve a single slot (its three partners have
+// converged): 13 cross-lane / select operations with two row swaps instead of 22 with six.
+__device__ inline int reduce_pair_all(int v0, int v1, int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const int keep = b0 ? v1 : v0, give = b0 ? v0 : v1;
+    int d = keep + dpp_xor1(give);                         // t = lane bit 0; sums of 2 lanes
+    d += dpp_xor2(d);                                      // sums of 4 lanes (< 2^30), the same in lanes i and i ^ 2
+    const int e = b1 ? d >> 16 : d & 0xFFFF;               // half = lane bit 1
+    return allsum_mod4(e);                                 // over the 16 quads: |lo| < 2^20, |hi| < 2^18
+}
+
 // broadcast lane q of every quad to the whole quad
 template <int Q>
 __device__ inline int quad_bcast(int v)
