@@ -80,6 +80,10 @@ def parse():
                          "sse2 = an x86 OpenCV 3 build's lane order (bit-identical to oracle/lk.c mode 2)")
     ap.add_argument("--shard", choices=["sequences", "pairs"], default="sequences")
     ap.add_argument("--config5", action="store_true", help="KITTI 00-07 sequence lengths dealt to the ranks (see the docstring)")
+    ap.add_argument("--scaling-table", action="store_true",
+                    help="run N = 1, 2, 4, ... up to --gpus one after the other (same flags, secondary legs off) and print the curve: "
+                         "one JSON line per N as the runs finish, then one summary line {\"scaling_table\": [...]} -- the 1/2/4/8-GPU "
+                         "batch scaling curve of north_star in one command, e.g. `python bench.py --gpus 8 --scaling-table [--config5 | --shard pairs]`")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1: nccl (= RCCL, the real path) or gloo (rehearsal of the "
                          "multi-rank control flow with several ranks sharing one GPU: collectives on CPU copies)")
@@ -489,8 +493,60 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
+def scaling_table(args):
+    """`--scaling-table`: the parent (which never touches the GPU) runs `bench.py --gpus N` for N = 1, 2, 4, ... <= --gpus,
+    each exactly as the driver would start it (self-launched ranks), and collects rank 0's line of every run."""
+    import subprocess
+    flags, skip = [], False
+    for a in sys.argv[1:]:
+        if skip:
+            skip = False
+            continue
+        if a == "--scaling-table":
+            continue
+        if a == "--gpus":
+            skip = True
+            continue
+        if a.startswith("--gpus="):
+            continue
+        flags.append(a)
+    for extra in ("--no-secondary", "--no-legs"):
+        if extra not in flags:
+            flags.append(extra)
+    if "--cpu-pairs" not in flags:
+        flags += ["--cpu-pairs", "0"]
+    rows, rc = [], 0
+    n = 1
+    while n <= args.gpus:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", str(n)] + flags, capture_output=True, env=env)
+        wall = time.perf_counter() - t0
+        line = next((ln for ln in reversed(r.stdout.decode().splitlines()) if ln.startswith("{")), None)
+        if r.returncode != 0 or line is None:
+            print(f"bench.py --scaling-table: the {n}-GPU run failed ({r.returncode}): {r.stderr.decode()[-600:]}", file=sys.stderr, flush=True)
+            rows.append({"n_gpus": n, "error": r.returncode})
+            rc = rc or r.returncode or 1
+        else:
+            print(line, flush=True)
+            o = json.loads(line)
+            rows.append({"n_gpus": n, "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "scaling": o["scaling"],
+                         "ranks": o.get("ranks"), "driver_wall_s": round(wall, 2), "imbalance_max_over_mean": (o.get("config5") or {}).get("imbalance_max_over_mean")})
+        n *= 2
+    base = next((r["value"] for r in rows if r.get("n_gpus") == 1 and "value" in r), None)
+    for r in rows:
+        if base and "value" in r:
+            r["speedup_vs_1"] = round(r["value"] / base, 3)
+    print(json.dumps({"scaling_table": rows, "flags": flags}), flush=True)
+    for r in rows:
+        print(f"  N={r['n_gpus']}: " + (f"{r['value']:.0f} {r['unit']}, x{r.get('speedup_vs_1')}" if "value" in r else "FAILED"), file=sys.stderr)
+    return rc
+
+
 def main():
     args = parse()
+    if args.scaling_table and "RANK" not in os.environ:
+        sys.exit(scaling_table(args))
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args))                # before anything in this process touches the GPU
     import torch

@@ -253,6 +253,23 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", [(), ("--shard", "pairs")])
+def test_bench_scaling_table_in_one_command(extra):
+    """`python bench.py --gpus 2 --scaling-table`: the N = 1 and N = 2 runs one after the other (each with self-launched
+    ranks; gloo, the ranks share the one card), a line per N and the summary line with the curve -- the command that prints
+    the 1/2/4/8-GPU batch scaling curve on a node that has the cards."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = _bench("--gpus", "2", "--scaling-table", "--steps", "2", "--warmup", "1", "--batch", "6", "--dist-backend", "gloo", *extra)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert [ln.get("n_gpus") for ln in lines[:2]] == [1, 2] and "scaling_table" in lines[-1]
+    tab = lines[-1]["scaling_table"]
+    assert [t["n_gpus"] for t in tab] == [1, 2] and all(t["value"] > 0 for t in tab) and tab[0]["speedup_vs_1"] == 1.0
+
+
+@pytest.mark.gpu
 def test_bench_refuses_more_nccl_ranks_than_gpus():
     """`--gpus N` over nccl (RCCL) on a node with fewer than N cards exits non-zero with a message: a run is
     never reported as N GPUs unless N ranks ran on N cards."""
