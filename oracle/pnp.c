@@ -494,13 +494,15 @@ int orc_pnp_ransac(const orc_pt3f *obj, const orc_pt2f *img, int n, const double
                    int iterations, float reproj_err, double confidence, orc_pnp_result *res,
                    uint8_t *inlier_mask)
 {
-    const int model_points = 5;
+    /* "if (npoints == 4) { model_points = 4; ransac_kernel_method = SOLVEPNP_P3P; }" (solvepnp.cpp): with exactly four points
+     * the minimal solver is P3P (oracle/p3p.c) on all of them, every point is an inlier, and the refit runs on the four */
+    const int model_points = n == 4 ? 4 : 5;
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     int i, iter;
     memset(res, 0, sizeof(*res));
     res->best_iter = -1;
     res->R[0] = res->R[4] = res->R[8] = 1;      /* rvec = 0 -> Rodrigues gives I */
-    if (n < model_points) return 0;             /* npoints == 4 would take the P3P kernel: out of scope */
+    if (n < model_points) return 0;             /* cv::solvePnPRansac asserts npoints >= 4 */
     const int refit_mode = orc_get_opencv_compat(ORC_COMPAT_PNP_REFIT);
     const int minimal_direct = orc_get_opencv_compat(ORC_COMPAT_PNP_MINIMAL) == 1 && n == model_points;
 
@@ -539,7 +541,11 @@ int orc_pnp_ransac(const orc_pt3f *obj, const orc_pt2f *img, int n, const double
             us[2 * i] = (double)xn * fx + cx;
             us[2 * i + 1] = (double)yn * fy + cy;
         }
-        orc_epnp(pws, us, model_points, fx, fy, cx, cy, R, t);
+        if (model_points == 4) {
+            if (!orc_p3p4(pws, us, fx, fy, cx, cy, R, t)) { res->ransac_iters = iter + 1; break; }   /* runKernel: no model, and the same four points again would give none either */
+        } else {
+            orc_epnp(pws, us, model_points, fx, fy, cx, cy, R, t);
+        }
         memcpy(lastR, R, sizeof(lastR)); memcpy(lastt, t, sizeof(lastt));
 
         int good = 0;

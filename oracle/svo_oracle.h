@@ -102,6 +102,9 @@ typedef struct {
     int ok;                /* solvePnPRansac's boolean result */
 } orc_pnp_result;
 
+/* cv::solvePnP(SOLVEPNP_P3P) on exactly four points (oracle/p3p.c): pws 4 x (X Y Z), us 4 x (u v) in pixels; 1 = solved */
+int orc_p3p4(const double pws[12], const double us[8], double fx, double fy, double cx, double cy, double R[9], double t[3]);
+int orc_solve_deg4(double a, double b, double c, double d, double e, double x[4]);    /* polynom_solver.cpp: real roots */
 int orc_pnp_ransac(const orc_pt3f *obj, const orc_pt2f *img, int n, const double K[9],
                    int iterations, float reproj_err, double confidence,
                    orc_pnp_result *res, uint8_t *inlier_mask /* n or NULL */);

@@ -310,6 +310,10 @@ __device__ void pnp_begin_item(const PnpBeginArgs &a, int n, int b, int lane)
             if (a.stream && n <= 65535) done = draw_subsets_stream(a.stream, n, hyps, sub, lane, &rng);
             if (done < hyps) rng = draw_subsets(rng, n, hyps - done, sub + 5 * done, lane);
         } else { hyps = 1; if (lane < 5) sub[lane] = lane; }          // npoints == model_points: one solve, all inliers
+    } else if (n == 4) {
+        // "if (npoints == 4) { model_points = 4; ransac_kernel_method = SOLVEPNP_P3P; }": one P3P solve on the four points
+        hyps = 1;
+        if (lane < 4) sub[lane] = lane;
     }
     if (lane != 0) return;
     st->n = n; st->niters = niters;
@@ -379,6 +383,28 @@ __device__ __forceinline__ void pnp_hyp_front_body(const PnpArgs &a, double *pnp
         return;
     }
     if (blockIdx.x * kHypBlock >= st->phase_hyps) return;    // block beyond the phase (uniform)
+    if (st->n == 4) {
+        // exactly four points: cv::solvePnPRansac's kernel is P3P (geom_device.h p3p4_d), ONE model from all four; a solve
+        // without a solution leaves the marker -1 in the hypothesis' inlier count (the selection rule then finds no model)
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const float *X3 = a.X3 + (int64_t)b * a.stride * 3;
+            const float2 *img = a.img + (int64_t)b * a.stride;
+            const double fx = a.fx, fy = a.fy, cx = a.cx, cy = a.cy;
+            double pws[12], us[8];
+            for (int i = 0; i < 4; i++) {
+                pws[3 * i] = (double)X3[3 * i]; pws[3 * i + 1] = (double)X3[3 * i + 1]; pws[3 * i + 2] = (double)X3[3 * i + 2];
+                const float2 m = img[i];
+                const float xn = (float)(((double)m.x - cx) * (1. / fx));       // undistortPoints: float out
+                const float yn = (float)(((double)m.y - cy) * (1. / fy));
+                us[2 * i] = (double)xn * fx + cx;                                // p3p::extract_points: back to pixels
+                us[2 * i + 1] = (double)yn * fy + cy;
+            }
+            PnpHyp out;
+            if (p3p4_d(pws, us, fx, fy, cx, cy, out.R, out.t)) a.hyp[(int64_t)b * kPhaseHyps] = out;
+            else a.counts[(int64_t)b * kPhaseHyps] = -1;
+        }
+        return;
+    }
     const bool active = h < st->phase_hyps;                  // idle lanes solve points 0..4 (they take part in the barriers)
     double *big = pnp_smem_w + lane, *W = pnp_smem_w + 144 * 64 + lane;
     double *hand = a.hand + ((int64_t)b * kPhaseBlocks + blockIdx.x) * (kEpnpHandDoubles * 64) + lane;   // element e at hand[e * 64]
@@ -427,6 +453,7 @@ __device__ __forceinline__ void pnp_hyp_back_body(const PnpArgs &a, double *pnp_
     const int h = blockIdx.x * kHypBlock + lane;
     if (st->next_base != a.phase_base) return;               // phase not needed
     if (blockIdx.x * kHypBlock >= st->phase_hyps) return;    // block beyond the phase
+    if (st->n == 4) return;                                  // a P3P item: the front kernel wrote its one model
     const bool active = h < st->phase_hyps;
     double *big = pnp_smem_w + lane;
     const double *hand = a.hand + ((int64_t)b * kPhaseBlocks + blockIdx.x) * (kEpnpHandDoubles * 64) + lane;
@@ -536,13 +563,17 @@ __global__ __launch_bounds__(64) void pnp_select_kernel(PnpArgs a)
     PnpState *st = a.state + b;
     if (st->next_base != a.phase_base || st->phase_hyps <= 0) return;
     int *counts = a.counts + (int64_t)b * kPhaseHyps;
-    const int n = st->n, model_points = 5;
+    const int n = st->n, model_points = n == 4 ? 4 : 5;
     const int hyps = st->phase_hyps;
     {
         int niters = st->niters, max_good = st->max_good, best_iter = st->best_iter, iters_done = st->iters_done, owner = -1;
         if (n == model_points) {
-            // one hypothesis on exactly five points: all inliers, one iteration
-            if (a.phase_base < niters) { max_good = n; best_iter = a.phase_base; owner = 0; iters_done = a.phase_base + 1; niters = a.phase_base + 1; }
+            // one hypothesis on exactly five (EPnP) or four (P3P) points: all inliers, one iteration; a P3P solve without a
+            // solution (count marker -1) is no model at all
+            if (a.phase_base < niters) {
+                iters_done = a.phase_base + 1; niters = a.phase_base + 1;
+                if (counts[0] >= 0) { max_good = n; best_iter = a.phase_base; owner = 0; }
+            }
         } else if (a.phase_base < niters) {
             constexpr int kChunks = kPhaseHyps / 64;
             int g[kChunks];
@@ -671,10 +702,10 @@ __global__ __launch_bounds__(kRefitThreads) void pnp_refit_kernel(PnpArgs a)
     const float2 *img = a.img + (int64_t)b * a.stride;
     uint8_t *mask = a.mask + (int64_t)b * a.stride;
     PnpRecord *out = a.out + b;
-    const int model_points = 5;
+    const int model_points = n == 4 ? 4 : 5;
     const int max_good = st->max_good;
     if (n < model_points || max_good <= 0) {
-        // npoints == 4 would take OpenCV's P3P kernel: out of scope, no solution.  max_good == 0:
+        // fewer than four points: cv::solvePnPRansac would assert; no solution.  max_good == 0:
         // solvePnPRansac returns false, rvec/tvec stay at the caller's zeros, no inliers
         if (tid == 0) {
             for (int i = 0; i < 3; i++) { out->rvec[i] = 0; out->tvec[i] = 0; }

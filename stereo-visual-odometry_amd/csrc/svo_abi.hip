@@ -185,12 +185,11 @@ extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
         return SVO_ERR_ARG;
     }
     if (cfg->fast_keep_strongest < 0) return SVO_ERR_ARG;
-    if (cfg->num_features_tracking < 5) {
-        // with fewer than 5 tracks required, a pair with exactly 4 would reach cv::solvePnPRansac's
-        // npoints == 4 branch (P3P kernel), which this library does not implement: refuse the
-        // configuration instead of answering "no solution" where the reference would solve
-        fprintf(stderr, "svo_create: num_features_tracking = %d < 5 is not supported (the 4-point P3P branch of "
-                        "cv::solvePnPRansac is out of scope)\n", cfg->num_features_tracking);
+    if (cfg->num_features_tracking < 4) {
+        // a pair with exactly 4 tracks takes cv::solvePnPRansac's npoints == 4 branch (the P3P kernel: geometry.hip); with
+        // fewer than 4 the reference's call asserts (CV_Assert(npoints >= 4)) and the process dies: refuse the configuration
+        fprintf(stderr, "svo_create: num_features_tracking = %d < 4 is not supported (cv::solvePnPRansac asserts npoints >= 4)\n",
+                cfg->num_features_tracking);
         return SVO_ERR_ARG;
     }
     svo_ctx *ctx = new (std::nothrow) svo_ctx();

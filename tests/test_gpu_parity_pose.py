@@ -120,9 +120,36 @@ def test_pnp_ransac_many_rounds_and_failure(ctx, oracle, tc):
     Xg = _scene(60, 9).astype(np.float32)
     xg = rng.uniform(0, 1200, (60, 2)).astype(np.float32)
     _check_pnp(ctx.pnp_ransac(Xg, xg, K, iterations=130), oracle.pnp_ransac(Xg, xg, K, iterations=130))
-    # fewer than 5 points: no solution (P3P branch out of scope), identity rotation, zero inliers
-    res = ctx.pnp_ransac(X[:4], x[:4], K)
+    # fewer than 4 points: no solution (cv::solvePnPRansac would assert), identity rotation, zero inliers
+    res = ctx.pnp_ransac(X[:3], x[:3], K)
     assert res["ok"] == 0 and res["n_inliers"] == 0 and np.array_equal(res["R"], np.eye(3))
+
+
+def test_pnp_ransac_four_points_take_the_p3p_kernel(ctx, oracle):
+    """npoints == 4: cv::solvePnPRansac's minimal solver is P3P (round 5; reachable with num_features_tracking = 4, reference
+    src/tracking.cpp:274, 485): one model from the four points, every point an inlier, LM refit on them.  Discrete fields equal
+    the oracle's; the pose to 1e-6 (pow / acos / cos of the device library seed the refit with other last bits, and four points
+    leave the refit's minimum shallow)."""
+    n_ok = 0
+    for seed in range(24):
+        X, x, r, t = _planted(4, 100 + seed, 0, noise=0.0 if seed % 2 else 0.05)
+        ref = oracle.pnp_ransac(X, x, K)
+        got = ctx.pnp_ransac(X, x, K)
+        assert got["ok"] == ref["ok"] and got["n_inliers"] == ref["n_inliers"] and got["ransac_iters"] == ref["ransac_iters"], seed
+        assert np.array_equal(got["mask"], ref["mask"]), seed
+        if ref["ok"]:
+            n_ok += 1
+            assert got["n_inliers"] == 4 and abs(got["lm_iters"] - ref["lm_iters"]) <= 1, seed
+            assert np.abs(got["tvec"] - ref["tvec"]).max() <= 1e-6 * max(1.0, np.abs(ref["tvec"]).max()), seed
+            assert np.abs(got["rvec"] - ref["rvec"]).max() <= 1e-6, seed
+    assert n_ok >= 20
+
+
+def test_num_features_tracking_four_is_accepted_three_refused(pkg):
+    c = pkg.Context(416, 128, device=0, num_features_tracking=4)
+    c.close()
+    with pytest.raises(pkg.SvoError):
+        pkg.Context(416, 128, device=0, num_features_tracking=3)
 
 
 @pytest.mark.parametrize("n,n_out,iterations", [(6, 3, 500), (7, 4, 500), (12, 9, 500), (40, 33, 500), (300, 255, 500),
@@ -527,3 +554,42 @@ def test_new_entry_points_reject_bad_arguments(pkg, tc, small_seq):
         pkg.Context(w, h, device=0, track_mode=pkg.MODE_ORB, max_keypoints=1 << 15).orb_extract(frames[0][0])
     with pytest.raises(pkg.SvoError):
         pkg.Context(w, h, device=0, track_mode=pkg.MODE_ORB, orb_nfeatures=40000, orb_nlevels=1).orb_extract(frames[0][0])
+
+
+def test_fused_step_with_exactly_four_tracks_runs_p3p(pkg, oracle, small_seq):
+    """The whole frame step down the P3P branch: num_features_tracking = 4 and a feature_match_error chosen so that EXACTLY
+    four point chains survive deleteBadmatchFeatures (the reference then calls cv::solvePnPRansac with four points,
+    src/tracking.cpp:274, 485).  Counts, failure stage and inlier mask as the oracle's; pose to 1e-6."""
+    seq, frames = small_seq
+    h, w = frames[0][0].shape
+    P1s, P2s = seq.proj()
+    imgs = [*frames[0], *frames[1]]
+    kps = oracle.fast(imgs[0])
+    pts = np.stack([kps["x"], kps["y"]], 1).astype(np.float32)
+    pyr = [oracle.PyramidHandle(im) for im in imgs]
+    chain, cur, outs, sts = ((0, 1), (1, 3), (3, 2), (2, 0)), pts, [pts], []          # L1 -> R1 -> R2 -> L2 -> L1'
+    for a, b in chain:
+        nxt, st = oracle.lk_track(pyr[a], pyr[b], cur)
+        outs.append(nxt); sts.append(st); cur = nxt
+    ok = np.all([s == 1 for s in sts], axis=0) & np.all([(o >= 0).all(axis=1) for o in outs], axis=0)
+    dy = np.maximum(np.abs(outs[0][:, 1] - outs[1][:, 1]), np.abs(outs[2][:, 1] - outs[3][:, 1])).astype(np.float64)
+    cand = np.sort(dy[ok])
+    assert len(cand) > 8 and cand[3] < cand[4]
+    err = 0.5 * (cand[3] + cand[4])                          # exactly four chains pass |y0 - y1|, |y2 - y3| <= err
+    prm = oracle.make_params(P1s, P2s, feature_match_error=err, num_features_tracking=4)
+    r, _, pose = oracle.lk_track_step(prm, *imgs, kps, np.eye(4), want_tracks=True)
+    assert r["n_tracked"] == 4
+    c = pkg.Context(w, h, device=0, P1=P1s, P2=P2s, feature_match_error=err, num_features_tracking=4)
+    c.add_frame(*frames[0])
+    rc, g = c.add_frame(*frames[1])
+    assert rc == (0 if r["ok"] else r["fail_stage"])
+    for k in ("ok", "fail_stage", "n_prev_kps", "n_cur_kps", "n_tracked", "n_inliers", "ransac_iters"):
+        assert int(g[k]) == int(r[k]) if k in r else True, k
+    assert int(g["n_tracked"]) == 4
+    t1l, t1r, t2r, t2l, inl = c.last_tracks()
+    assert np.stack([t1l, t1r, t2r, t2l]).tobytes() == r["tracks"].tobytes()
+    if r["ok"]:
+        assert inl.tolist() == [1, 1, 1, 1]
+        assert np.abs(g["tvec"] - r["tvec"]).max() <= 1e-6 and np.abs(g["rvec"] - r["rvec"]).max() <= 1e-6
+        assert relfro(c.get_pose(), pose) <= 1e-6
+    c.close()

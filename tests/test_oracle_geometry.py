@@ -134,8 +134,12 @@ def test_pnp_ransac_edge_cases(oracle):
     # exactly 5 points: one model, everything an inlier
     res = oracle.pnp_ransac(X.astype(np.float32), x.astype(np.float32), K)
     assert res["ok"] == 1 and res["n_inliers"] == 5 and res["ransac_iters"] == 1
-    # fewer than 5 points: solvePnPRansac's 4-point P3P kernel is out of scope -> no solution
+    # exactly 4 points: solvePnPRansac's kernel is P3P, one model from all four, all inliers, LM refit on them
     res = oracle.pnp_ransac(X[:4].astype(np.float32), x[:4].astype(np.float32), K)
+    assert res["ok"] == 1 and res["n_inliers"] == 4 and res["ransac_iters"] == 1 and res["mask"].tolist() == [1, 1, 1, 1]
+    assert np.abs(res["tvec"] - t).max() < 1e-3 and np.abs(res["rvec"] - r).max() < 1e-4
+    # fewer than 4 points: cv::solvePnPRansac would assert -> no solution
+    res = oracle.pnp_ransac(X[:3].astype(np.float32), x[:3].astype(np.float32), K)
     assert res["ok"] == 0 and res["n_inliers"] == 0 and np.array_equal(res["R"], np.eye(3))
     # pure garbage: no hypothesis reaches 5 inliers -> failure, zero inliers
     rng = np.random.default_rng(0)
@@ -180,3 +184,42 @@ def test_full_step_recovers_synthetic_motion(oracle, small_seq):
         kps = kps_next
     gt_pose = (np.linalg.inv(seq.poses_wc()[0].numpy()) @ seq.poses_wc()[3].numpy())
     assert np.abs(pose[:3, 3] - gt_pose[:3, 3]).max() < 0.2
+
+
+def test_quartic_solver_against_numpy_roots(oracle):
+    """polynom_solver.cpp's solve_deg4 (behind P3P): the REAL roots of random quartics, against numpy.roots."""
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    lib = oracle.lib()
+    for it in range(600):
+        roots = rng.uniform(-3, 3, 4)
+        co = (np.poly(roots) if it % 3 else np.poly([roots[0], roots[1], 1 + 2j, 1 - 2j]).real) * rng.uniform(0.5, 2)
+        x = (C.c_double * 4)()
+        n = lib.orc_solve_deg4(*[C.c_double(v) for v in co], x)
+        want = np.sort([r.real for r in np.roots(co) if abs(r.imag) < 1e-9])
+        got = np.sort(list(x)[:n])
+        assert len(want) == len(got) and (not len(want) or np.abs(want - got).max() <= 1e-6 * max(1.0, np.abs(want).max())), (it, co)
+
+
+def test_p3p_recovers_planted_poses(oracle):
+    """cv::solvePnP(SOLVEPNP_P3P) as restated in oracle/p3p.c: four exact projections -> the planted pose.  Gao's closed form
+    is not a numerically gentle method (nor is upstream's): most solves are at 1e-9, a few per cent at 1e-3 -- the RANSAC path
+    follows it with an LM refit on the four points."""
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    lib = oracle.lib()
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    errs = []
+    for it in range(400):
+        Xw = np.c_[rng.uniform(-8, 8, 4), rng.uniform(-2, 2, 4), rng.uniform(6, 40, 4)]
+        rv, tt = rng.normal(0, 0.05, 3), rng.normal(0, 0.5, 3)
+        R = Rotation.from_rotvec(rv).as_matrix()
+        Xc = (R @ Xw.T).T + tt
+        us = np.c_[fx * Xc[:, 0] / Xc[:, 2] + cx, fy * Xc[:, 1] / Xc[:, 2] + cy]
+        Ro, to = (C.c_double * 9)(), (C.c_double * 3)()
+        ok = lib.orc_p3p4((C.c_double * 12)(*Xw.reshape(-1)), (C.c_double * 8)(*us.reshape(-1)), C.c_double(fx), C.c_double(fy),
+                          C.c_double(cx), C.c_double(cy), Ro, to)
+        assert ok == 1
+        errs.append(max(np.abs(np.array(Ro).reshape(3, 3) - R).max(), np.abs(np.array(to) - tt).max()))
+    errs = np.array(errs)
+    assert np.median(errs) < 1e-8 and (errs < 1e-6).mean() > 0.85 and (errs < 1e-2).mean() > 0.97, (np.median(errs), (errs < 1e-6).mean())
