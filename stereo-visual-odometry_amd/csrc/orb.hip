@@ -88,15 +88,16 @@ constexpr int kResizeRows = 6;               // output rows per workgroup
 // The LDS image is sized for THIS level's scale (11 KB at 1.2): in overlap mode the previous batch's
 // EPnP workgroups hold 147 of a CU's 160 KB, and a resize workgroup has to fit beside them.
 __global__ __launch_bounds__(256) void orb_resize_kernel(OrbGeom g, uint8_t *slots, int64_t slot_stride, int l,
-                                                         const int2 *xtab, const int4 *ytab, int src_rows_cap, int kResizeDw)
+                                                         const int2 *xtab, const int4 *ytab, int src_rows_cap, int kResizeDw, OrbL0 z)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t rs_rows[];       // src_rows_cap x kResizeDw
     const int b = blockIdx.z, tid = threadIdx.x;
-    const int dw = g.w[l], dh = g.h[l], sp = g.pitch[l - 1];
+    const bool in_place = l == 1 && z.img != nullptr;                 // level 0 = the input image itself
+    const int dw = g.w[l], dh = g.h[l], sp = in_place ? z.pitch : g.pitch[l - 1];
     const int dy0 = blockIdx.y * kResizeRows, dy1 = min(dy0 + kResizeRows, dh);
     const int dx_first = blockIdx.x * 1024, dx_last = min(dx_first + 1023, dw - 1);
     uint8_t *slot = slots + (int64_t)b * slot_stride;
-    const uint8_t *src = slot + g.origin[l - 1];
+    const uint8_t *src = in_place ? orb_level0(z, b) : slot + g.origin[l - 1];
     const int2 *xt = xtab + g.xtab_off[l];
     const int4 *yt = ytab + g.ytab_off[l];
     // source rows [sy_first, sy_last] (the table's rows are monotone), columns [s0, s0 + 4 ndw)
@@ -144,6 +145,115 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(OrbGeom g, uint8_t *slo
         if (dx0 + 4 <= dw) *(uint32_t *)d = out;
         else for (int q = 0; dx0 + q < dw; q++) d[q] = (uint8_t)(out >> (8 * q));
     }
+}
+
+// The same resize with the source rows STREAMED through registers (round 5; the staged kernel above stays for scale
+// factors this one does not cover, OrbGeom::rs_stream).  cv::resize's linear path is two passes -- every source row is
+// blended horizontally ONCE into an int row, an output row blends two of those vertically --, and at a scale of 1.2 a
+// source row serves 1.67 output rows: the staged kernel redid the horizontal blend for both rows of every output row
+// (4 LDS byte reads + 4 multiplies per pixel).  Here a lane owns four output columns and walks down a band of output
+// rows: per SOURCE row three aligned dwords (the 8-byte window from its first source column holds every tap of its four
+// pixels while sx1[3] - sx[0] <= 7), two v_alignbyte to normalise the alignment, per pixel one v_perm (the two taps as
+// 16-bit halves) + one v_dot2 against the table's (a0 | a1 << 16) + the `>> 4` of the vertical pass kept as `& ~15`; the
+// rows r - 1 and r stay in registers.  An output row whose second source row is r is then four times
+//   ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2  =  (mulhi24(b0 << 12, S0 & ~15) + mulhi24(b1 << 12, S1 & ~15) + 2) >> 2
+// (b <= 2^11 and S < 2^20: both factors fit 24 bits, the 48-bit product >> 32 is the same floor), the four bytes
+// gathered by three v_perm.  No LDS, no barrier; source rows are requested ahead of their blend.
+__device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__global__ __launch_bounds__(256) void orb_resize_stream_kernel(OrbGeom g, uint8_t *__restrict__ slots, int64_t slot_stride, int l,
+                                                                const int2 *__restrict__ xtab, const int4 *__restrict__ ytab, int n_img, int gx, int gy, int band, OrbL0 z)
+{
+    int b, blk;
+    xcd_image_block(blockIdx.x, gx * gy, n_img, b, blk);
+    const int by = blk / gx, bx = blk - by * gx;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (uniform: the row walk below is scalar control)
+    const bool in_place = l == 1 && z.img != nullptr;                 // level 0 = the input image itself
+    const int dw = g.w[l], dh = g.h[l], sp = in_place ? z.pitch : g.pitch[l - 1], sw = g.w[l - 1];
+    const int dy0 = (by * 4 + wave) * band, dy1 = min(dy0 + band, dh);
+    if (dy0 >= dh) return;
+    const int dx0 = (bx * 64 + lane) * 4;
+    uint8_t *slot = slots + (int64_t)b * slot_stride;
+    const int2 *xt = xtab + g.xtab_off[l];
+    const int4 *yt = ytab + g.ytab_off[l];
+    // the lane's four columns (a lane past the row's end takes the last column four times: its loads stay in the row, it stores nothing)
+    uint32_t sel[4], wt[4];
+    int sx0;
+    {
+        int2 t[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) t[q] = xt[min(dx0 + q, dw - 1)];
+        sx0 = t[0].x & 0xFFFF;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int p0 = (t[q].x & 0xFFFF) - sx0, p1 = (t[q].x >> 16) - sx0;          // 0..7: bytes of the window from sx0
+            sel[q] = (uint32_t)p0 | 0x0c00u | ((uint32_t)p1 << 16) | 0x0c000000u;
+            wt[q] = (uint32_t)t[q].y;
+        }
+    }
+    const int off0 = sx0 & 3, last_dw = (sw - 1) >> 2;
+    const int c0 = sx0 >> 2, c1 = min(c0 + 1, last_dw), c2 = min(c0 + 2, last_dw);       // (a clamped dword holds no tap of this lane)
+    const uint8_t *src = in_place ? orb_level0(z, b) : slot + g.origin[l - 1];
+    uint8_t *dst = slot + g.origin[l] + dx0;
+    const int dpitch = g.pitch[l];
+    const int rs = yt[dy0].x, re = yt[dy1 - 1].y;
+    auto request = [&](uint32_t (&d)[3], int r) {
+        const uint32_t *row = (const uint32_t *)(src + (int64_t)r * sp);
+        d[0] = row[c0]; d[1] = row[c1]; d[2] = row[c2];
+    };
+    auto hblend = [&](int (&H)[4], const uint32_t (&d)[3]) {
+        const uint32_t A = __builtin_amdgcn_alignbyte(d[1], d[0], off0), B = __builtin_amdgcn_alignbyte(d[2], d[1], off0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t taps = __builtin_amdgcn_perm(B, A, sel[q]);
+            int r;
+            asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(taps), "v"(wt[q]));      // (the VOP3P form: no zeroed accumulator to set up)
+            H[q] = r & ~15;
+        }
+    };
+    int dy = dy0;
+    int4 ty = yt[dy];
+    auto emit = [&](const int (&H0)[4], const int (&H1)[4]) {      // the output rows whose second source row is the one in H1
+        const uint32_t B0 = (uint32_t)ty.z << 12, B1 = (uint32_t)ty.w << 12;
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = ((mulhi_u24(B0, (uint32_t)H0[q]) + mulhi_u24(B1, (uint32_t)H1[q])) << 6) + 128u;   // byte 1 = (sum + 2) >> 2
+        const uint32_t lo = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0501u), hi = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0501u);
+        const uint32_t out = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        // origin and pitch are 4-byte aligned; the row's last dword may run up to three bytes into the 32-byte margin every
+        // level has on each side (nothing reads it: the blur reflects, cell FAST and this kernel ignore what they stage past a row)
+        if (dx0 < dw) *(uint32_t *)(dst + (int64_t)dy * dpitch) = out;
+    };
+    int HA[4] = {0, 0, 0, 0}, HB[4] = {0, 0, 0, 0};
+    // Source rows are requested three ahead.  Four rows a turn: the row buffers rotate with static indices, the roles
+    // (previous, current) alternate between HA and HB without moves.
+    uint32_t d[4][3];
+    // (measured: requesting unconditionally -- so that the compiler's s_waitcnt can count the loads in flight instead of
+    // waiting for all of them -- is no faster, 0.55 against 0.52 ms per 514 images: eight waves per SIMD hide the round trip)
+    request(d[0], rs);
+    if (rs + 1 <= re) request(d[1], rs + 1);
+    if (rs + 2 <= re) request(d[2], rs + 2);
+#define SVO_RS_STEP(K, HP, HC)                                                                        \
+        if (r + K + 3 <= re) request(d[(K + 3) & 3], r + K + 3);                                      \
+        hblend(HC, d[K]);                                                                             \
+        while (dy < dy1 && ty.y == r + K) {                                                           \
+            if (__builtin_expect(ty.x == r + K, 0)) emit(HC, HC); else emit(HP, HC);                  \
+            if (++dy < dy1) ty = yt[dy];                                                              \
+        }
+    for (int r = rs; r <= re; r += 4) {
+        SVO_RS_STEP(0, HB, HA)
+        if (r + 1 > re) break;
+        SVO_RS_STEP(1, HA, HB)
+        if (r + 2 > re) break;
+        SVO_RS_STEP(2, HB, HA)
+        if (r + 3 > re) break;
+        SVO_RS_STEP(3, HA, HB)
+    }
+#undef SVO_RS_STEP
 }
 
 // ---- per-cell FAST ---------------------------------------------------------------------------
@@ -195,7 +305,7 @@ __device__ __forceinline__ int fast_cornerness(const uint8_t *c, int P)
 // of the one-cell-per-workgroup kernel's, and the overlap columns are tested once instead of twice.
 __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, const uint8_t *slots, int64_t slot_stride,
                                                            int iniTh, int minTh, float4 *cell_cand, int *cell_cnt,
-                                                           int64_t cand_img_stride, int64_t cnt_img_stride, int n_img)
+                                                           int64_t cand_img_stride, int64_t cnt_img_stride, int n_img, OrbL0 z)
 {
     int b, blk_all;                                                       // image, workgroup index over all levels
     xcd_image_block(blockIdx.x, g.blks_total, n_img, b, blk_all);
@@ -210,7 +320,8 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
                                                              // quarter of the window's pixels: a fifth plane of bytes holds plane / 2 of them)
     __shared__ int s_any[kCellGroup], s_nkept[kCellGroup], s_nlist, s_ncand, s_nk;
     const int blk = blk_all - g.blk_off[l];
-    const int W = g.w[l], H = g.h[l], pitch = g.pitch[l];
+    const bool in_place = l == 0 && z.img != nullptr;                     // level 0 = the input image itself
+    const int W = g.w[l], H = g.h[l], pitch = in_place ? z.pitch : g.pitch[l];
     const int minBX = 16, minBY = 16, maxBX = W - 16, maxBY = H - 16;
     const int nCols = g.nCols[l], wCell = g.wCell[l], hCell = g.hCell[l], gcols = g.gcols[l], G = g.gcell[l];
     const int ci = blk / gcols, cg = blk - ci * gcols, cj0 = cg * G;
@@ -235,7 +346,7 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
     // instructions): (i + 0.5) / n is never within 1e-3 of an integer for the i, n that occur here,
     // far above the float error, so truncating (i + 0.5) * (1 / n) is exact
     const int lowTh = min(iniTh, minTh);
-    const uint8_t *img = slots + (int64_t)b * slot_stride + g.origin[l];
+    const uint8_t *img = in_place ? orb_level0(z, b) : slots + (int64_t)b * slot_stride + g.origin[l];
     if (tid < kCellGroup) { s_any[tid] = 0; s_nkept[tid] = 0; }
     if (tid == 0) { s_nlist = 0; s_ncand = 0; s_nk = 0; }
     // V must read 0 wherever the NMS looks and no cornerness is computed.  The rows of the tested pixels are
@@ -1458,15 +1569,16 @@ __global__ __launch_bounds__(kQpThreads) __attribute__((amdgpu_waves_per_eu(6, 6
 // column pass (28-row band), so neither the int intermediate image nor a second launch exists.
 constexpr int kBlurRows = kBlurRowsPerThread;     // 4 x 7: the row ring rotates with static indices
 __global__ __launch_bounds__(256) void orb_blur_kernel(OrbGeom g, const uint8_t *__restrict__ slots, int64_t slot_stride,
-                                                       uint8_t *__restrict__ blur, int64_t blur_img_stride)
+                                                       uint8_t *__restrict__ blur, int64_t blur_img_stride, OrbL0 z)
 {
     const int b = blockIdx.z;
     const int l = level_of_block(g.blur_blk, g.nlevels, blockIdx.y);      // blockIdx.y = row band over all levels
-    const int w = g.w[l], h = g.h[l], pitch = g.pitch[l];
+    const bool in_place = l == 0 && z.img != nullptr;                     // level 0 = the input image itself
+    const int w = g.w[l], h = g.h[l], pitch = in_place ? z.pitch : g.pitch[l];
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y0 = ((blockIdx.y - g.blur_blk[l]) * 4 + threadIdx.y) * kBlurRows;
     if (x0 >= w || y0 >= h) return;
-    const uint8_t *lvl = slots + (int64_t)b * slot_stride + g.origin[l];
+    const uint8_t *lvl = in_place ? orb_level0(z, b) : slots + (int64_t)b * slot_stride + g.origin[l];
     uint8_t *dst = blur + (int64_t)b * blur_img_stride + g.blur_off[l] + x0;
     const int bp = g.bpitch[l];
     // BORDER_REFLECT_101 is applied HERE (ORBextractor.cpp:1034-1035 blurs the un-bordered clone of the level):
@@ -1511,8 +1623,11 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(OrbGeom g, const uint8_t 
     auto load_row = [&](int yy, uint32_t (&d)[3]) {
         yy = yy < 0 ? -yy : (yy >= h ? 2 * h - 2 - yy : yy);        // reflect-101 (one reflection: |offset| < 32 <= h)
         yy = min(max(yy, 0), h - 1);
-        const uint32_t *p = (const uint32_t *)(lvl + (int64_t)yy * pitch + x0 - 4);   // (a thread at a row end reads a few
-        d[0] = p[0]; d[1] = p[1]; d[2] = p[2];                                        //  bytes of the slot's unused frame area)
+        // (a thread at a row end reads a few bytes past it -- the slot's unused frame area, or an input row's padding --; the
+        //  dword LEFT of a row's first one is never needed, the reflection replaces every byte of it: the row's first thread
+        //  reads its own dword twice instead, so that row 0 of an input image read in place stays inside the buffer)
+        const uint32_t *p = (const uint32_t *)(lvl + (int64_t)yy * pitch + x0);
+        d[0] = p[x0 == 0 ? 0 : -1]; d[1] = p[0]; d[2] = p[1];
         if (wave_edge) {
             const uint32_t d0 = d[0], d1 = d[1], d2 = d[2];
 #pragma unroll
@@ -1581,6 +1696,7 @@ struct OrbDescArgs {
     OrbGeom g;
     const uint8_t *slots; int64_t slot_stride;
     const uint8_t *blur; int64_t blur_img_stride;
+    OrbL0 z;                                                         // level 0 read in place (z.img != null)
     const float4 *lvl_cand; int cand_cap;
     const int *sel; const int *sel_cnt; int sel_cap;
     svo_keypoint *kps; uint8_t *desc; int *n_out; int out_cap;       // per image: out_cap keypoints
@@ -1622,7 +1738,8 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     }
     __shared__ int4 s_lv[kOrbMaxLevels];                                 // origin, pitch, blurred pitch, blurred offset of a level
     if (threadIdx.x < kOrbMaxLevels)
-        s_lv[threadIdx.x] = make_int4((int)a.g.origin[threadIdx.x], a.g.pitch[threadIdx.x], a.g.bpitch[threadIdx.x], (int)a.g.blur_off[threadIdx.x]);
+        s_lv[threadIdx.x] = threadIdx.x == 0 && a.z.img ? make_int4(0, a.z.pitch, a.g.bpitch[0], (int)a.g.blur_off[0])      // level 0 in place: see img_base
+                                                       : make_int4((int)a.g.origin[threadIdx.x], a.g.pitch[threadIdx.x], a.g.bpitch[threadIdx.x], (int)a.g.blur_off[threadIdx.x]);
     __syncthreads();
     const bool valid = gidx < total && gidx < a.out_cap;
     if (__ballot(valid) == 0ull) return;
@@ -1651,24 +1768,34 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     __shared__ uint32_t s_raw[8][31 * 9], s_blr[8][39 * 11];
     const int hw = (threadIdx.x >> 6) * 2 + half;
     uint32_t *raw = s_raw[hw], *blr = s_blr[hw];
-    // (addresses = a base that is uniform over the workgroup + a 32-bit offset per lane: an image's slot is a few MB)
-    const uint8_t *img_base = a.slots + (int64_t)b * a.slot_stride;                // 4-byte aligned rows
+    // (addresses = a base that is uniform over the wave + a 32-bit offset per lane: an image's slot is a few MB.  The keypoints of
+    // a level 0 that is read in place take their windows from the input image instead: keypoints are ordered by level, so a wave
+    // is all level 0 or has none of it -- the base stays in scalar registers -- except the one wave per image that straddles the
+    // boundary, which runs the fetch twice, each half-wave in its pass)
+    const uint8_t *slot_base = a.slots + (int64_t)b * a.slot_stride;               // 4-byte aligned rows
+    const uint8_t *lvl0 = a.z.img ? orb_level0(a.z, b) : nullptr;
+    const unsigned long long m0 = lvl0 ? __ballot(l == 0) : 0ull;
+    const bool mixed = m0 != 0ull && m0 != ~0ull;
     const int rx0 = (ix - 15) & ~3, roff = (ix - 15) - rx0;
     // a lane keeps ONE dword column of the window and walks down the rows (27 of the 32 lanes: 9 columns x 3 rows per
     // step): the address and the LDS index advance by a constant, no division or multiplication per load
-    {
+#pragma nounroll
+    for (int pass = 0; pass < (mixed ? 2 : 1); pass++) {
+        const bool from0 = mixed ? pass == 1 : m0 != 0ull;
+        const uint8_t *img_base = from0 ? lvl0 : slot_base;
+        const bool mine = sl < 27 && (!mixed || (l == 0) == from0);
         const int c = sl % 9, rr = sl / 9;
         uint32_t off = (uint32_t)lv.x + (uint32_t)((iy - 15 + rr) * pitch + rx0 + 4 * c);
         int li = rr * 9 + c;
         uint32_t v[11];                                              // (all the loads in flight before the first LDS store)
 #pragma unroll
         for (int t = 0; t < 11; t++) {
-            v[t] = sl < 27 && rr + 3 * t < 31 ? *(const uint32_t *)(img_base + off) : 0u;
+            v[t] = mine && rr + 3 * t < 31 ? *(const uint32_t *)(img_base + off) : 0u;
             off += 3u * (uint32_t)pitch;
         }
 #pragma unroll
         for (int t = 0; t < 11; t++) {
-            if (sl < 27 && rr + 3 * t < 31) raw[li] = v[t];
+            if (mine && rr + 3 * t < 31) raw[li] = v[t];
             li += 27;
         }
     }
@@ -2068,6 +2195,32 @@ void orb_make_tables(const OrbGeom &g, std::vector<int2> &xt, std::vector<int4> 
     }
 }
 
+// Which levels the row-streaming resize kernel covers: every group of four output columns must find its taps inside the
+// 8-byte window from its first source column, the weights must be non-negative 11-bit values, and the second source row of
+// consecutive output rows must not decrease (the walk goes down the source rows once).  True for every scale factor in (1, 2].
+void orb_resize_stream_levels(OrbGeom &g, const std::vector<int2> &xt, const std::vector<int4> &yt)
+{
+    for (int l = 0; l < kOrbMaxLevels; l++) g.rs_stream[l] = 0;
+    for (int l = 1; l < g.nlevels; l++) {
+        bool ok = true;
+        const int dw = g.w[l], dh = g.h[l];
+        for (int dx0 = 0; dx0 < dw && ok; dx0 += 4) {
+            const int s0 = xt[(size_t)g.xtab_off[l] + dx0].x & 0xFFFF;
+            for (int q = 0; q < 4; q++) {
+                const int2 t = xt[(size_t)g.xtab_off[l] + (dx0 + q < dw ? dx0 + q : dw - 1)];
+                const int a0 = (short)(t.y & 0xFFFF), a1 = t.y >> 16;
+                if ((t.x & 0xFFFF) < s0 || (t.x >> 16) - s0 > 7 || (t.x >> 16) < (t.x & 0xFFFF) || a0 < 0 || a1 < 0 || a0 > 2048 || a1 > 2048) ok = false;
+            }
+        }
+        for (int dy = 0; dy < dh && ok; dy++) {
+            const int4 t = yt[(size_t)g.ytab_off[l] + dy];
+            if (t.y < t.x || t.y > t.x + 1 || t.z < 0 || t.w < 0 || t.z > 2048 || t.w > 2048) ok = false;
+            if (dy > 0 && t.y < yt[(size_t)g.ytab_off[l] + dy - 1].y) ok = false;
+        }
+        g.rs_stream[l] = ok ? 1 : 0;
+    }
+}
+
 
 int orb_alloc(svo_ctx *ctx)
 {
@@ -2115,6 +2268,9 @@ int orb_alloc(svo_ctx *ctx)
     {
         std::vector<int2> xt; std::vector<int4> yt;
         orb_make_tables(g, xt, yt);
+        orb_resize_stream_levels(g, xt, yt);
+        ctx->orb_resize_staged = getenv("SVO_ORB_RESIZE_STAGED") != nullptr;      // the round-4 kernel, for A/B measurements and its test
+        ctx->orb_copy_level0 = getenv("SVO_ORB_COPY_LEVEL0") != nullptr;          // level 0 always copied into the slot (A/B, its test)
         DA(ctx->orb_xtab, sizeof(int2) * (xt.size() + 1));
         DA(ctx->orb_ytab, sizeof(int4) * (yt.size() + 1));
         // (inside svo_create the buffers exist only after the context's one allocation: the uploads wait for it)
@@ -2159,7 +2315,7 @@ void orb_free(svo_ctx *) {}        // the ORB buffers belong to the context's ar
 // ORBextractor::operator() on `n_img` images (image b at img + b*img_stride, or interleaved L/R
 // when img2 != null) into output slots [slot0, slot0 + n_img).
 int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int pitch, int64_t img_stride, int slot0,
-                      int n_img, hipStream_t st)
+                      int n_img, hipStream_t st, bool in_place)
 {
     const OrbGeom &g = ctx->orb_geom;
     const int L = g.nlevels, kCandCap = ctx->orb_cand_cap;
@@ -2167,35 +2323,57 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     dim3 blk(256);
     int *ovf = ctx->orb_overflow + slot0;
     SVO_HIP(hipMemsetAsync(ovf, 0, sizeof(int) * (size_t)n_img, st));
+    // Level 0 is the input image: read IN PLACE when the caller says the images stay put until this call's kernels are done
+    // (the batched and online paths: frame buffers / staging owned by the context) and they can be read the way the slots are --
+    // 16-byte aligned rows with at least 16 bytes of padding (the blur, the descriptor windows and the aligned staging loads
+    // run a few bytes past a row's last pixel).  Otherwise (stage API, odd pitches) it is copied into the slot first:
+    // 0.16 ms per 514 images alone, 0.36 ms beside the previous batch's pose stage.
+    OrbL0 z{};
+    if (in_place && !ctx->orb_copy_level0 && ((uintptr_t)img & 15) == 0 && (!img2 || ((uintptr_t)img2 & 15) == 0) && (pitch & 15) == 0 && (img_stride & 15) == 0 &&
+        pitch >= g.w[0] + 16)
+        z = OrbL0{img, img2, pitch, img_stride};
     {
-        const int lanes = (g.w[0] + 15) / 16, bx = lanes < 256 ? lanes : 256, by = 256 / bx;
-        const dim3 cblk(bx, by), cgrid((lanes + bx - 1) / bx, (g.h[0] + by - 1) / by, img2 ? n_img / 2 : n_img);
-        if (img2) {
-            // left images -> even slots, right images -> odd slots
-            hipLaunchKernelGGL(orb_copy0_kernel, cgrid, cblk, 0, st, g, img, pitch, img_stride, slots, 2 * g.slot_bytes);
-            hipLaunchKernelGGL(orb_copy0_kernel, cgrid, cblk, 0, st, g, img2, pitch, img_stride, slots + g.slot_bytes, 2 * g.slot_bytes);
-        } else {
-            hipLaunchKernelGGL(orb_copy0_kernel, cgrid, cblk, 0, st, g, img, pitch, img_stride, slots, g.slot_bytes);
+        const int n = n_img;
+        uint8_t *sl = slots;
+        if (!z.img) {
+            const int lanes = (g.w[0] + 15) / 16, bx = lanes < 256 ? lanes : 256, by = 256 / bx;
+            const dim3 cblk(bx, by), cgrid((lanes + bx - 1) / bx, (g.h[0] + by - 1) / by, img2 ? n / 2 : n);
+            if (img2) {
+                // left images -> even slots, right images -> odd slots
+                hipLaunchKernelGGL(orb_copy0_kernel, cgrid, cblk, 0, st, g, img, pitch, img_stride, sl, 2 * g.slot_bytes);
+                hipLaunchKernelGGL(orb_copy0_kernel, cgrid, cblk, 0, st, g, img2, pitch, img_stride, sl + g.slot_bytes, 2 * g.slot_bytes);
+            } else {
+                hipLaunchKernelGGL(orb_copy0_kernel, cgrid, cblk, 0, st, g, img, pitch, img_stride, sl, g.slot_bytes);
+            }
         }
-    }
-    for (int l = 0; l < L; l++) {
-        if (l > 0) {
+        for (int l = 1; l < L; l++) {
+            if (g.rs_stream[l] && !ctx->orb_resize_staged) {
+                // output rows per wave: long bands amortise a wave's set-up (its table entries, the first source row), short ones
+                // keep >= 16 K waves in the launch (the small levels, the online pair)
+                const int gx = ((g.w[l] + 3) / 4 + 63) / 64;
+                int band = (int)((int64_t)g.h[l] * gx * n / 16384) & ~7;
+                band = band < 8 ? 8 : band > 32 ? 32 : band;
+                const int gy = (g.h[l] + 4 * band - 1) / (4 * band);
+                hipLaunchKernelGGL(orb_resize_stream_kernel, dim3(gx * gy * n), blk, 0, st, g, sl, g.slot_bytes, l,
+                                   (const int2 *)ctx->orb_xtab, (const int4 *)ctx->orb_ytab, n, gx, gy, band, z);
+                continue;
+            }
             // source rows a strip of kResizeRows output rows can touch (+3: second tap, rounding), and the
             // dwords 1024 output columns can span (+3: second tap, alignment slack)
             int cap_rows = (int)((double)kResizeRows * g.h[l - 1] / g.h[l]) + 3;
             int row_dw = (((int)(1024.0 * g.w[l - 1] / g.w[l] / 4.0) + 3 + 4) + 3) & ~3;     // + the 16-byte alignment slack, multiple of 4
             if ((size_t)cap_rows * row_dw * 4 > 60 * 1024) cap_rows = 60 * 1024 / (row_dw * 4);     // beyond it: the unstaged path
-            hipLaunchKernelGGL(orb_resize_kernel, dim3((g.w[l] + 1023) / 1024, (g.h[l] + kResizeRows - 1) / kResizeRows, n_img), blk,
-                               (size_t)cap_rows * row_dw * 4, st, g, slots, g.slot_bytes, l,
-                               (const int2 *)ctx->orb_xtab, (const int4 *)ctx->orb_ytab, cap_rows, row_dw);
+            hipLaunchKernelGGL(orb_resize_kernel, dim3((g.w[l] + 1023) / 1024, (g.h[l] + kResizeRows - 1) / kResizeRows, n), blk,
+                               (size_t)cap_rows * row_dw * 4, st, g, sl, g.slot_bytes, l,
+                               (const int2 *)ctx->orb_xtab, (const int4 *)ctx->orb_ytab, cap_rows, row_dw, z);
         }
+        // the blurred levels only depend on the pyramid: computed here, before the LDS-hungry kernels,
+        // so that in overlap mode the previous batch's pose solver (74 KB of LDS per workgroup) runs
+        // beside kernels that need no LDS
+        uint8_t *blur = ctx->orb_blur + (size_t)slot0 * g.blur_total;
+        hipLaunchKernelGGL(orb_blur_kernel, dim3((g.w[0] + 255) / 256, g.blur_blk[L], n), dim3(64, 4), 0, st, g, sl, g.slot_bytes,
+                           blur, g.blur_total, z);
     }
-    // the blurred levels only depend on the pyramid: computed here, before the LDS-hungry kernels,
-    // so that in overlap mode the previous batch's pose solver (74 KB of LDS per workgroup) runs
-    // beside kernels that need no LDS
-    uint8_t *blur = ctx->orb_blur + (size_t)slot0 * g.blur_total;
-    hipLaunchKernelGGL(orb_blur_kernel, dim3((g.w[0] + 255) / 256, g.blur_blk[L], n_img), dim3(64, 4), 0, st, g, slots, g.slot_bytes,
-                       blur, g.blur_total);
     timing_mark(ctx, "orb_pyramid");
     float4 *cell_cand = ctx->orb_cell_cand + (size_t)slot0 * g.cells_total * kCellCap;
     int *cell_cnt = ctx->orb_cell_cnt + (size_t)slot0 * g.cells_total;
@@ -2205,7 +2383,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
         if (g.blks_total > 0)
             hipLaunchKernelGGL(orb_cellfast_kernel, dim3(g.blks_total * n_img), dim3(kCellThreads), (size_t)5 * ((kCellPitch * (hmax + 6) + 15) & ~15) + 16, st,
                                g, slots, g.slot_bytes, ctx->cfg.orb_ini_th, ctx->cfg.orb_min_th, cell_cand, cell_cnt,
-                               (int64_t)g.cells_total * kCellCap, (int64_t)g.cells_total, n_img);
+                               (int64_t)g.cells_total * kCellCap, (int64_t)g.cells_total, n_img, z);
     }
     float4 *lvl_cand = ctx->orb_lvl_cand + (size_t)slot0 * L * kCandCap;
     int *lvl_cnt = ctx->orb_lvl_cnt + (size_t)slot0 * L;
@@ -2224,7 +2402,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
         hipLaunchKernelGGL(orb_distribute_kernel, dim3(n_img, L), dim3(64), qlds_bytes(ctx->orb_node_cap), st, d);
     timing_mark(ctx, "orb_quadtree");
     OrbDescArgs e{};
-    e.g = g; e.slots = slots; e.slot_stride = g.slot_bytes; e.blur = blur; e.blur_img_stride = g.blur_total;
+    e.g = g; e.z = z; e.slots = slots; e.slot_stride = g.slot_bytes; e.blur = ctx->orb_blur + (size_t)slot0 * g.blur_total; e.blur_img_stride = g.blur_total;
     e.lvl_cand = lvl_cand; e.cand_cap = kCandCap; e.sel = d.sel; e.sel_cnt = d.sel_cnt; e.sel_cap = ctx->orb_node_cap;
     e.kps = (svo_keypoint *)ctx->orb_kps + (size_t)slot0 * ctx->orb_kp_cap; e.desc = ctx->orb_desc + (size_t)slot0 * ctx->orb_kp_cap * 32;
     e.n_out = ctx->orb_n + slot0; e.out_cap = ctx->orb_kp_cap; e.overflow = ovf;

@@ -42,7 +42,8 @@ static int ingest_frames(svo_ctx *ctx, const uint8_t *L, const uint8_t *R, int p
         // Detect_MyORBFeatures (src/tracking.cpp:502-532): ORBextractor on the left AND right image;
         // frame f -> feature slots 2f (left), 2f+1 (right)
         // (orb_extract_batch records its own stage marks: orb_pyramid, orb_cellfast, orb_quadtree, orb_describe)
-        return orb_extract_batch(ctx, L, R, pitch, frame_stride, 2 * f0, 2 * n_new, ctx->stream);
+        // (level 0 read in place: the frames belong to the caller's batch / the context's staging until the step is done)
+        return orb_extract_batch(ctx, L, R, pitch, frame_stride, 2 * f0, 2 * n_new, ctx->stream, /*in_place*/ true);
     }
     const PyrGeom &g = ctx->geom;
     PyrArgs p{};

@@ -68,6 +68,8 @@ struct svo_ctx {
     // ---- ORB path (allocated on first use: orb_alloc)
     bool orb_ready = false;
     bool orb_qt_parallel = false;            // the node-parallel quadtree kernel is usable for this configuration
+    bool orb_resize_staged = false;          // SVO_ORB_RESIZE_STAGED: the LDS-staged resize kernel on every level (A/B measurements, its test)
+    bool orb_copy_level0 = false;            // SVO_ORB_COPY_LEVEL0: level 0 copied into the slot even where it could be read in place (A/B, its test)
     svo::OrbGeom orb_geom;
     uint8_t *orb_slots = nullptr, *orb_blur = nullptr;
     void *orb_xtab = nullptr, *orb_ytab = nullptr;       // cv::resize coordinate / weight tables
@@ -148,7 +150,7 @@ const uint8_t *pnp_inlier_mask(const svo_ctx *ctx);
 int stage_chain_relative(svo_ctx *ctx, const double *T, const int32_t *ok, int n, const double *pose0_host, double *out, int mem);
 int stage_host_image(svo_ctx *ctx, const uint8_t *img, int pitch, int stage_idx, const uint8_t **dptr, int *dpitch);
 int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int pitch, int64_t img_stride, int slot0,
-                      int n_img, hipStream_t st);
+                      int n_img, hipStream_t st, bool in_place = false);
 int orb_match_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, hipStream_t st);
 void orb_launch_match_fixed(svo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, hipStream_t st);
 void launch_finalize_chain(svo_ctx *ctx, int n_pairs, const int *n_prev, const int *n_cur, const int *ovf,

@@ -38,9 +38,19 @@ struct OrbGeom {
     // the cell-FAST launch: a workgroup takes gcell[l] consecutive cells of a cell row (gcols[l] workgroups per row)
     int gcell[kOrbMaxLevels], gcols[kOrbMaxLevels], blk_off[kOrbMaxLevels], blks_total;
     int xtab_off[kOrbMaxLevels], ytab_off[kOrbMaxLevels], xtab_total, ytab_total;   // resize tables (levels >= 1)
+    int rs_stream[kOrbMaxLevels];        // level l is produced by the row-streaming resize kernel (orb_resize_stream_levels)
     // the blur launch covers ALL levels: first block (y) of level l
     int blur_blk[kOrbMaxLevels + 1];
 };
+
+// Level 0 of the ORB pyramid read IN PLACE from the input images (the batched and online paths, whose frames stay put until the
+// step's kernels are done): left / right images interleave into the image slots 2f, 2f + 1.  img == null: level 0 was copied
+// into the slot (stage API, inputs that cannot be read as aligned dwords).
+struct OrbL0 { const uint8_t *img, *img2; int pitch; int64_t stride; };
+__device__ __forceinline__ const uint8_t *orb_level0(const OrbL0 &z, int b)
+{
+    return z.img2 ? ((b & 1) ? z.img2 : z.img) + (int64_t)(b >> 1) * z.stride : z.img + (int64_t)b * z.stride;
+}
 
 // inclusive prefix sum over the wave's lanes on the DPP network (row shifts inside the rows of 16, then the two row
 // broadcasts: the sequence of LLVM's AMDGPUAtomicOptimizer for gfx9) -- six adds, no LDS round trips

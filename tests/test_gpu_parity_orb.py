@@ -143,6 +143,23 @@ def test_orb_mode_online_and_batch_parity(pkg, oracle, tc, synth):
     c.sync()
     assert np.frombuffer(dres.cpu().numpy().tobytes(), dtype=pkg.STEP_DTYPE).tobytes() == res.tobytes()
     c.close()
+    # frames with padded rows (pitch 864: 16-byte aligned, >= 16 bytes of padding) are read IN PLACE as pyramid level 0 -- the
+    # tensors above (pitch = width) were copied into the slots first --; same records, also with the copy forced
+    Lp = tc.zeros((4, h, w + 32), dtype=tc.uint8, device="cuda")
+    Rp = tc.zeros((4, h, w + 32), dtype=tc.uint8, device="cuda")
+    Lp[:, :, :w] = L
+    Rp[:, :, :w] = R
+    Lp[:, :, w:] = 0xA5                                    # (whatever lies in the padding must not matter)
+    import os
+    for force_copy in (False, True):
+        if force_copy:
+            os.environ["SVO_ORB_COPY_LEVEL0"] = "1"
+        try:
+            c = pkg.Context(w, h, device=0, max_batch=3, **kw)
+            assert c.track_batch(Lp[:, :, :w], Rp[:, :, :w]).tobytes() == res.tobytes()
+            c.close()
+        finally:
+            os.environ.pop("SVO_ORB_COPY_LEVEL0", None)
 
 
 def test_orb_mode_failure_stages(pkg, oracle, tc, synth):
@@ -236,3 +253,24 @@ def test_match_hamming_shapes_and_ties(pkg, oracle, tc, nq, nt):
     idx, dist = ctx.match_hamming(q, t)
     assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
     ctx.close()
+
+
+def test_orb_pyramid_both_resize_kernels(pkg, oracle, tc, monkeypatch):
+    """ComputePyramid (src/ORBextractor.cpp:1061-1085) through the row-streaming resize kernel (scale factors in (1, 2]) and
+    through the LDS-staged one it replaced (SVO_ORB_RESIZE_STAGED=1; taken by itself for a scale factor whose four taps do
+    not fit the streaming kernel's 8-byte window): every level byte-equal to the oracle's cv::resize restatement, keypoints
+    and descriptors byte-equal to the oracle's; host image and a device image with padded rows."""
+    img = rand_image(201, 333, 7)
+    img_dev = tc.from_numpy(np.ascontiguousarray(np.pad(img, ((0, 0), (0, 3))))).cuda()[:, :333]     # pitch 336
+    for env, sf, nl in ((None, 1.2, 8), ("SVO_ORB_RESIZE_STAGED", 1.2, 8), (None, 2.0, 4), (None, 2.7, 3), (None, 1.05, 8)):
+        monkeypatch.delenv("SVO_ORB_RESIZE_STAGED", raising=False)
+        if env:
+            monkeypatch.setenv(env, "1")
+        ctx = pkg.Context(333, 201, device=0, track_mode=pkg.MODE_ORB, max_keypoints=8192, orb_nlevels=nl, orb_scale_factor=sf)
+        rk, rd, _ = oracle.orb_extract(img, nlevels=nl, scale_factor=sf, nfeatures=2000, ini_th=20, min_th=7)
+        for src in (img, img_dev):
+            kps, desc, _ = ctx.orb_extract(src)
+            for l in range(nl):
+                assert np.array_equal(ctx.orb_read_level(l), oracle.orb_pyramid_level(img, l, scale_factor=sf, nlevels=nl)), (env, sf, l)
+            assert kps.tobytes() == rk.tobytes() and desc.tobytes() == rd.tobytes(), (env, sf)
+        ctx.close()
