@@ -20,7 +20,9 @@
  *    svo_signal_stream(ctx, consumer_stream) -- or svo_sync() -- before it reads device-resident results from another
  *    stream (ABI v7; both are event waits on the device, no host synchronisation).
  *  - one context per (thread, GPU); calls on a context are serialised by the caller.
- *  - images are 8-bit grayscale, row-major, `pitch` bytes per row.
+ *  - images are 8-bit grayscale, row-major, `pitch` bytes per row.  A call's kernels read the caller's DEVICE frames in the order
+ *    of the context's stream until the call's last front-end kernel (ORB mode reads pyramid level 0 in place; LK mode runs FAST
+ *    on the frame itself): frames handed over with SVO_MEM_DEVICE stay unchanged until then (svo_sync, or stream order).
  */
 #ifndef SVO_ABI_H
 #define SVO_ABI_H
@@ -189,7 +191,8 @@ int svo_pnp_ransac(svo_ctx *ctx, const svo_pt3f *obj, const svo_pt2f *img, int n
  * the keypoints kept per pyramid level. */
 int svo_orb_extract(svo_ctx *ctx, const uint8_t *img, int pitch, int mem, svo_keypoint *kps, uint8_t *desc,
                     int cap, int *n_out, int *per_level);
-/* test/debug read-back of one ORB pyramid level (tight rows) of the last svo_orb_extract */
+/* test/debug read-back of one ORB pyramid level (tight rows) of the last svo_orb_extract.  (After svo_add_frame / a batch call in
+ * ORB mode level 0 may not be there -- those read it in place from the input frame -- and asking for it is SVO_ERR_ARG.) */
 int svo_orb_read_level(svo_ctx *ctx, int level, uint8_t *out, int *w, int *h);
 /* test/debug: FAST candidates (x, y, response, 0) of one level of the last svo_orb_extract, before the quadtree */
 int svo_orb_read_candidates(svo_ctx *ctx, int level, float *out4, int cap, int *n_out);

@@ -2332,6 +2332,7 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     if (in_place && !ctx->orb_copy_level0 && ((uintptr_t)img & 15) == 0 && (!img2 || ((uintptr_t)img2 & 15) == 0) && (pitch & 15) == 0 && (img_stride & 15) == 0 &&
         pitch >= g.w[0] + 16)
         z = OrbL0{img, img2, pitch, img_stride};
+    ctx->orb_level0_in_slot = z.img == nullptr;
     {
         const int n = n_img;
         uint8_t *sl = slots;

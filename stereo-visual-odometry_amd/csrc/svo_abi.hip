@@ -667,6 +667,9 @@ extern "C" int svo_orb_read_level(svo_ctx *ctx, int level, uint8_t *out, int *w,
     if (w) *w = g.w[level];
     if (h) *h = g.h[level];
     if (!out) return SVO_OK;
+    // (svo_add_frame / the batch calls read level 0 in place from the caller's frames: image slot 0 then holds levels >= 1 only)
+    SVO_ARG(level > 0 || ctx->orb_level0_in_slot, "level 0 was read in place from the input frame by the last extraction (svo_add_frame / batch): "
+                                                  "it is the input image; svo_orb_extract copies it");
     SVO_HIP(hipMemcpy2DAsync(out, g.w[level], ctx->orb_slots + g.origin[level], g.pitch[level], g.w[level], g.h[level],
                              hipMemcpyDeviceToHost, ctx->stream));
     SVO_HIP(hipStreamSynchronize(ctx->stream));

@@ -68,6 +68,7 @@ struct svo_ctx {
     // ---- ORB path (allocated on first use: orb_alloc)
     bool orb_ready = false;
     bool orb_qt_parallel = false;            // the node-parallel quadtree kernel is usable for this configuration
+    bool orb_level0_in_slot = false;         // the last extraction copied level 0 into the image slots (false: read in place, OrbL0)
     bool orb_resize_staged = false;          // SVO_ORB_RESIZE_STAGED: the LDS-staged resize kernel on every level (A/B measurements, its test)
     bool orb_copy_level0 = false;            // SVO_ORB_COPY_LEVEL0: level 0 copied into the slot even where it could be read in place (A/B, its test)
     svo::OrbGeom orb_geom;

@@ -274,3 +274,18 @@ def test_orb_pyramid_both_resize_kernels(pkg, oracle, tc, monkeypatch):
                 assert np.array_equal(ctx.orb_read_level(l), oracle.orb_pyramid_level(img, l, scale_factor=sf, nlevels=nl)), (env, sf, l)
             assert kps.tobytes() == rk.tobytes() and desc.tobytes() == rd.tobytes(), (env, sf)
         ctx.close()
+
+
+def test_orb_level0_in_place_is_not_in_the_slot(pkg, oracle, tc, synth):
+    """svo_add_frame in ORB mode reads pyramid level 0 in place from the (staged) input frame: the read-back of level 0 says so
+    instead of returning a stale slot; the levels built from it are the oracle's."""
+    seq = synth.StereoSequence(width=832, height=256, n_frames=1, seed=5)
+    left, right = (x.numpy() for x in seq.render(0))
+    c = pkg.Context(832, 256, device=0, track_mode=pkg.MODE_ORB)
+    c.add_frame(left, right)
+    with pytest.raises(pkg.SvoError):
+        c.orb_read_level(0)
+    assert np.array_equal(c.orb_read_level(1), oracle.orb_pyramid_level(left, 1))     # image slot 0 = the left image
+    c.orb_extract(left)                                                                 # the stage API copies level 0
+    assert np.array_equal(c.orb_read_level(0), left)
+    c.close()
