@@ -65,8 +65,11 @@ def run(pkg, O, torch, synth, n_pairs, mode="exact", batch=256, seed=20200710, w
     worst_pose = worst_rel = 0.0
     n_ok = tracked = 0
     t_gpu = t_cpu = 0.0
-    L = torch.zeros((B + 1, height, width), dtype=torch.uint8, device=dev)
-    R = torch.zeros_like(L)
+    # rows padded to a multiple of 256 bytes (>= 16 bytes of padding), like the product's frame buffers: ORB mode then reads
+    # pyramid level 0 in place from these tensors, the path the runner and the bench take
+    pitch = (width + 16 + 255) // 256 * 256
+    L = torch.full((B + 1, height, pitch), 0x5A, dtype=torch.uint8, device=dev)[:, :, :width]
+    R = torch.full((B + 1, height, pitch), 0xA5, dtype=torch.uint8, device=dev)[:, :, :width]
     last = None
     try:
         for p0 in range(0, n_pairs, B):
@@ -80,8 +83,8 @@ def run(pkg, O, torch, synth, n_pairs, mode="exact", batch=256, seed=20200710, w
             t0 = time.perf_counter()
             res = ctx.track_batch(L[:nb + 1], R[:nb + 1], pose0=pose_gpu)
             t_gpu += time.perf_counter() - t0
-            fl = L[:nb + 1].cpu().numpy()
-            fr = R[:nb + 1].cpu().numpy()
+            fl = np.ascontiguousarray(L[:nb + 1].cpu().numpy())
+            fr = np.ascontiguousarray(R[:nb + 1].cpu().numpy())
 
             def one_lk(t):
                 kps = O.fast(fl[t])
