@@ -75,10 +75,10 @@ def parse():
     ap.add_argument("--mode", choices=["lk", "orb"], default="lk",
                     help="lk = BASELINE config #2 (FAST+LK, the quoted metric); orb = config #3 (ORB extractor + "
                          "descriptor match path, the reference's shipped default track_mode)")
-    ap.add_argument("--lk-accum", choices=["exact", "sse2", "simd128"], default="exact",
+    ap.add_argument("--lk-accum", choices=["exact", "sse2", "simd128", "sse2_legacy"], default="exact",
                     help="order of the float sums inside the LK tracker (svo_config.lk_accum): exact = the canonical integer sums; "
-                         "sse2 / simd128 = float accumulation in a lane order of upstream's x86 SIMD code as restated in oracle/lk.c "
-                         "(modes 2 / 4; DESIGN.md section 2 C11), bit-identical to that oracle mode")
+                         "sse2 / simd128 / sse2_legacy = float accumulation in a lane order of upstream's x86 SIMD code as restated in "
+                         "oracle/lk.c (modes 2 / 4 / 3; DESIGN.md section 2 C11), bit-identical to that oracle mode")
     ap.add_argument("--shard", choices=["sequences", "pairs"], default="sequences")
     ap.add_argument("--config5", action="store_true", help="KITTI 00-07 sequence lengths dealt to the ranks (see the docstring)")
     ap.add_argument("--scaling-table", action="store_true",
@@ -292,7 +292,7 @@ def self_check(pkg, O, ctx, recs, L, R, width, f0, P1, P2, mode="lk", sse2=False
         pnp = O.pnp_ransac(O.triangulate(P1, P2, t1l, t1r), t2l, K) if len(t1l) >= 5 else None
         return r, [t1l, t1r, None, t2l], pnp
 
-    # sse2: False / True (oracle mode 2) or the oracle's accumulation mode itself (4 = the SIMD128 order)
+    # sse2: False / True (oracle mode 2) or the oracle's accumulation mode itself (4 = the SIMD128 order, 3 = the legacy SSE2 block)
     old = O.set_lk_accum(O.LK_ACCUM_EXACT if not sse2 else (O.LK_ACCUM_FLOAT_SSE if sse2 is True else int(sse2)))
     try:
         with ThreadPoolExecutor(max_workers=min(len(pairs), usable_cores())) as ex:
@@ -640,7 +640,7 @@ def main():
     if args.mode == "orb":       # config/default.yaml:75,87-93: ORB_stereof2f_pnp, minmove 0.05, maxmove 10
         mode_kw = dict(track_mode=pkg.MODE_ORB, min_move2=0.05 ** 2, max_move2=10.0 ** 2)
     if args.lk_accum != "exact":
-        mode_kw["lk_accum"] = pkg.LK_ACCUM_SSE2 if args.lk_accum == "sse2" else pkg.LK_ACCUM_SIMD128
+        mode_kw["lk_accum"] = {"sse2": pkg.LK_ACCUM_SSE2, "simd128": pkg.LK_ACCUM_SIMD128, "sse2_legacy": pkg.LK_ACCUM_SSE2_LEGACY}[args.lk_accum]
     ctx = pkg.Context(W, H, device=local_rank, max_batch=B, P1=P1, P2=P2, **mode_kw)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)            # launches, events and the RCCL gather share one stream
@@ -823,14 +823,16 @@ def main():
                                                 "(00-02 1241x376, 03 1242x375, 04-07 1226x370: a context per size), on the rank's rendered chunks "
                                                 "of that size, cycled (sequence LENGTHS and SIZES are modelled, not their content)",
                                         "frame_sizes": [f"{r['width']}x{r['height']}" for r in mg.KITTI_RIGS]}
-        out["roofline"] = (roofline_lk(stage_ms, pts_total, B, sse2=args.lk_accum != "exact") if stage_ms.get("lk") else
+        out["roofline"] = (roofline_lk(stage_ms, pts_total, B, sse2=args.lk_accum != "exact",
+                                       profile=("lk_" + args.lk_accum if args.lk_accum in ("simd128", "sse2_legacy") else None))   # (counters exist for exact / sse2)
+                           if stage_ms.get("lk") else
                            roofline_orb(stage_ms, B, W, H) if stage_ms.get("orb_cellfast") else None)
         if world == 1 and not args.config5 and not args.no_self_check and steps > 0:
             O = entry.load_oracle()
             O.build()
             # the context still holds the last step's tracks and masks (B pairs, overlap on, chunks cycled)
             out["self_check"] = self_check(pkg, O, ctx, res, L, R, W, ((steps - 1) % NC) * B, P1, P2, mode=args.mode,
-                                           sse2=({"exact": False, "sse2": True, "simd128": 4}[args.lk_accum] if not args.self_check_sabotage
+                                           sse2=({"exact": False, "sse2": True, "simd128": 4, "sse2_legacy": 3}[args.lk_accum] if not args.self_check_sabotage
                                                  else args.lk_accum == "exact"),
                                            n_check=args.self_check_pairs if args.mode == "lk" else max(32, args.self_check_pairs // 8))
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 7
+#define SVO_ABI_VERSION 8
 
 /* status codes */
 #define SVO_OK                 0
@@ -96,8 +96,11 @@ typedef struct {
            oracle mode; about 1.9x the LK kernel time;
        SVO_LK_ACCUM_SIMD128 (ABI v7): the universal-intrinsic (CV_SIMD128) block restated whole = oracle mode 4: b
            as above, A in groups of eight pixels (four lanes over x = 0..15 + scalar tail x = 16..20).  Same cost.
-           (The legacy CV_SSE2 block with one float add per pixel product is oracle mode 3; no kernel: DESIGN.md 2.)
-       YAML key `lk_accum: exact | sse2 | simd128`. */
+       SVO_LK_ACCUM_SSE2_LEGACY (ABI v8): the older hand-written CV_SSE2 block restated whole = oracle mode 3: A as in
+           SVO_LK_ACCUM_SSE2, b with one float add per pixel product (_mm_mullo / _mm_mulhi_epi16 of (It_k It_k) x (Ix_k Iy_k):
+           pixels 0, 1, then 4, 5 of a group of eight into qb0, 2, 3, then 6, 7 into qb1).  About 2.2x the LK kernel time.
+       Which of the three an x86 OpenCV 3 build runs depends on its version; none is validated
+       against a binary.  YAML key `lk_accum: exact | sse2 | simd128 | sse2_legacy`. */
     int32_t lk_accum;
     /* ABI v6.  LK mode, fused entry points only (svo_add_frame / svo_track_*): 0 = track every cv::FAST corner, as
        the reference does (src/tracking.cpp:94-113); N > 0 = keep the N highest-response corners of every left image
@@ -111,6 +114,7 @@ typedef struct {
 #define SVO_LK_ACCUM_EXACT 0
 #define SVO_LK_ACCUM_SSE2  1
 #define SVO_LK_ACCUM_SIMD128 2
+#define SVO_LK_ACCUM_SSE2_LEGACY 3
 
 typedef struct {                    /* solvePnPRansac + Rodrigues outcome */
     double rvec[3], tvec[3], R[9];

@@ -10,7 +10,7 @@ library or a GPU is missing.  The directory name contains '-', so load it throug
 `__graft_entry__.load_package()` (importlib) under the module name `stereo_visual_odometry_amd`.
 """
 from .binding import (Context, Config, StepResult, PnPResult, KP_DTYPE, STEP_DTYPE, SvoError,
-                      build_library, library_path, load_library, MEM_HOST, MEM_DEVICE, MODE_LK, MODE_ORB, LK_ACCUM_EXACT, LK_ACCUM_SSE2, LK_ACCUM_SIMD128)
+                      build_library, library_path, load_library, MEM_HOST, MEM_DEVICE, MODE_LK, MODE_ORB, LK_ACCUM_EXACT, LK_ACCUM_SSE2, LK_ACCUM_SIMD128, LK_ACCUM_SSE2_LEGACY)
 
 __all__ = ["Context", "Config", "StepResult", "PnPResult", "KP_DTYPE", "STEP_DTYPE", "SvoError",
-           "build_library", "library_path", "load_library", "MEM_HOST", "MEM_DEVICE", "MODE_LK", "MODE_ORB", "LK_ACCUM_EXACT", "LK_ACCUM_SSE2", "LK_ACCUM_SIMD128"]
+           "build_library", "library_path", "load_library", "MEM_HOST", "MEM_DEVICE", "MODE_LK", "MODE_ORB", "LK_ACCUM_EXACT", "LK_ACCUM_SSE2", "LK_ACCUM_SIMD128", "LK_ACCUM_SSE2_LEGACY"]

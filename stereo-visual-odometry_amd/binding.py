@@ -32,7 +32,7 @@ class Config(C.Structure):
 
 
 MODE_LK, MODE_ORB = 0, 1
-LK_ACCUM_EXACT, LK_ACCUM_SSE2, LK_ACCUM_SIMD128 = 0, 1, 2          # svo_config.lk_accum
+LK_ACCUM_EXACT, LK_ACCUM_SSE2, LK_ACCUM_SIMD128, LK_ACCUM_SSE2_LEGACY = 0, 1, 2, 3          # svo_config.lk_accum
 
 
 class PnPResult(C.Structure):

@@ -70,6 +70,18 @@ __host__ __device__ constexpr int a_stride(bool simd128) { return simd128 ? 84 :
 __host__ __device__ constexpr int a_tail_base(bool simd128) { return kAq0 + 4 * a_stride(simd128); }                   // 484 | 388
 constexpr int kLdsDwSse2 = kTilesDw + kSlots * kStageDw + 16;                      // 5024 dwords = 20 096 B (16: the A tail lane reads on past its words)
 constexpr int kDumpB = kChainOff[0] + 43, kDumpA = kStageDw - 1;                    // entries no chain uses: padding of lane chain 0 / the last word of the area
+// LEGACY b order (a.accum = 3, SVO_LK_ACCUM_SSE2_LEGACY = oracle mode 3: upstream's older CV_SSE2 block multiplies pixel by pixel --
+// _mm_mullo / _mm_mulhi_epi16 of (It_k It_k) x (Ix_k Iy_k) -- and adds the converted products one by one: pixels 0, 1, then 4, 5 of a
+// group of eight to qb0, 2, 3, then 6, 7 to qb1).  The eight lane chains are the same lanes as above, but a chain takes TWO terms per
+// group -- pixel k, then pixel k + 4 -- instead of their exact int32 sum: 84 terms (88 read), term t = 4 row + 2 group + (0 | 1).  A
+// slot's staging is 928 words: the tails at 0 / 108, lane chain c at 216 + 88 c; 25.7 KB of LDS per wave, six waves per CU.  (The
+// layout is the plain one: this order is kept for completeness -- whichever block a target OpenCV is found to run can be selected --,
+// not tuned like the two above.)
+constexpr int kStageDwL = 928, kTailYL = 0, kTailXL = 108, kChain0L = 216, kChainStrideL = 88;
+constexpr int kLdsDwLegacy = kTilesDw + kSlots * kStageDwL + 16;                   // 6432 dwords = 25 728 B
+constexpr int kDumpBL = kChain0L + 87, kDumpAL = kStageDwL - 1;
+static_assert(kChain0L + 8 * kChainStrideL <= kStageDwL && a_tail_base(false) + 24 < kStageDwL && kLdsDwLegacy * 4 <= 26 * 1024, "legacy staging");
+template <bool LEGACY> __host__ __device__ constexpr int stage_dw() { return LEGACY ? kStageDwL : kStageDw; }
 static_assert(kStageDw % 64 == 0 && kTailX % 4 == 0 && kTailY % 4 == 0 && kTilesDw % 4 == 0 && kAq0 % 4 == 0 && a_stride(false) % 4 == 0 && a_stride(true) % 4 == 0,
               "chain reads are 16-byte loads; the conflict-free order assumes a slot stride of whole bank rounds");
 static_assert(a_tail_base(false) + 24 < kStageDw && a_tail_base(true) + 108 < kStageDw && kJPairs2 <= kCS2 && kQPairs2 <= kCS2, "staging / tile geometry");
@@ -89,7 +101,7 @@ struct Sse2Lane {
     uint32_t pmask;         // mask of the patch pairs: a tail lane owns pixels 0..4 only (high halves = pixels 4..7 leave the pairs)
     uint32_t t4mask;        // tail lanes: the high half of pair 0 (pixel 4, x = 20) as a patch pair of its own; group lanes: 0
     uint32_t qoff;          // byte offset of the lane's first tile word inside a slot tile (I and J tiles share the layout)
-    uint32_t wb[10];        // b term j of slot 0 goes to LDS byte address wb[j]
+    uint32_t wb[16];        // b term j of slot 0 goes to LDS byte address wb[j] (ten terms; sixteen in the legacy order)
     uint32_t wa[8];         // patch word i (pixel x0 + i) of slot 0 goes to LDS byte address wa[i]
     uint32_t cb, cbA, cbB;  // b chain reads: own terms 0..43; the half row's tail terms 44 + 4 f.., 76 + 4 f.. (f = lane & 7)
     uint32_t ca;            // A chain read address
@@ -99,6 +111,7 @@ struct Sse2Lane {
 
 __device__ __forceinline__ void lds_store(uint32_t byte_addr, uint32_t v) { *(lds_u32 *)(size_t)byte_addr = v; }
 
+template <bool LEGACY>
 __device__ __forceinline__ Sse2Lane make_lane(int lane, uint32_t lds_base, bool simd128)
 {
     Sse2Lane L;
@@ -111,10 +124,20 @@ __device__ __forceinline__ Sse2Lane make_lane(int lane, uint32_t lds_base, bool 
     L.qoff = (uint32_t)((L.x0 * kCS2 + L.row) * 4);
     const uint32_t stage0 = lds_base + kTilesDw * 4;
 #pragma unroll
-    for (int j = 0; j < 10; j++) {
-        int e = kDumpB;
-        if (group && j < 8) e = kChainOff[j] + lane;                                    // lane chain j, term t = lane
-        if (tail) e = ((j & 1) ? kTailY : kTailX) + 5 * L.row + (j >> 1);               // tail x | y, term 5 row + i
+    for (int j = 0; j < 16; j++) {
+        int e;
+        if (!LEGACY) {
+            e = kDumpB;
+            if (group && j < 8) e = kChainOff[j] + lane;                                // lane chain j, term t = lane
+            if (tail && j < 10) e = ((j & 1) ? kTailY : kTailX) + 5 * L.row + (j >> 1); // tail x | y, term 5 row + i
+        } else {
+            // term j = 2 m + xy: pixel m of the lane's eight (m < 4), j = 8 + 2 m + xy: pixel m + 4
+            const int c = j & 7, second = j >> 3;
+            e = kDumpBL;
+            if (group) e = kChain0L + kChainStrideL * c + 4 * L.row + 2 * (lane & 1) + second;
+            if (tail && j < 8) e = ((j & 1) ? kTailYL : kTailXL) + 5 * L.row + (j >> 1);              // x = 16..19
+            if (tail && (j == 8 || j == 9)) e = ((j & 1) ? kTailYL : kTailXL) + 5 * L.row + 4;         // x = 20
+        }
         L.wb[j] = stage0 + (uint32_t)e * 4;
     }
     // patch words.  SSE2 order: pixel x -> W[x & 3][5 row + (x >> 2)] for x < 20, tail word `row` for x = 20.
@@ -123,7 +146,7 @@ __device__ __forceinline__ Sse2Lane make_lane(int lane, uint32_t lds_base, bool 
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int x = L.x0 + i;
-        int e = kDumpA;
+        int e = LEGACY ? kDumpAL : kDumpA;
         if (group || (tail && !simd128 && i < 4)) e = kAq0 + (x & 3) * aq + per_row * L.row + (x >> 2);
         if (tail && !simd128 && i == 4) e = at + L.row;
         if (tail && simd128 && i < 5) e = at + 5 * L.row + i;
@@ -133,13 +156,13 @@ __device__ __forceinline__ Sse2Lane make_lane(int lane, uint32_t lds_base, bool 
     // an idle position reads what a busy lane of ITS read group reads (one broadcast access): 5..7 follow position 4,
     // 13..15 position 12
     const int p = lane & 15, f = p & 7, h = p >> 3;
-    const uint32_t stage_s = stage0 + (uint32_t)((lane >> 4) * kStageDw) * 4;
-    const int tail_dw = h ? kTailY : kTailX;
+    const uint32_t stage_s = stage0 + (uint32_t)((lane >> 4) * stage_dw<LEGACY>()) * 4;
+    const int tail_dw = LEGACY ? (h ? kTailYL : kTailXL) : (h ? kTailY : kTailX);
     L.b_tail = f == 0;
     const int fc = f == 0 ? 0 : (f < 4 ? f : 4);                      // 1..4: the lane chain whose terms this position reads
     const int cmap = ((fc - 1) & 1) * 4 + ((fc - 1) >> 1) * 2 + h;
-    L.cb = stage_s + (uint32_t)(fc == 0 ? tail_dw : kChainOff[fc == 0 ? 0 : cmap]) * 4;
-    L.cbA = stage_s + (uint32_t)(tail_dw + 44 + 4 * f) * 4;
+    L.cb = stage_s + (uint32_t)(fc == 0 ? tail_dw : (LEGACY ? kChain0L + kChainStrideL * (fc == 0 ? 0 : cmap) : kChainOff[fc == 0 ? 0 : cmap])) * 4;
+    L.cbA = stage_s + (uint32_t)(tail_dw + (LEGACY ? 88 : 44) + 4 * f) * 4;
     L.cbB = L.cbA + 32 * 4;
     // A: positions 0..3 the SSE lanes, 4 the tail; 5..11 follow position 4, 12..15 position 0
     L.a_sel = simd128 ? (p == 4 ? 2 : 1) : (p == 4 ? 0 : 2);
@@ -269,9 +292,12 @@ __device__ __forceinline__ void patch_slot8(uint32_t tile_addr, const Sse2Lane &
 //               _mm_cvtepi32_ps does (round to nearest even);  v[8], v[9] = 0 (stored to a dump entry)
 // tail lanes:   v[2 i + xy] = (float)(diff_i I_i) for the tail pixels i = 0..3 (x = 16..19: the pairs' high halves are
 //               masked out of the patch), v[8 + xy] for i = 4 (x = 20: the high half of pair 0 against Ix4 / Iy4)
+// LEGACY (the older CV_SSE2 block): every product on its own -- v[2 m + xy] = (float)(diff_m I_m), v[8 + 2 m + xy] = (float)(diff_m+4
+// I_m+4) (group lanes: sixteen chain terms; tail lanes: pixels 0..3 in v[0..7], x = 20 in v[8 + xy], the rest zero)
+template <bool LEGACY>
 __device__ __forceinline__ void mismatch_slot8(const uint32_t (&C)[9], uint32_t Wa, uint32_t Wb, const uint32_t (&IvP)[4],
                                                const uint32_t (&IxP)[4], const uint32_t (&IyP)[4], uint32_t Ix4, uint32_t Iy4,
-                                               int vround, float (&v)[10])
+                                               int vround, float (&v)[16])
 {
     int d[8];
 #pragma unroll
@@ -280,10 +306,21 @@ __device__ __forceinline__ void mismatch_slot8(const uint32_t (&C)[9], uint32_t 
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         df[m] = as_u32(as_u16x2(perm_b32((uint32_t)d[m + 4], (uint32_t)d[m], 0x07060302u)) - as_u16x2(IvP[m]));
-        v[2 * m] = (float)dot2_0(df[m], IxP[m]);
-        v[2 * m + 1] = (float)dot2_0(df[m], IyP[m]);
+        if (!LEGACY) {
+            v[2 * m] = (float)dot2_0(df[m], IxP[m]);
+            v[2 * m + 1] = (float)dot2_0(df[m], IyP[m]);
+        } else {
+            // the pair's two products apart: the other half of the difference word masked away (a tail lane's pixel 4 rides Ix4 / Iy4:
+            // zero in the group lanes, whose pair 0 keeps its own high half)
+            const uint32_t lo = df[m] & 0x0000FFFFu, hi = df[m] & 0xFFFF0000u;
+            const uint32_t ixh = m == 0 ? (IxP[0] | Ix4) : IxP[m], iyh = m == 0 ? (IyP[0] | Iy4) : IyP[m];
+            v[2 * m] = (float)dot2_0(lo, IxP[m]);
+            v[2 * m + 1] = (float)dot2_0(lo, IyP[m]);
+            v[8 + 2 * m] = (float)dot2_0(hi, ixh);
+            v[8 + 2 * m + 1] = (float)dot2_0(hi, iyh);
+        }
     }
-    v[8] = (float)dot2_0(df[0], Ix4); v[9] = (float)dot2_0(df[0], Iy4);
+    if (!LEGACY) { v[8] = (float)dot2_0(df[0], Ix4); v[9] = (float)dot2_0(df[0], Iy4); }
 }
 
 // ---- the serial sums: every chain lane adds its chain's terms in order -------------------------------------------
@@ -297,9 +334,27 @@ __device__ __forceinline__ void tail_adds(float &acc, const f32x4 &q, int first_
     for (int e = 0; e < 4; e++)
         if (first_term + 4 * F + e < 105) acc += row_shl<F>(q[e]);
 }
+template <bool LEGACY>
 __device__ __forceinline__ float chain_b(const Sse2Lane &L)
 {
     lds_cf32x4 *p = (lds_cf32x4 *)(size_t)L.cb;
+    if (LEGACY) {
+        // 22 reads: the 84 terms of a lane chain (+ 4 of padding), the first 88 of a tail; terms 88..104 of the tails over the DPP
+        // network from five feeder lanes
+        const f32x4 qa = *(lds_cf32x4 *)(size_t)L.cbA;
+        float acc = 0.f, acc84 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 22; t++) {
+            const f32x4 q = p[t];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (4 * t + e == 84) acc84 = acc;
+                acc += q[e];
+            }
+        }
+        tail_adds<0>(acc, qa, 88); tail_adds<1>(acc, qa, 88); tail_adds<2>(acc, qa, 88); tail_adds<3>(acc, qa, 88); tail_adds<4>(acc, qa, 88);
+        return L.b_tail ? acc : acc84;
+    }
     const f32x4 qa = *(lds_cf32x4 *)(size_t)L.cbA, qb = *(lds_cf32x4 *)(size_t)L.cbB;
     float acc = 0.f, acc42 = 0.f;
 #pragma unroll
@@ -382,6 +437,7 @@ __device__ __forceinline__ float combine_a(float r)
 
 // One cv::calcOpticalFlowPyrLK call for the wave's four points (cf. lk_call4 in lk.hip; control values are per
 // lane = per slot lane >> 4).
+template <bool LEGACY>
 __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *slotI, const uint8_t *slotJ, float2 prevPt,
                                               float2 &outPt, int &status, bool live, uint32_t *lds, int lane,
                                               const Sse2Lane &L)
@@ -467,7 +523,7 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
                 patch_slot8<true>(qaddr, L, W01s, W23s, ipxs, ipys, w, h, IvP[s], IxP[s], IyP[s], Ix4[s], Iy4[s], Aw);
             else
                 patch_slot8<false>(qaddr, L, W01s, W23s, ipxs, ipys, w, h, IvP[s], IxP[s], IyP[s], Ix4[s], Iy4[s], Aw);
-            const uint32_t so = (uint32_t)(s * kStageDw * 4);
+            const uint32_t so = (uint32_t)(s * stage_dw<LEGACY>() * 4);
 #pragma unroll
             for (int i = 0; i < 8; i++) lds_store(L.wa[i] + so, Aw[i]);
         }
@@ -532,16 +588,16 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
                 uint32_t C[9];
 #pragma unroll
                 for (int k = 0; k < 9; k++) C[k] = pj[k * kCS2];
-                float v[10];
-                mismatch_slot8(C, Was, Wbs, IvP[s], IxP[s], IyP[s], Ix4[s], Iy4[s], vround, v);
-                const uint32_t so = (uint32_t)(s * kStageDw * 4);
+                float v[16];
+                mismatch_slot8<LEGACY>(C, Was, Wbs, IvP[s], IxP[s], IyP[s], Ix4[s], Iy4[s], vround, v);
+                const uint32_t so = (uint32_t)(s * stage_dw<LEGACY>() * 4);
 #pragma unroll
-                for (int t = 0; t < 10; t++) lds_store(L.wb[t] + so, __float_as_uint(v[t]));
+                for (int t = 0; t < (LEGACY ? 16 : 10); t++) lds_store(L.wb[t] + so, __float_as_uint(v[t]));
             }
             wave_lds_fence();
             float b1f, b2f;
             {
-                const float r = chain_b(L);
+                const float r = chain_b<LEGACY>(L);
                 // bbuf = qb0 + qb1; ib1 += bbuf[0] + bbuf[2]; ib2 += bbuf[1] + bbuf[3]  (the tails are already in ib), on the
                 // DPP network inside the row.  Positions: 0 tail x | 1..4 chains 0, 4, 2, 6 | 8 tail y | 9..12 chains 1, 5, 3, 7:
                 // position 1 + 2 = bb0, 3 + 4 = bb2 (9.. : bb1, bb3), then their sum, then the tail at the head of the half row
@@ -581,9 +637,10 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
 
 // Grid: ONE wave per workgroup, a.gx WAVES per batch item walking the item's points in strides of a.gx * 4 slots;
 // the same XCD-aware item mapping as lk_kernel (consecutive workgroup ids go round the 8 XCDs).
+template <bool LEGACY>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lk_sse2_kernel(LkArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsDwSse2];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[LEGACY ? kLdsDwLegacy : kLdsDwSse2];
     const int n_aware = (a.batch & ~7) * a.gx;
     int b, wv;
     if ((int)blockIdx.x < n_aware) {
@@ -597,7 +654,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int slot = lane >> 4;
     int n = a.n_pts ? a.n_pts[b] : a.n_fixed;
     n = min(n, a.cap);
-    const Sse2Lane L = make_lane(lane, (uint32_t)(size_t)(lds_cu32 *)lds, a.accum == 2);
+    const Sse2Lane L = make_lane<LEGACY>(lane, (uint32_t)(size_t)(lds_cu32 *)lds, a.accum == 2);
     int spw = kSlots;
     if (a.spread) spw = min(kSlots, max(1, (n + a.gx - 1) / a.gx));
     for (int first = wv * spw; first < n; first += a.gx * spw) {
@@ -615,7 +672,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const uint8_t *sI = a.prev[c] + (int64_t)b * a.slot_stride;
             const uint8_t *sJ = a.next[c] + (int64_t)b * a.slot_stride;
             int st;
-            lk_call4_sse2(a.g, sI, sJ, cur, nxt, st, live, lds, lane, L);
+            lk_call4_sse2<LEGACY>(a.g, sI, sJ, cur, nxt, st, live, lds, lane, L);
             if (writer && live) {
                 a.pts_out[c][po] = nxt;
                 a.status[c][po] = (uint8_t)st;
@@ -649,7 +706,15 @@ void launch_lk_sse2(const LkArgs &a0, int batch, int max_pts, hipStream_t st)
         a.spread = 1;
     }
     a.batch = batch;
-    hipLaunchKernelGGL(lk_sse2_kernel, dim3(batch * a.gx), dim3(64), 0, st, a);
+    if (a.accum == 3) {
+        if (batch < 4) {                          // six legacy workgroups per CU
+            const int room = 1536 / batch;
+            a.gx = max_pts < room ? max_pts : room;
+        }
+        hipLaunchKernelGGL(lk_sse2_kernel<true>, dim3(batch * a.gx), dim3(64), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(lk_sse2_kernel<false>, dim3(batch * a.gx), dim3(64), 0, st, a);
+    }
 }
 
 }  // namespace svo

@@ -180,8 +180,9 @@ extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
     if (cfg->width < 32 || cfg->height < 32 || cfg->max_keypoints < 64 || cfg->max_batch < 1 ||
         cfg->num_slots < 4 || cfg->width > 16384 || cfg->height > 16384)
         return SVO_ERR_ARG;
-    if (cfg->lk_accum != SVO_LK_ACCUM_EXACT && cfg->lk_accum != SVO_LK_ACCUM_SSE2 && cfg->lk_accum != SVO_LK_ACCUM_SIMD128) {
-        fprintf(stderr, "svo_create: lk_accum = %d is none of SVO_LK_ACCUM_EXACT / _SSE2 / _SIMD128\n", cfg->lk_accum);
+    if (cfg->lk_accum != SVO_LK_ACCUM_EXACT && cfg->lk_accum != SVO_LK_ACCUM_SSE2 && cfg->lk_accum != SVO_LK_ACCUM_SIMD128 &&
+        cfg->lk_accum != SVO_LK_ACCUM_SSE2_LEGACY) {
+        fprintf(stderr, "svo_create: lk_accum = %d is none of SVO_LK_ACCUM_EXACT / _SSE2 / _SIMD128 / _SSE2_LEGACY\n", cfg->lk_accum);
         return SVO_ERR_ARG;
     }
     if (cfg->fast_keep_strongest < 0) return SVO_ERR_ARG;

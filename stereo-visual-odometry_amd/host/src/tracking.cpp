@@ -18,14 +18,15 @@ Tracking::Tracking(System *system, Parameter::Ptr parameter, Sensors::Ptr sensor
     // the other and then run side by side
     max_keypoints_key_ = Config::Has("max_keypoints") ? Config::Get<int>("max_keypoints") : 0;
     // order of the float sums inside cv::calcOpticalFlowPyrLK (include/svo_abi.h): `exact` is independent of the
-    // build; `sse2` / `simd128` add them in float in the lane orders of upstream's x86 SIMD code as restated in oracle/lk.c
-    // (modes 2 / 4; recalled, not validated against an OpenCV binary) at about 1.9 x the LK kernel time
+    // build; `sse2` / `simd128` / `sse2_legacy` add them in float in the lane orders of upstream's x86 SIMD code as restated in
+    // oracle/lk.c (modes 2 / 4 / 3; recalled, not validated against an OpenCV binary) at about 1.9-2.2 x the LK kernel time
     fast_keep_strongest_ = Config::Has("fast_keep_strongest") ? Config::Get<int>("fast_keep_strongest") : 0;
     if (Config::Has("lk_accum")) {
         const std::string v = Config::Get<std::string>("lk_accum");
         if (v == "sse2") lk_accum_ = SVO_LK_ACCUM_SSE2;
         else if (v == "simd128") lk_accum_ = SVO_LK_ACCUM_SIMD128;
-        else if (v != "exact") LZB_LOG("WARNING", "lk_accum: '%s' is none of 'exact', 'sse2', 'simd128'; using 'exact'", v.c_str());
+        else if (v == "sse2_legacy") lk_accum_ = SVO_LK_ACCUM_SSE2_LEGACY;
+        else if (v != "exact") LZB_LOG("WARNING", "lk_accum: '%s' is none of 'exact', 'sse2', 'simd128', 'sse2_legacy'; using 'exact'", v.c_str());
     }
 }
 

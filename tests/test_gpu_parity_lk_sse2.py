@@ -230,3 +230,36 @@ def test_lk_simd128_24_pairs_batched_and_online(pkg, oracle, tc, synth):
     assert all(r["ok"] for r, _, _, _ in ref)
     _check_batch(pkg, tc, seq, frames, ref, lk_accum=pkg.LK_ACCUM_SIMD128)
     _check_online(pkg, seq, frames[:9], ref[:8], lk_accum=pkg.LK_ACCUM_SIMD128)
+
+
+# ---- SVO_LK_ACCUM_SSE2_LEGACY (ABI v8): the older hand-written CV_SSE2 block restated whole = oracle mode 3 ---------------------
+@pytest.mark.parametrize("w,h,n,seed", [(416, 128, 1, 3), (416, 128, 5, 4), (333, 201, 700, 5), (1241, 376, 3000, 6)])
+def test_lk_track_sse2_legacy_points_and_status(pkg, oracle, w, h, n, seed):
+    """One float add per pixel product (pixels 0, 1, then 4, 5 of a group of eight into qb0; 2, 3, then 6, 7 into qb1) instead of
+    the madd pair sums of the other two orders: bit-identical to oracle mode 3."""
+    prev, nxt = _shifted_pair(h, w, seed)
+    rng = np.random.default_rng(seed)
+    pts = np.stack([rng.uniform(-3, w + 3, n), rng.uniform(-3, h + 3, n)], 1).astype(np.float32)
+    pts[: n // 4] = np.round(pts[: n // 4])
+    c = pkg.Context(w, h, device=0, max_keypoints=max(n, 64), lk_accum=pkg.LK_ACCUM_SSE2_LEGACY)
+    c.build_pyramid(0, prev)
+    c.build_pyramid(1, nxt)
+    got, st = c.lk_track(0, 1, pts)
+    c.close()
+    with accum_oracle(oracle, oracle.LK_ACCUM_LEGACY_SSE2):
+        want, wst = oracle.lk_track(prev, nxt, pts)
+    assert st.tobytes() == wst.tobytes() and got.tobytes() == want.tobytes()
+    # (against the madd order the bits differ only where a b sum passes 2^24 between a pair's two products: 6 of 2 478 points on
+    #  an S0 frame pair, none on this shifted pair -- the 24-pair sequence below is where the two orders part)
+
+
+def test_lk_sse2_legacy_24_pairs_batched_and_online(pkg, oracle, tc, synth):
+    seq, frames = _render(synth, tc, 1241, 376, 25, 20200710)
+    with accum_oracle(oracle, oracle.LK_ACCUM_LEGACY_SSE2):
+        ref = _oracle_lk_sequence(oracle, seq, frames)
+    with sse2_oracle(oracle):
+        ref2 = _oracle_lk_sequence(oracle, seq, frames)
+    assert all(r["ok"] for r, _, _, _ in ref)
+    assert any(a[0]["tracks"][3].tobytes() != b[0]["tracks"][3].tobytes() for a, b in zip(ref, ref2))   # the two orders do part on 24 pairs
+    _check_batch(pkg, tc, seq, frames, ref, lk_accum=pkg.LK_ACCUM_SSE2_LEGACY)
+    _check_online(pkg, seq, frames[:9], ref[:8], lk_accum=pkg.LK_ACCUM_SSE2_LEGACY)

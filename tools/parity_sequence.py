@@ -7,8 +7,8 @@ Compared at EVERY pair: ok, fail_stage, n_prev_kps, n_cur_kps, n_tracked, n_inli
 matched tracks and the RANSAC inlier mask (bytes), the relative motion (1e-8; the pairs beyond 1e-9 are counted as
 information: the LM refit solves its normal equations by Cholesky on the GPU and by SVD in the oracle, DESIGN.md section 2,
 and ORB mode's smaller inlier sets take that difference to 2e-9 on one pair in a hundred) and the chained pose (1e-4
-required by north_star; the observed maximum is reported).  Modes: exact (lk_kernel vs oracle mode 0), sse2 / simd128 (lk_sse2_kernel vs
-oracle mode 2 / 4), orb (ORB extractor + matcher).
+required by north_star; the observed maximum is reported).  Modes: exact (lk_kernel vs oracle mode 0), sse2 / simd128 / sse2_legacy (lk_sse2_kernel vs
+oracle mode 2 / 4 / 3), orb (ORB extractor + matcher).
 
 usage (GPU box): python3 tools/parity_sequence.py --pairs 4540 --modes exact,sse2 --orb-pairs 512 --out gpurun_out/parity.json
 The frames are rendered chunk by chunk (a 4541-frame sequence is 4 GB of images)."""
@@ -50,12 +50,14 @@ def run(pkg, O, torch, synth, n_pairs, mode="exact", batch=256, seed=20200710, w
         kw["lk_accum"] = pkg.LK_ACCUM_SSE2
     if mode == "simd128":
         kw["lk_accum"] = pkg.LK_ACCUM_SIMD128
+    if mode == "sse2_legacy":
+        kw["lk_accum"] = pkg.LK_ACCUM_SSE2_LEGACY
     if mode == "orb":
         kw.update(track_mode=pkg.MODE_ORB, min_move2=0.05 ** 2, max_move2=10.0 ** 2)
     B = min(batch, n_pairs)
     ctx = pkg.Context(width, height, device=0, P1=P1, P2=P2, max_batch=B, **kw)
     prm = O.make_params(P1, P2, **({"min_t2": 0.05 ** 2, "max_t2": 10.0 ** 2} if mode == "orb" else {}))
-    old = O.set_lk_accum({"sse2": O.LK_ACCUM_FLOAT_SSE, "simd128": O.LK_ACCUM_SIMD128}.get(mode, O.LK_ACCUM_EXACT))
+    old = O.set_lk_accum({"sse2": O.LK_ACCUM_FLOAT_SSE, "simd128": O.LK_ACCUM_SIMD128, "sse2_legacy": O.LK_ACCUM_LEGACY_SSE2}.get(mode, O.LK_ACCUM_EXACT))
     fields = ("ok", "fail_stage", "n_prev_kps", "n_cur_kps", "n_tracked", "n_inliers")
     mism = {k: 0 for k in fields + ("ransac_iters", "lm_iters", "tracks", "inlier_mask", "T_rel_inv_gt_1e-8", "pose_gt_1e-4")}
     info = {"T_rel_inv_gt_1e-9": 0}
