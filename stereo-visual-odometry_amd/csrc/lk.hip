@@ -553,7 +553,7 @@ extern "C" int svo_debug_lk_stamps(unsigned long long out[2], int reset)
 void launch_lk(const LkArgs &a0, int batch, int max_pts, hipStream_t st)
 {
     if (max_pts <= 0 || batch <= 0) return;
-    if (a0.accum != 0) { launch_lk_sse2(a0, batch, max_pts, st); return; }      // SVO_LK_ACCUM_SSE2 / _SIMD128 / _SSE2_LEGACY: the float-order kernel
+    if (a0.accum != 0) { launch_lk_sse2(a0, batch, max_pts, st); return; }      // SVO_LK_ACCUM_SSE2 / _SIMD128: the float-order kernel
     // up to 192 workgroups per item (3072 points per pass: a KITTI frame's ~2.5 k corners in one pass,
     // a few workgroups leave at once; denser frames loop), never more than capacity / 16
     const int chunks = (max_pts + 4 * kSlots - 1) / (4 * kSlots);
