@@ -1779,24 +1779,19 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
     const int rx0 = (ix - 15) & ~3, roff = (ix - 15) - rx0;
     // a lane keeps ONE dword column of the window and walks down the rows (27 of the 32 lanes: 9 columns x 3 rows per
     // step): the address and the LDS index advance by a constant, no division or multiplication per load
-#pragma nounroll
-    for (int pass = 0; pass < (mixed ? 2 : 1); pass++) {
-        const bool from0 = mixed ? pass == 1 : m0 != 0ull;
-        const uint8_t *img_base = from0 ? lvl0 : slot_base;
-        const bool mine = sl < 27 && (!mixed || (l == 0) == from0);
-        const int c = sl % 9, rr = sl / 9;
-        uint32_t off = (uint32_t)lv.x + (uint32_t)((iy - 15 + rr) * pitch + rx0 + 4 * c);
-        int li = rr * 9 + c;
-        uint32_t v[11];                                              // (all the loads in flight before the first LDS store)
+    // (straight-line code, so that these loads and the blurred window's below are all in flight together; the straddling wave's
+    // other half is fetched by the rare branch behind the LDS stores)
+    const bool from0 = m0 != 0ull;                                    // a mixed wave serves its level-0 half first
+    const uint8_t *img_base = from0 ? lvl0 : slot_base;
+    const bool mine = sl < 27 && (!mixed || l == 0);
+    const int rc = sl % 9, rrw = sl / 9;
+    uint32_t vraw[11];                                                // (all the loads in flight before the first LDS store)
+    {
+        uint32_t off = (uint32_t)lv.x + (uint32_t)((iy - 15 + rrw) * pitch + rx0 + 4 * rc);
 #pragma unroll
         for (int t = 0; t < 11; t++) {
-            v[t] = mine && rr + 3 * t < 31 ? *(const uint32_t *)(img_base + off) : 0u;
+            vraw[t] = mine && rrw + 3 * t < 31 ? *(const uint32_t *)(img_base + off) : 0u;
             off += 3u * (uint32_t)pitch;
-        }
-#pragma unroll
-        for (int t = 0; t < 11; t++) {
-            if (mine && rr + 3 * t < 31) raw[li] = v[t];
-            li += 27;
         }
     }
     const uint8_t *blur_base = a.blur + (int64_t)b * a.blur_img_stride;          // 4-byte aligned rows, bp apart
@@ -1815,6 +1810,25 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDescArgs a)
         for (int t = 0; t < 20; t++) {
             if (sl < 22 && rr + 2 * t < 39) blr[li] = v[t];
             li += 22;
+        }
+    }
+    {
+        int li = rrw * 9 + rc;
+#pragma unroll
+        for (int t = 0; t < 11; t++) {
+            if (mine && rrw + 3 * t < 31) raw[li] = vraw[t];
+            li += 27;
+        }
+    }
+    if (__builtin_expect(mixed, 0)) {                                 // the half-wave whose keypoint is NOT at level 0: from the slot
+        const bool mine2 = sl < 27 && l != 0;
+        uint32_t off = (uint32_t)lv.x + (uint32_t)((iy - 15 + rrw) * pitch + rx0 + 4 * rc);
+        int li = rrw * 9 + rc;
+#pragma nounroll
+        for (int t = 0; t < 11; t++) {
+            if (mine2 && rrw + 3 * t < 31) raw[li] = *(const uint32_t *)(slot_base + off);
+            off += 3u * (uint32_t)pitch;
+            li += 27;
         }
     }
     wave_lds_fence();
