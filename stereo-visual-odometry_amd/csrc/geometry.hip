@@ -440,7 +440,14 @@ __device__ __forceinline__ void pnp_hyp_front_body(const PnpArgs &a, double *pnp
             for (int k = 0; k < 12; k++) hand[(kEpnpHandV + i * 12 + k) * 64] = big[((11 - i) * 12 + k) * 64];
     }
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pnp_hyp_front_kernel(PnpArgs a)
+// Two builds.  WPE = 2: 256 registers a lane (82 spilled, all in the straight-line front) -- the lone online pair, whose eight
+// blocks never share a CU with anything, and LK mode.  WPE = 3: 168 registers (338 spilled): the ORB-mode batch build.  Two blocks still share a CU
+// (78 KB of LDS each), but they now hold 336 of a SIMD's 512 registers instead of all of them, so the next batch's extraction
+// kernels run BESIDE the hypothesis blocks instead of waiting for block turnover: the pose stage alone 1.63 -> 1.69 ms, the
+// overlapped ORB step 5.92 -> 5.81 ms (same box; 128 registers: 1.87 ms alone, the next matcher waits for it, 6.05 ms).
+// (amdgpu_num_vgpr is not honoured for this kernel: the register budget comes in the steps waves_per_eu allows.)
+template <int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void pnp_hyp_front_kernel(PnpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double pnp_smem[];
     pnp_hyp_front_body(a, pnp_smem);
@@ -1006,7 +1013,9 @@ const uint8_t *pnp_inlier_mask(const svo_ctx *ctx) { return (const uint8_t *)ctx
 int geom_workspace_bytes(const svo_config &cfg, int n_items, size_t *bytes)
 {
     // called once per context at creation: the EPnP and refit kernels need more dynamic LDS than the default limit
-    if (hipFuncSetAttribute((const void *)pnp_hyp_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void *)pnp_hyp_front_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kPnpFrontLdsBytes) != hipSuccess ||
+        hipFuncSetAttribute((const void *)pnp_hyp_front_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPnpFrontLdsBytes) != hipSuccess)
         return SVO_ERR_HIP;
     if (hipFuncSetAttribute((const void *)pnp_hyp_back_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1059,7 +1068,9 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
         a.phase_base = base; a.phase_cap = cap; a.phase_index = phase;
         // one block per CU (94 KB of LDS, one wave per SIMD); beside the next batch's front end that leaves the
         // LDS-staged front-end kernels room on the CU (two 78 KB blocks locked them out: ORB mode, 1.7 ms per step)
-        hipLaunchKernelGGL(pnp_hyp_front_kernel, dim3(blocks + 1, n_items), dim3(256), kPnpFrontLdsBytes, st, a);   // + the drawer
+        // (ORB-mode batches only: beside lk_kernel the lighter build costs the LK launch 0.1 ms of shared vector-unit time)
+        if (n_items >= 16 && ctx->cfg.track_mode == SVO_MODE_ORB) hipLaunchKernelGGL(pnp_hyp_front_kernel<3>, dim3(blocks + 1, n_items), dim3(256), kPnpFrontLdsBytes, st, a);   // + the drawer
+        else hipLaunchKernelGGL(pnp_hyp_front_kernel<2>, dim3(blocks + 1, n_items), dim3(256), kPnpFrontLdsBytes, st, a);
         hipLaunchKernelGGL(pnp_hyp_back_kernel, dim3(blocks, n_items), dim3(256), kPnpLdsBytes, st, a);
         hipLaunchKernelGGL(pnp_score_kernel, dim3(blocks, n_items, zchunks), dim3(256), 0, st, a);
         hipLaunchKernelGGL(pnp_select_kernel, dim3(n_items), dim3(64), 0, st, a);
