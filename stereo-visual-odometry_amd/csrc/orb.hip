@@ -229,29 +229,23 @@ __global__ __launch_bounds__(256) void orb_resize_stream_kernel(OrbGeom g, uint8
         if (dx0 < dw) *(uint32_t *)(dst + (int64_t)dy * dpitch) = out;
     };
     int HA[4] = {0, 0, 0, 0}, HB[4] = {0, 0, 0, 0};
-    // Source rows are requested three ahead.  Four rows a turn: the row buffers rotate with static indices, the roles
-    // (previous, current) alternate between HA and HB without moves.
-    uint32_t d[4][3];
-    // (measured: requesting unconditionally -- so that the compiler's s_waitcnt can count the loads in flight instead of
-    // waiting for all of them -- is no faster, 0.55 against 0.52 ms per 514 images: eight waves per SIMD hide the round trip)
-    request(d[0], rs);
-    if (rs + 1 <= re) request(d[1], rs + 1);
-    if (rs + 2 <= re) request(d[2], rs + 2);
-#define SVO_RS_STEP(K, HP, HC)                                                                        \
-        if (r + K + 3 <= re) request(d[(K + 3) & 3], r + K + 3);                                      \
-        hblend(HC, d[K]);                                                                             \
-        while (dy < dy1 && ty.y == r + K) {                                                           \
-            if (__builtin_expect(ty.x == r + K, 0)) emit(HC, HC); else emit(HP, HC);                  \
+    // The next source row is requested before this one is blended; two rows a turn, so that the row buffers and the roles
+    // (previous, current: HA / HB) alternate without moves.  (Three rows in flight measured no faster -- eight waves per SIMD
+    // hide the round trip, 0.52 against 0.52-0.55 ms per 514 images -- and cost six registers: at 56 instead of 60 a third wave
+    // of this kernel fits beside two hypothesis blocks of the previous batch's pose stage.)
+    uint32_t dA[3], dB[3];
+    request(dA, rs);
+#define SVO_RS_STEP(DN, DC, RR, HP, HC)                                                               \
+        if ((RR) + 1 <= re) request(DN, (RR) + 1);                                                    \
+        hblend(HC, DC);                                                                               \
+        while (dy < dy1 && ty.y == (RR)) {                                                            \
+            if (__builtin_expect(ty.x == (RR), 0)) emit(HC, HC); else emit(HP, HC);                   \
             if (++dy < dy1) ty = yt[dy];                                                              \
         }
-    for (int r = rs; r <= re; r += 4) {
-        SVO_RS_STEP(0, HB, HA)
+    for (int r = rs; r <= re; r += 2) {
+        SVO_RS_STEP(dB, dA, r, HB, HA)
         if (r + 1 > re) break;
-        SVO_RS_STEP(1, HA, HB)
-        if (r + 2 > re) break;
-        SVO_RS_STEP(2, HB, HA)
-        if (r + 3 > re) break;
-        SVO_RS_STEP(3, HA, HB)
+        SVO_RS_STEP(dA, dB, r + 1, HA, HB)
     }
 #undef SVO_RS_STEP
 }
