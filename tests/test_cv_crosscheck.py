@@ -130,6 +130,28 @@ def test_solve_pnp_ransac_names_its_refit(oracle, compat):
     assert min(report.values()) < 1e-9, report
 
 
+def test_solve_pnp_ransac_with_four_points_is_p3p(oracle):
+    """npoints == 4: cv::solvePnPRansac switches its minimal solver to P3P (one model from the four points, all of them inliers, the
+    LM refit on them) -- reachable with num_features_tracking: 4, /root/reference/src/tracking.cpp:274, 485.  oracle/p3p.c restates
+    p3p.cpp + polynom_solver.cpp."""
+    x1, x2 = G["tracks"][0], G["tracks"][1]
+    X = oracle.triangulate(G["P1"], G["P2"], x1, x2)
+    K = G["P1"].reshape(3, 4)[:, :3].copy()
+    checked = 0
+    for start in range(0, len(X) - 4, max(1, (len(X) - 4) // 12)):
+        Xs, xs = X[start:start + 4].copy(), G["tracks"][3][start:start + 4].copy()
+        rvec, tvec = np.zeros((3, 1)), np.zeros((3, 1))
+        ok, rvec, tvec, inl = cv2.solvePnPRansac(Xs.reshape(-1, 1, 3), xs.reshape(-1, 1, 2), K, None, rvec, tvec, True,
+                                                 500, 0.5, 0.99, None, cv2.SOLVEPNP_ITERATIVE)
+        r = oracle.pnp_ransac(Xs, xs, K)
+        assert bool(ok) == bool(r["ok"]), start
+        if ok:
+            assert r["n_inliers"] == (0 if inl is None else len(inl))
+            assert np.abs(r["rvec"] - rvec.reshape(3)).max() < 1e-8 and np.abs(r["tvec"] - tvec.reshape(3)).max() < 1e-8, start
+            checked += 1
+    assert checked > 0
+
+
 def test_orb_callees(oracle):
     img = G["L0"]
     h, w = img.shape
