@@ -320,7 +320,7 @@ def self_check(pkg, O, ctx, recs, L, R, width, f0, P1, P2, mode="lk", sse2=False
             if not e <= 1e-9:
                 bad.append(f"pair {p}: T_rel_inv off by {e:.2e}")
     return {"pairs": len(pairs), "pairs_of_step": len(recs), "ok": not bad, "compared": "fail_stage, counts, ransac_iters, lm_iters, tracks + inlier mask "
-            "(bytes), T_rel_inv (1e-9) vs oracle/ on the same frames" + (", oracle in SSE2 accumulation order" if sse2 else ""),
+            "(bytes), T_rel_inv (1e-9) vs oracle/ on the same frames" + ("" if not sse2 else ", oracle in SSE2 accumulation order" if sse2 is True else ", oracle in accumulation mode %d" % int(sse2)),
             "which_pairs_of_last_step": ("all" if len(pairs) == len(recs) else pairs), **({"mismatches": bad[:12]} if bad else {})}
 
 
@@ -929,6 +929,15 @@ def main():
                         "lk_ms_per_step": round(st_ms.get("lk", 0.0), 4),
                         "lk_ms_per_step_exact": round(stage_ms.get("lk", 0.0), 4) if stage_ms.get("lk") else None},
                        dict(mode="lk", sse2=True, n_check=args.self_check_pairs))
+                # (1b) the other two restated x86 orders, briefly (which one an OpenCV 3 build runs depends on
+                # its version): the same workload, 64 pairs of the last step checked against their oracle modes (4 / 3)
+                for oname, oacc, omode in (("simd128", pkg.LK_ACCUM_SIMD128, 4), ("sse2_legacy", pkg.LK_ACCUM_SSE2_LEGACY, 3)):
+                    lctx, el, st_ms, recs, f0 = run_leg(pkg, torch, dev, L, R, W, H, B, max(2, leg_steps // 2), 1,
+                                                        dict(P1=P1, P2=P2, lk_accum=oacc))
+                    finish("lk_accum_" + oname, lctx, el, st_ms, recs, f0, max(2, leg_steps // 2), B,
+                           {"definition": "the main workload with svo_config.lk_accum = " + oname + " (lk_sse2_kernel, bit-identical to oracle/lk.c mode %d)" % omode,
+                            "lk_ms_per_step": round(st_ms.get("lk", 0.0), 4)},
+                           dict(mode="lk", sse2=omode, n_check=min(64, args.self_check_pairs)))
             if args.mode == "lk":
                 # (2) BASELINE config #3: the ORB extractor + descriptor-match path on the same frames
                 lctx, el, st_ms, recs, f0 = run_leg(pkg, torch, dev, L, R, W, H, B, leg_steps, leg_warm,

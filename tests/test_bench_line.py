@@ -1,4 +1,4 @@
-"""bench.py's one-GPU line (-m gpu): the legs the driver's default run carries (lk_accum_sse2, orb = BASELINE config #3,
+"""bench.py's one-GPU line (-m gpu): the legs the driver's default run carries (lk_accum_sse2 / _simd128 / _sse2_legacy, orb = BASELINE config #3,
 hd = config #4 on exactly 2000 corners) and the oracle self-check, on a small batch; and the self-check's teeth: with the
 oracle deliberately run in the other accumulation order bench.py must exit with 3."""
 import json
@@ -26,7 +26,7 @@ def test_default_line_carries_the_legs_and_a_green_self_check():
     out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0
     assert out["self_check"]["ok"] and out["self_check"]["pairs"] == 12 and out["self_check"]["which_pairs_of_last_step"] == "all"
-    for leg, stage in (("lk_accum_sse2", "lk"), ("orb", "orb_cellfast"), ("hd", "lk")):
+    for leg, stage in (("lk_accum_sse2", "lk"), ("lk_accum_simd128", "lk"), ("lk_accum_sse2_legacy", "lk"), ("orb", "orb_cellfast"), ("hd", "lk")):
         d = out[leg]
         assert d["value"] > 0 and d["self_check"]["ok"] and d["stage_ms_per_step"][stage] > 0, leg
         assert d["self_check"]["pairs"] == d["self_check"]["pairs_of_step"], leg          # small batches are checked whole
