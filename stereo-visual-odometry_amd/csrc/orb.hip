@@ -8,8 +8,8 @@
 // off), so keypoints, angles, descriptors and matches are bit-identical to oracle/orb.c.
 //
 // Launch sequence for a batch of images (every kernel covers all images of the batch):
-//   copy0 -> resize(l) x7 -> blur (all levels) -> cellfast (all levels) -> gather -> distribute
-//   -> orient+describe -> assemble.  (No frame is written around the ORB levels: the blur, its only
+//   [copy0 -- only where level 0 cannot be read in place from the input frames] -> resize(l) x7 (row-streaming) -> blur (all
+//   levels) -> cellfast (all levels) -> gather -> distribute -> orient+describe -> assemble.  (No frame is written around the ORB levels: the blur, its only
 //   reader, reflects at the edges itself.)
 // The quadtree (std::list / sort / pointer code in the reference) is restated as an array-based
 // doubly linked list in LDS walked by ONE WAVE per (image, level): the walk is serial by nature (each
