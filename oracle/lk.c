@@ -148,6 +148,21 @@ static int16_t *scharr_deriv(const uint8_t *lvl, int w, int h, int pad, int pitc
 static int32_t *g_iter_log = NULL;
 static _Thread_local int g_iter_pt = 0;
 void orc_lk_set_iter_log(int32_t *log) { g_iter_log = log; }
+/* Exactness log (tools only: tools/model/lk_guard_model.py prices lk_sse2_kernel's integer fast path with it).  For every
+ * (point, level) eight 32-bit masks over the iterations j (bit j), at log[(point * ORC_LK_MAX_LEVELS + level) * 8 + k]:
+ *   k = 0  every one of the ten b chains of the madd-pair orders (modes 2, 4: eight lane chains of 42 pair sums, two tails of
+ *          105 products) has max(sum of its positive terms, sum of |negative terms|) < 2^24 -- then every partial sum in ANY
+ *          order is an integer below 2^24 and every float add of the chain is exact
+ *   k = 1  the same for the legacy order's chains (mode 3: 84 single products a lane chain)
+ *   k = 2  the float b of the current accumulation mode equals the exact integer b bit for bit
+ *   k = 3  the iteration ran
+ *   k = 4  as k = 0 with the lane chains merged in the pairs the final adds join first: (k0, k2), (k1, k3), tail -- six sums
+ *   k = 5  ... all four lane chains of a coordinate merged: lanes, tail -- four sums
+ *   k = 6  ... the whole window merged: two sums (then b is lk_kernel's exact b)
+ *   k = 7  as k = 0 with the positive sums taken from the terms' high halves only (t >> 16, one unit of slack a term: what a
+ *          packed 16-bit reduction on the GPU can afford) */
+static uint32_t *g_guard_log = NULL;
+void orc_lk_set_guard_log(uint32_t *log) { g_guard_log = log; }
 
 /* 0 exact int64 (CANONICAL); float accumulation: 1 raster order (the scalar loop), 2 the round-4 restatement (A: four
  * lanes over x = 0..19, b: madd pairs over x = 0..15 -- the parity target of lk_sse2_kernel), and the two upstream SIMD
@@ -270,6 +285,9 @@ static void lk_point_level(const uint8_t *I, int pitchI, const int16_t *dI, int 
         float fb1 = 0.f, fb2 = 0.f;
         float qb0[4] = {0.f, 0.f, 0.f, 0.f}, qb1[4] = {0.f, 0.f, 0.f, 0.f};
         const int simdB = accum >= 2 ? (win / 8) * 8 : 0;
+        /* exactness log: [chain][0 positive | 1 negative] sums; chains 0..7 = 2 k + xy (pixels k, k + 4 of a group), 8 / 9 the tails */
+        int64_t gpair[10][2], gprod[10][2], gq[10][2], gtl[21][2][2];
+        memset(gpair, 0, sizeof gpair); memset(gprod, 0, sizeof gprod); memset(gq, 0, sizeof gq); memset(gtl, 0, sizeof gtl);
         for (y = 0; y < win; y++) {
             const uint8_t *Jp = J + (ptrdiff_t)(y + iny) * pitchJ + inx;
             const int16_t *Ip = Ibuf + y * win, *dIp = dIbuf + y * win * 2;
@@ -279,6 +297,22 @@ static void lk_point_level(const uint8_t *I, int pitchI, const int16_t *dI, int 
                                    Jp[x + pitchJ + 1] * iw11, W_BITS - 5) - Ip[x];
                 ib1 += (int64_t)(diff * dIp[2 * x]);
                 ib2 += (int64_t)(diff * dIp[2 * x + 1]);
+                if (g_guard_log) {
+                    const int gb = (win / 8) * 8, xy_n = 2;
+                    int xy;
+                    for (xy = 0; xy < xy_n; xy++) {
+                        const int64_t p = (int64_t)diff * dIp[2 * x + xy];
+                        const int c = x >= gb ? 8 + xy : 2 * (x & 3) + xy;
+                        gprod[c][p < 0] += p < 0 ? -p : p;
+                        if (x >= gb) { gpair[c][p < 0] += p < 0 ? -p : p; gtl[y][xy][p < 0] += p < 0 ? -p : p; }
+                        else if ((x & 7) >= 4) {         /* the pair (k, k + 4) is complete */
+                            const int64_t q = (int64_t)(DESCALE(Jp[x - 4] * iw00 + Jp[x - 3] * iw01 + Jp[x - 4 + pitchJ] * iw10 +
+                                                                Jp[x - 3 + pitchJ] * iw11, W_BITS - 5) - Ip[x - 4]) * dIp[2 * (x - 4) + xy] + p;
+                            gpair[c][q < 0] += q < 0 ? -q : q;
+                            gq[c][q < 0] += ((q < 0 ? -q : q) >> 16) + 1;
+                        }
+                    }
+                }
                 if (accum && x >= simdB) {                 /* ib1 += (itemtype)(diff*dIptr[0]) */
                     fb1 += (float)(diff * dIp[2 * x]);
                     fb2 += (float)(diff * dIp[2 * x + 1]);
@@ -317,6 +351,36 @@ static void lk_point_level(const uint8_t *I, int pitchI, const int16_t *dI, int 
             b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE;
         } else {
             b1 = (float)ib1 * FLT_SCALE; b2 = (float)ib2 * FLT_SCALE;
+        }
+        if (g_guard_log) {
+            uint32_t *gl = g_guard_log + ((size_t)g_iter_pt * ORC_LK_MAX_LEVELS + level) * 8;
+            int c, okp = 1, okl = 1, ok6 = 1, ok4 = 1, ok2 = 1, okq = 1, xy, sg;
+            const int64_t lim = 1 << 24;
+            for (xy = 0; xy < 2; xy++)
+                for (sg = 0; sg < 2; sg++) {
+                    const int64_t k0 = gpair[0 + xy][sg], k1 = gpair[2 + xy][sg], k2 = gpair[4 + xy][sg], k3 = gpair[6 + xy][sg], tl = gpair[8 + xy][sg];
+                    if (k0 + k2 >= lim || k1 + k3 >= lim || tl >= lim) ok6 = 0;
+                    if (k0 + k1 + k2 + k3 >= lim || tl >= lim) ok4 = 0;
+                    if (k0 + k1 + k2 + k3 + tl >= lim) ok2 = 0;
+                    /* packed version: a lane chain's terms by their high halves; a tail lane (one row, five products) sums its
+                     * products exactly first */
+                    for (c = 0; c < 4; c++) if (gq[2 * c + xy][sg] >= 256) okq = 0;
+                    { int64_t q = 0; int r; for (r = 0; r < win; r++) q += (gtl[r][xy][sg] >> 16) + 1; if (q >= 256) okq = 0; }
+                }
+            for (c = 0; c < 10; c++) {
+                if (gpair[c][0] >= (1 << 24) || gpair[c][1] >= (1 << 24)) okp = 0;
+                if (gprod[c][0] >= (1 << 24) || gprod[c][1] >= (1 << 24)) okl = 0;
+            }
+            if (j < 32) {
+                if (okp) gl[0] |= 1u << j;
+                if (okl) gl[1] |= 1u << j;
+                if (b1 == (float)ib1 * FLT_SCALE && b2 == (float)ib2 * FLT_SCALE) gl[2] |= 1u << j;
+                gl[3] |= 1u << j;
+                if (ok6) gl[4] |= 1u << j;
+                if (ok4) gl[5] |= 1u << j;
+                if (ok2) gl[6] |= 1u << j;
+                if (okq) gl[7] |= 1u << j;
+            }
         }
         float dlx = (A12 * b2 - A22 * b1) * D;
         float dly = (A12 * b1 - A11 * b2) * D;
@@ -374,6 +438,7 @@ int orc_lk_track(const orc_pyramid *prev, const orc_pyramid *next, const orc_pt2
             next_pts[i].x = 0.f; next_pts[i].y = 0.f;
             g_iter_pt = i;
             if (g_iter_log) for (lv = 0; lv < ORC_LK_MAX_LEVELS; lv++) g_iter_log[(size_t)i * ORC_LK_MAX_LEVELS + lv] = -1;
+            if (g_guard_log) memset(g_guard_log + (size_t)i * ORC_LK_MAX_LEVELS * 8, 0, sizeof(uint32_t) * ORC_LK_MAX_LEVELS * 8);
             for (lv = max_level; lv >= 0; lv--) {
                 int dp = (prev->w[lv] + 2 * pad) * 2;
                 lk_point_level(prev->data[lv] + (size_t)pad * prev->pitch[lv] + pad,

@@ -179,6 +179,7 @@ class Context:
 
     def set_stream(self, stream_handle):
         self._check(self.lib.svo_set_stream(self.h, C.c_void_p(stream_handle)))
+        self._stream_handle = int(stream_handle or 0)
 
     def wait_stream(self, stream_handle):
         """The context's stream waits ON THE DEVICE for everything queued on `stream_handle` so far (svo_wait_stream, ABI v7):
@@ -195,12 +196,19 @@ class Context:
         """Tensors torch has just produced (an output's zero fill is a kernel on TORCH's current stream; an input may still
         be being written there) are ordered before the library's kernels on the device -- no host synchronisation."""
         import torch
-        self.wait_stream(torch.cuda.current_stream(t.device).cuda_stream)
+        other = torch.cuda.current_stream(t.device).cuda_stream
+        if other and other == getattr(self, "_stream_handle", 0):
+            return False                   # the context was handed this very stream (set_stream): already in order
+        self.wait_stream(other)
+        return True
 
     def _order_out(self, t):
         """... and what the library wrote into them before whatever torch's current stream does next."""
         import torch
-        self.signal_stream(torch.cuda.current_stream(t.device).cuda_stream)
+        other = torch.cuda.current_stream(t.device).cuda_stream
+        if other and other == getattr(self, "_stream_handle", 0):
+            return                         # (and a signal would make the next front end wait for this batch's pose stage)
+        self.signal_stream(other)
 
     @property
     def num_levels(self):
@@ -386,6 +394,11 @@ class Context:
         pr, pitch_r, mem_r = self._img(right)
         assert pitch == pitch_r and mem == mem_r
         res = StepResult()
+        if mem == MEM_DEVICE:
+            # ORB mode reads level 0 IN PLACE until the end of the front end, and the frames may still be being written on
+            # torch's stream: order them before the library's kernels.  svo_add_frame returns with the record on the host,
+            # i.e. after everything that reads the frames, so nothing is left to order afterwards.
+            self._order_in(left)
         rc = self._check(self.lib.svo_add_frame(self.h, pl, pr, pitch, mem, C.byref(res)), allow_soft=True)
         return rc, np.frombuffer(bytes(res), dtype=STEP_DTYPE)[0].copy()
 
@@ -414,9 +427,17 @@ class Context:
         else:
             out = results
             rp, rmem = C.c_void_p(results.data_ptr()), MEM_DEVICE
+        # The frames (read in place until the end of the front end in ORB mode) and a device result buffer (its zero fill) may
+        # still be in flight on torch's current stream, and with device results the call returns while the kernels run:
+        # order torch's stream before the launch and the library's work -- side-stream pose stage included -- before
+        # whatever torch's stream does next (freeing or overwriting the frames, reading the records).  Two event operations
+        # each, no host synchronisation; skipped when the context runs ON torch's current stream (set_stream).
+        self._order_in(left_frames)
         self._check(self.lib.svo_track_batch(self.h, C.c_void_p(left_frames.data_ptr()),
                                              C.c_void_p(right_frames.data_ptr()), int(pitch), int(fstride),
                                              int(F), p0, rp, rmem))
+        if results is not None:
+            self._order_out(results)
         return out
 
     # ---- host-resident frame batches (svo_upload_frames / svo_track_uploaded) -----------------

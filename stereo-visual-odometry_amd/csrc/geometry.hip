@@ -891,8 +891,12 @@ __device__ __forceinline__ double quad_bcast_f64(double v)
     return __hiloint2double(hi, lo);
 }
 // The gates of every pair, then the chain, in ONE launch of one workgroup (the pose stage ends with it: two launches were
-// 10 us of a lone pair's 750): 256 threads finalize the pairs, the first wave multiplies the chain through.
-constexpr int kFinThreads = 256;
+// 10 us of a lone pair's 750).  ONE WAVE (round 6): the launch is queued on the side stream while the NEXT batch's LK grid
+// fills the chip; behind lk_sse2_kernel's single-wave workgroups (two a SIMD, all 160 KB of LDS) wave slots come free one at
+// a time, and a four-wave workgroup never found four at once until that grid drained -- the poses of a batch arrived up to a
+// whole LK launch (20 ms) late (profiles/r06_sse2_timeline_before.csv).  A lone wave takes the first slot that frees; the 256
+// pairs of a batch are four trips of finalize_pair instead of one.
+constexpr int kFinThreads = 64;
 __global__ __launch_bounds__(kFinThreads) void finalize_chain_kernel(FinalizeArgs a, Pose16 pose0, const double *seed_dev)
 {
     __shared__ double sT[64 * 16];
@@ -902,7 +906,7 @@ __global__ __launch_bounds__(kFinThreads) void finalize_chain_kernel(FinalizeArg
     svo_step_result *res = a.res;
     const int n_pairs = a.n_pairs;
     const int lane = threadIdx.x & 63, i = (lane >> 2) & 3, j = lane & 3;
-    const bool first = threadIdx.x < 64;
+    const bool first = true;
     double P = seed_dev ? seed_dev[i * 4 + j] : pose0.m[i * 4 + j];     // device seed: the previous batch's last pose
     for (int base = 0; base < n_pairs; base += 64) {
         // the records of 64 pairs are fetched together (one dependent global load per pair made the

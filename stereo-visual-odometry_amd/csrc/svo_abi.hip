@@ -270,7 +270,17 @@ extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
     PHASE("one device allocation + deferred initialisation");
     CK(hipHostMalloc(&ctx->h_stage, (size_t)ctx->stage_pitch * h * 2, hipHostMallocDefault));
     for (int k = 0; k < 2; k++) CK(hipEventCreateWithFlags(&ctx->ev_stage[k], hipEventDisableTiming));
-    CK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    {
+        // the pose stage of batch k runs beside the front end of batch k + 1 and ends batch k's latency: its queue goes first
+        // when the dispatcher has a free slot (SVO_SIDE_PRIORITY=0: a plain stream, for A/B runs)
+        int lo = 0, hi = 0;
+        const char *e = getenv("SVO_SIDE_PRIORITY");
+        if (e && e[0] == '0') CK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        else {
+            CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            CK(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi));
+        }
+    }
     CK(hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&ctx->ev_back, hipEventDisableTiming));
     if (B > 1) {
@@ -832,6 +842,8 @@ extern "C" int svo_upload_frames_at(svo_ctx *ctx, int buf, int first_slot, const
     SVO_ARG(buf == 0 || buf == 1, "buf must be 0 or 1");
     SVO_ARG(left_frames && right_frames, "null frames");
     SVO_ARG(first_slot >= 0 && n_frames >= 1 && first_slot + n_frames <= ctx->cfg.max_batch + 1, "first_slot + n_frames must be in [1, max_batch + 1]");
+    // slot 0 is either uploaded or carried on the device (SVO_CONTINUE_CARRY_FRAME): nothing else may be left out
+    SVO_ARG(first_slot <= 1, "first_slot must be 0 (a whole batch) or 1 (frame 0 is carried on the device)");
     SVO_ARG(pitch >= ctx->cfg.width && frame_stride >= (int64_t)pitch * ctx->cfg.height, "bad pitch / frame_stride");
     SVO_HIP(hipSetDevice(ctx->device));
     int rc = frame_buffers(ctx);
@@ -853,6 +865,7 @@ extern "C" int svo_upload_frames_at(svo_ctx *ctx, int buf, int first_slot, const
     }
     SVO_HIP(hipEventRecord(ctx->ev_up[buf], ctx->copy_stream));
     ctx->fb_frames[buf] = first_slot + n_frames;
+    ctx->fb_first[buf] = first_slot;
     return SVO_OK;
 }
 
@@ -871,6 +884,9 @@ extern "C" int svo_track_uploaded(svo_ctx *ctx, int buf, int n_frames, const dou
     if (!ctx) return SVO_ERR_ARG;
     SVO_ARG(buf == 0 || buf == 1, "buf must be 0 or 1");
     SVO_ARG(n_frames >= 2 && n_frames <= ctx->fb_frames[buf], "n_frames exceeds what was uploaded");
+    // an upload that started at slot 1 left slot 0 to a carried frame: only an async launch with SVO_CONTINUE_CARRY_FRAME reads it
+    SVO_ARG(ctx->fb_first[buf] == 0, "frame slot 0 of this buffer was not uploaded (svo_upload_frames_at first_slot = 1): "
+                                     "launch it with svo_track_uploaded_async and SVO_CONTINUE_CARRY_FRAME");
     SVO_HIP(hipSetDevice(ctx->device));
     const size_t fbytes = (size_t)ctx->stage_pitch * ctx->cfg.height, per_cam = fbytes * (size_t)(ctx->cfg.max_batch + 1);
     SVO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_up[buf], 0));
@@ -901,6 +917,9 @@ extern "C" int svo_track_uploaded_async(svo_ctx *ctx, int buf, int n_frames, con
     SVO_ARG((continue_chain & ~(SVO_CONTINUE_CHAIN | SVO_CONTINUE_CARRY_FRAME)) == 0, "unknown continue_chain bits");
     SVO_ARG(!(continue_chain & SVO_CONTINUE_CARRY_FRAME) || (continue_chain & SVO_CONTINUE_CHAIN),
             "SVO_CONTINUE_CARRY_FRAME without SVO_CONTINUE_CHAIN: the carried frame belongs to the chain being continued");
+    SVO_ARG(ctx->fb_first[buf] == 0 || (continue_chain & SVO_CONTINUE_CARRY_FRAME),
+            "frame slot 0 of this buffer was not uploaded (svo_upload_frames_at first_slot = 1): it holds stale pixels unless the "
+            "launch carries the previous batch's last frame (SVO_CONTINUE_CHAIN | SVO_CONTINUE_CARRY_FRAME)");
     if (continue_chain) {
         SVO_ARG(ctx->async_tail > 0, "continue_chain needs a previous async batch");
         const int pr = r ^ 1;

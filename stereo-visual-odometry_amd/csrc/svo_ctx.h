@@ -93,6 +93,7 @@ struct svo_ctx {
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_fb_free[2] = {nullptr, nullptr};
     bool fb_used[2] = {false, false};
     int fb_frames[2] = {0, 0};
+    int fb_first[2] = {0, 0};          // first frame slot of the last upload into the buffer (svo_upload_frames_at: 0 or 1)
     // svo_track_uploaded_async: two result buffers, collected in launch order
     svo_step_result *d_async[2] = {nullptr, nullptr};
     hipEvent_t ev_async[2] = {nullptr, nullptr};

@@ -64,6 +64,12 @@ public:
     void SetFrameRange(int first, int last) { frame_base_ = first; frame_last_ = last; }
     void SetRecordSink(std::vector<svo_step_result> *sink) { record_sink_ = sink; }
     void SetBatchSize(int b) { batch_size_ = b; }
+    void SetDecodeThreads(int t) { decode_threads_ = t; }
+    // additive: the output files the YAML names (pose_file / tracks_file keys; empty: none), and a switch for constructors
+    // that must not open them (a probe, or chunk Systems whose records go to a sink): set it, construct, clear it
+    const std::string &YamlPoseFile() const { return yaml_pose_file_; }
+    const std::string &YamlTracksFile() const { return yaml_tracks_file_; }
+    static void DeferYamlOutputs(bool on) { s_defer_yaml_outputs = on; }
     int BatchSize() const { return batch_size_; }
     bool Failed() const { return run_failed_; }
     void CloseOutputs();                                     // flushes and closes the pose / tracks files, waits for the device (fast exit)              // a stream / batch submission failed: the pose file is short
@@ -88,6 +94,8 @@ private:
     bool inited_ = false;
     std::string dataset_path_;
     FILE *pose_file_ = nullptr, *tracks_file_ = nullptr;
+    std::string yaml_pose_file_, yaml_tracks_file_;
+    static bool s_defer_yaml_outputs;
     // additive YAML keys batch_size / decode_threads, read once in the constructor (Config is process-wide:
     // another System may have loaded ITS file by the time Run() is called)
     int batch_size_ = 1, decode_threads_ = 0;

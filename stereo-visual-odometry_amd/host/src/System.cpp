@@ -247,6 +247,7 @@ bool ReadImageGrayInto(const std::string &path, uint8_t *dst, int pitch, int w, 
 }
 
 // ---- System ------------------------------------------------------------------------------------
+bool System::s_defer_yaml_outputs = false;
 System::System(std::string &config_path) : config_file_path_(config_path)
 {
     if (Config::SetParameterFile(config_file_path_) == false) {
@@ -257,10 +258,15 @@ System::System(std::string &config_path) : config_file_path_(config_path)
     sensors_ = Sensors::Ptr(new Sensors(init_parameter_));
     tracking_ = Tracking::Ptr(new Tracking(this, init_parameter_, sensors_));
     dataset_path_ = init_parameter_->dataset_path_;
-    if (Config::Has("pose_file")) SetPoseFile(Config::Get<std::string>("pose_file"));   // additive key
-    // additive keys: the headless stand-in for Tracking::displayTracking (src/tracking.cpp:345-382) and
-    // the reference's per-frame Feature carriers
-    if (Config::Has("tracks_file")) SetTracksFile(Config::Get<std::string>("tracks_file"));
+    // additive keys pose_file / tracks_file (the headless stand-in for Tracking::displayTracking, src/tracking.cpp:345-382).
+    // A System that only probes the sequence or hands its records to a sink (RunSplitPairs) must not open -- and truncate --
+    // the files the YAML names: it remembers the names instead.
+    if (Config::Has("pose_file")) yaml_pose_file_ = Config::Get<std::string>("pose_file");
+    if (Config::Has("tracks_file")) yaml_tracks_file_ = Config::Get<std::string>("tracks_file");
+    if (!s_defer_yaml_outputs) {
+        if (!yaml_pose_file_.empty()) SetPoseFile(yaml_pose_file_);
+        if (!yaml_tracks_file_.empty()) SetTracksFile(yaml_tracks_file_);
+    }
     if (Config::Has("fill_features") && Config::Get<int>("fill_features") != 0) tracking_->SetFillFeatures(true);
     batch_size_ = Config::Has("batch_size") ? Config::Get<int>("batch_size") : 1;
     decode_threads_ = Config::Has("decode_threads") ? Config::Get<int>("decode_threads") : 0;    // 0: the usable cores
@@ -577,7 +583,8 @@ void System::RunBatched(int B, int decode_threads)
         // records of chunk c-1 are waited for: their pose stage runs beside chunk c's kernels and may finish late
         // (its LDS-heavy blocks wait for room behind the LK launch), and a copy queued only after that wait would
         // start when chunk c is nearly done -- the GPU would idle for the length of the copy
-        const bool more = ok && nn >= 2 && upload(k ^ 1, nn);
+        bool more = ok && nn >= 2;
+        if (more && !upload(k ^ 1, nn)) { ok = false; more = false; }      // a failed upload is an error, not the end of the sequence
         auto t_now = std::chrono::steady_clock::now();
         if (ok && outstanding == 2) { ok = flush(std::chrono::duration<double>(t_now - t_prev).count(), B); outstanding--; }
         t_prev = t_now;
@@ -807,17 +814,25 @@ int RunSplitPairs(const std::string &yaml, const std::string &pose_file, int n_p
         return 1;
     }
     std::string path = yaml;
+    // The probe and the chunk Systems hand their records to a sink: none of them may open (= truncate) the pose_file /
+    // tracks_file the YAML names.  The poses of the whole sequence go to `pose_file`, or to the YAML's pose_file when the
+    // command line gives none.
+    System::DeferYamlOutputs(true);
     std::unique_ptr<System> probe(new System(path));
     const int n_frames = probe->CountFrames();
     const int n_pairs = n_frames - 1;
     const int default_batch = probe->BatchSize() > 1 ? probe->BatchSize() : 256;
+    const std::string out_path = !pose_file.empty() ? pose_file : probe->YamlPoseFile();
+    if (!probe->YamlTracksFile().empty())
+        LZB_LOG("WARNING", "tracks_file is not written by --split-pairs runs (the chunks keep relative motions only)%s", "");
     probe.reset();
-    if (n_pairs < 1) { LZB_LOG("ERROR", "%s: fewer than two stereo frames", yaml.c_str()); return 1; }
+    if (n_pairs < 1) { System::DeferYamlOutputs(false); LZB_LOG("ERROR", "%s: fewer than two stereo frames", yaml.c_str()); return 1; }
     if (n_parts < 1) n_parts = 1;
     if (n_parts > n_pairs) n_parts = n_pairs;
     FILE *out = nullptr;
-    if (!pose_file.empty() && !(out = fopen(pose_file.c_str(), "w"))) {
-        LZB_LOG("ERROR", "cannot open %s for writing", pose_file.c_str());
+    if (!out_path.empty() && !(out = fopen(out_path.c_str(), "w"))) {
+        System::DeferYamlOutputs(false);
+        LZB_LOG("ERROR", "cannot open %s for writing", out_path.c_str());
         return 1;
     }
     // contiguous chunks, sizes differing by at most one (multigpu.shard_pairs); chunk c = pairs first[c] .. first[c] + n[c] - 1
@@ -826,6 +841,11 @@ int RunSplitPairs(const std::string &yaml, const std::string &pose_file, int n_p
     std::vector<std::vector<svo_step_result>> recs((size_t)n_parts);
     std::vector<int> first((size_t)n_parts), cnt((size_t)n_parts);
     const int base = n_pairs / n_parts, extra = n_pairs % n_parts;
+    // Workers, not chunks, set the footprint: a chunk's System holds a context with its arena, four page-locked buffers and a
+    // decoder pool while it runs.  Two workers a device (one decodes while the other's kernels run) pull chunks from a queue;
+    // the usable cores are divided among them.  Chunk c runs on device c % n_devices whoever takes it.
+    const int n_workers = std::min(n_parts, 2 * n_devices);
+    const int dec_threads = std::max(1, usable_cores() / n_workers);
     for (int c = 0; c < n_parts; c++) {
         first[(size_t)c] = c * base + (c < extra ? c : extra);
         cnt[(size_t)c] = base + (c < extra ? 1 : 0);
@@ -835,24 +855,30 @@ int RunSplitPairs(const std::string &yaml, const std::string &pose_file, int n_p
         sys[(size_t)c]->SetRecordSink(&recs[(size_t)c]);
         sys[(size_t)c]->SetBatchSize(default_batch < cnt[(size_t)c] ? default_batch : (cnt[(size_t)c] > 1 ? cnt[(size_t)c] : 2));
         sys[(size_t)c]->SetDevice(c % n_devices);
+        sys[(size_t)c]->SetDecodeThreads(dec_threads);
     }
+    System::DeferYamlOutputs(false);
     std::vector<SequenceReport> rep((size_t)n_parts);
     std::vector<std::thread> pool;
-    for (int c = 0; c < n_parts; c++)
-        pool.emplace_back([&, c]() {
-            SequenceReport &r = rep[(size_t)c];
-            r.yaml = yaml; r.device = c % n_devices; r.worker = c;
-            const auto t0 = std::chrono::steady_clock::now();
-            sys[(size_t)c]->Run();
-            r.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            r.frames = (int)recs[(size_t)c].size() + 1;
-            r.ok = (int)recs[(size_t)c].size() == cnt[(size_t)c] && !sys[(size_t)c]->Failed();
+    std::atomic<int> next_chunk{0};
+    for (int wk = 0; wk < n_workers; wk++)
+        pool.emplace_back([&, wk]() {
+            for (int c = next_chunk.fetch_add(1); c < n_parts; c = next_chunk.fetch_add(1)) {
+                SequenceReport &r = rep[(size_t)c];
+                r.yaml = yaml; r.device = c % n_devices; r.worker = wk;
+                const auto t0 = std::chrono::steady_clock::now();
+                sys[(size_t)c]->Run();
+                r.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                r.frames = (int)recs[(size_t)c].size() + 1;
+                r.ok = (int)recs[(size_t)c].size() == cnt[(size_t)c] && !sys[(size_t)c]->Failed();
+                if (c > 0) sys[(size_t)c].reset();           // its records are in the sink; chunk 0's context does the prefix product
+            }
         });
     for (auto &th : pool) th.join();
     int failed = 0;
     for (int c = 0; c < n_parts; c++) {
-        fprintf(stderr, "chunk %d (device %d): frames %d..%d, %d pairs, %.3f s%s\n", c, rep[(size_t)c].device, first[(size_t)c],
-                first[(size_t)c] + cnt[(size_t)c], cnt[(size_t)c], rep[(size_t)c].seconds, rep[(size_t)c].ok ? "" : "  [FAILED]");
+        fprintf(stderr, "chunk %d (device %d, worker %d): frames %d..%d, %d pairs, %.3f s%s\n", c, rep[(size_t)c].device, rep[(size_t)c].worker,
+                first[(size_t)c], first[(size_t)c] + cnt[(size_t)c], cnt[(size_t)c], rep[(size_t)c].seconds, rep[(size_t)c].ok ? "" : "  [FAILED]");
         failed += rep[(size_t)c].ok ? 0 : 1;
     }
     if (report) *report = rep;

@@ -117,3 +117,42 @@ def test_carry_frame_needs_a_valid_previous_async_batch(pkg, synth):
         c.track_uploaded_async(0, 3, continue_chain=True, carry_frame=True)
     c.host_free(hl); c.host_free(hr)
     c.close()
+
+
+@pytest.mark.parametrize("mode", ["orb", "lk"])
+def test_track_batch_orders_frames_and_results_against_torchs_stream(pkg, tc, synth, mode):
+    """Context.track_batch with device frames + device results on a context that runs on its OWN stream: the frames arrive
+    late on a busy torch stream (non-blocking upload behind queued work), the result buffer's zero fill is a kernel on that
+    stream, and right after the call the frames are dropped and their blocks refilled with noise.  ORB mode reads level 0 in
+    place until the end of the front end, so without ordering on both sides the keypoints are garbage.  The binding orders
+    torch's stream before the launch and the library's work before torch's next operation (two event operations each)."""
+    seq = synth.StereoSequence(width=416, height=128, n_frames=6, seed=5)
+    fr = [seq.render(t) for t in range(6)]
+    hostL = tc.stack([f[0] for f in fr]).pin_memory()
+    hostR = tc.stack([f[1] for f in fr]).pin_memory()
+    P1, P2 = seq.proj()
+    kw = dict(track_mode=pkg.MODE_ORB, min_move2=0.05 ** 2, max_move2=100.0, orb_nlevels=3, orb_nfeatures=400) if mode == "orb" else {}
+    c = pkg.Context(416, 128, device=0, P1=P1, P2=P2, max_batch=5, **kw)
+    want = c.track_batch(hostL.cuda(), hostR.cuda())
+    assert int(want["ok"].sum()) >= 4
+    c.set_overlap(True)
+    side = tc.cuda.Stream()
+    busy = tc.empty(64 << 20, dtype=tc.float32, device="cuda")
+    for trial in range(3):
+        with tc.cuda.stream(side):
+            for _ in range(6):
+                busy.normal_()
+            L = hostL.to("cuda", non_blocking=True)
+            R = hostR.to("cuda", non_blocking=True)
+            buf = tc.zeros((5, pkg.STEP_DTYPE.itemsize), dtype=tc.uint8, device="cuda")
+            c.track_batch(L, R, results=buf)
+            del L, R                                       # the caching allocator hands these blocks to the next tensors
+            junk = [tc.randint(0, 255, hostL.shape, dtype=tc.uint8, device="cuda") for _ in range(2)]
+            host = buf.to("cpu", non_blocking=True)
+        side.synchronize()
+        got = np.frombuffer(host.numpy().tobytes(), dtype=pkg.STEP_DTYPE)
+        for k in ("ok", "n_prev_kps", "n_cur_kps", "n_tracked", "n_inliers"):
+            assert got[k].tolist() == want[k].tolist(), (trial, k)
+        assert got["pose"].tobytes() == want["pose"].tobytes(), trial
+        del junk
+    c.close()

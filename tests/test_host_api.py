@@ -524,6 +524,20 @@ def test_run_kitti_stereo_split_pairs(host_built, synth, tmp_path):
     # more chunks than pairs: clamped; a sequence that cannot be read: exit code 1
     r = subprocess.run([exe, str(y), str(y) + ".many.txt", "--split-pairs", "64"], capture_output=True, timeout=300)
     assert r.returncode == 0 and open(str(y) + ".many.txt", "rb").read() == want
+    # at most two chunk workers a device run at a time (here: one card), whatever the chunk count
+    assert {int(l.split("worker ")[1].split(")")[0]) for l in r.stderr.decode().splitlines() if l.startswith("chunk ")} <= {0, 1}
+    # the pose file named by the YAML (no path on the command line): the split run writes THAT file, the same bytes as the
+    # single run; the probe and the chunk Systems neither truncate it nor leave it empty
+    y2 = tmp_path / "orb_yaml_out.yaml"
+    yaml_out = tmp_path / "yaml_named_poses.txt"
+    with open(y2, "w", encoding="utf-8") as f:
+        f.write(open(y, encoding="utf-8").read() + f"pose_file: {yaml_out}\n")
+    r = subprocess.run([exe, str(y2)], capture_output=True, timeout=300)
+    assert r.returncode == 0 and open(yaml_out, "rb").read() == want
+    os.remove(yaml_out)
+    r = subprocess.run([exe, str(y2), "--split-pairs", "3"], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert open(yaml_out, "rb").read() == want
     bad = tmp_path / "bad.yaml"
     _write_yaml(bad, str(tmp_path / "nowhere"))
     r = subprocess.run([exe, str(bad), str(tmp_path / "bad.txt"), "--split-pairs", "2"], capture_output=True, timeout=300)
