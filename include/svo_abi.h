@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 8
+#define SVO_ABI_VERSION 9
 
 /* status codes */
 #define SVO_OK                 0
@@ -149,6 +149,13 @@ int         svo_sync(svo_ctx *ctx);
  * queued on `hip_stream` next.  NULL = the legacy default stream.  Device-side waits only. */
 int         svo_wait_stream(svo_ctx *ctx, void *hip_stream);
 int         svo_signal_stream(svo_ctx *ctx, void *hip_stream);
+/* ABI v9.  svo_signal_stream_inputs: every kernel that READS the caller's input buffers of the calls made so far (the frames
+ * of svo_track_batch / svo_add_frame are read in place until the end of the front end) happens-before whatever is queued on
+ * `hip_stream` next -- the stream may then overwrite or free them.  Unlike svo_signal_stream it does NOT wait for the
+ * side-stream pose stage of an overlap-mode batch: a producer that calls it after every batch keeps the overlap of batch k's
+ * pose stage with batch k + 1's front end (svo_signal_stream after every batch would serialise them through the producer's
+ * stream).  Results are complete only after svo_signal_stream / svo_sync. */
+int         svo_signal_stream_inputs(svo_ctx *ctx, void *hip_stream);
 int         svo_num_levels(const svo_ctx *ctx);               /* LK pyramid levels actually built */
 
 /* ---- stage API: one call per OpenCV call site of the reference ---------------------------- */

@@ -102,6 +102,7 @@ def load_library():
     lib.svo_upload_frames_at.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]
     lib.svo_wait_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.svo_signal_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.svo_signal_stream_inputs.argtypes = [C.c_void_p, C.c_void_p]
     lib.svo_wait_upload.argtypes = [C.c_void_p, C.c_int]
     lib.svo_track_uploaded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     lib.svo_track_uploaded_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -191,6 +192,11 @@ class Context:
         an overlap-mode batch included (svo_signal_stream): what a consumer of device-resident results on another stream
         calls instead of svo_sync()."""
         self._check(self.lib.svo_signal_stream(self.h, C.c_void_p(stream_handle)))
+
+    def signal_stream_inputs(self, stream_handle):
+        """`stream_handle` waits ON THE DEVICE until the kernels that read the caller's frames have run (the front end);
+        the side-stream pose stage is NOT waited for (svo_signal_stream_inputs, ABI v9)."""
+        self._check(self.lib.svo_signal_stream_inputs(self.h, C.c_void_p(stream_handle)))
 
     def _order_in(self, t):
         """Tensors torch has just produced (an output's zero fill is a kernel on TORCH's current stream; an input may still
@@ -429,15 +435,19 @@ class Context:
             rp, rmem = C.c_void_p(results.data_ptr()), MEM_DEVICE
         # The frames (read in place until the end of the front end in ORB mode) and a device result buffer (its zero fill) may
         # still be in flight on torch's current stream, and with device results the call returns while the kernels run:
-        # order torch's stream before the launch and the library's work -- side-stream pose stage included -- before
-        # whatever torch's stream does next (freeing or overwriting the frames, reading the records).  Two event operations
-        # each, no host synchronisation; skipped when the context runs ON torch's current stream (set_stream).
-        self._order_in(left_frames)
+        # torch's stream is ordered before the launch, and the kernels that READ THE FRAMES before whatever torch's stream
+        # does next (freeing or overwriting them) -- svo_signal_stream_inputs, not svo_signal_stream: making torch's stream
+        # wait for the side-stream pose stage after every batch would chain batch k + 1's front end behind batch k's pose
+        # stage through that stream and end their overlap.  The RECORDS of a device result buffer are complete after
+        # signal_stream(consumer) / sync(), as before.  Two event operations each, no host synchronisation; skipped when
+        # the context runs ON torch's current stream (set_stream).
+        ordered = self._order_in(left_frames)
         self._check(self.lib.svo_track_batch(self.h, C.c_void_p(left_frames.data_ptr()),
                                              C.c_void_p(right_frames.data_ptr()), int(pitch), int(fstride),
                                              int(F), p0, rp, rmem))
-        if results is not None:
-            self._order_out(results)
+        if results is not None and ordered:
+            import torch
+            self.signal_stream_inputs(torch.cuda.current_stream(left_frames.device).cuda_stream)
         return out
 
     # ---- host-resident frame batches (svo_upload_frames / svo_track_uploaded) -----------------

@@ -372,6 +372,42 @@ __device__ __forceinline__ float chain_b(const Sse2Lane &L)
     tail_adds<4>(acc, qb, 76); tail_adds<5>(acc, qb, 76); tail_adds<6>(acc, qb, 76); tail_adds<7>(acc, qb, 76);
     return L.b_tail ? acc : acc42;
 }
+#ifdef SVO_LKS_EXPERIMENTS
+// TIMING EXPERIMENTS of round 6 (never in the shipped build: tools/gpu/lks_chain_bound.sh compiles them in on the GPU box and
+// selects one with SVO_LKS_EXP; results in profiles/r06_lk_sse2_chain_bound.json).  Question: what would an integer / tree
+// fast path for the b chains buy when the float sums are provably exact?  chain_b_tree adds the same staged terms as a TREE --
+// four accumulators over phase 1, every lane of a half row its own eight tail terms, three DPP steps -- which is what ANY
+// exact fast path has to do at least (its sums differ from the serial order in the last bit when a partial sum passes 2^24:
+// a bound, not a product path), optionally with the sums of |terms| beside it (a guard evaluated in the chain lanes).
+template <bool GUARD>
+__device__ __forceinline__ float chain_b_tree(const Sse2Lane &L, int lane, float &guard)
+{
+    lds_cf32x4 *p = (lds_cf32x4 *)(size_t)L.cb;
+    const f32x4 qa = *(lds_cf32x4 *)(size_t)L.cbA, qb = *(lds_cf32x4 *)(size_t)L.cbB;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+        const f32x4 q = p[t];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { s[e] += q[e]; if (GUARD) a[e] += __builtin_fabsf(q[e]); }
+    }
+    const f32x4 q10 = p[10];
+    s[0] += q10[0]; s[1] += q10[1];
+    if (GUARD) { a[0] += __builtin_fabsf(q10[0]); a[1] += __builtin_fabsf(q10[1]); }
+    const float pad_s = q10[2] + q10[3], pad_a = __builtin_fabsf(q10[2]) + __builtin_fabsf(q10[3]);
+    float S = (s[0] + s[1]) + (s[2] + s[3]), A = (a[0] + a[1]) + (a[2] + a[3]);
+    const int f = lane & 7;
+    const bool v1 = f < 7;
+    float ts = (qa[0] + qa[1]) + (qa[2] + qa[3]) + (qb[0] + (v1 ? (qb[1] + qb[2]) + qb[3] : 0.f));
+    float ta = 0.f;
+    if (GUARD) ta = (__builtin_fabsf(qa[0]) + __builtin_fabsf(qa[1])) + (__builtin_fabsf(qa[2]) + __builtin_fabsf(qa[3])) +
+                    (__builtin_fabsf(qb[0]) + (v1 ? (__builtin_fabsf(qb[1]) + __builtin_fabsf(qb[2])) + __builtin_fabsf(qb[3]) : 0.f));
+    ts += row_shl<4>(ts); ts += row_shl<2>(ts); ts += row_shl<1>(ts);
+    if (GUARD) { ta += row_shl<4>(ta); ta += row_shl<2>(ta); ta += row_shl<1>(ta); }
+    guard = L.b_tail ? A + pad_a + ta : A;
+    return L.b_tail ? S + pad_s + ts : S;
+}
+#endif
 // A: positions 0..3 of a row = the SSE lanes q (105 terms), position 4 = the scalar tail (21 terms); every lane carries
 // all three sums.  A term is the product of two 16-bit patch values, < 2^24: exact in float, so fma(fx, fy, acc) rounds
 // once exactly where _mm_add_ps(acc, _mm_mul_ps(fx, fy)) / iA += (float)(ix * iy) round.
@@ -437,7 +473,7 @@ __device__ __forceinline__ float combine_a(float r)
 
 // One cv::calcOpticalFlowPyrLK call for the wave's four points (cf. lk_call4 in lk.hip; control values are per
 // lane = per slot lane >> 4).
-template <bool LEGACY>
+template <bool LEGACY, int EXP>
 __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *slotI, const uint8_t *slotJ, float2 prevPt,
                                               float2 &outPt, int &status, bool live, uint32_t *lds, int lane,
                                               const Sse2Lane &L)
@@ -597,7 +633,19 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
             wave_lds_fence();
             float b1f, b2f;
             {
-                const float r = chain_b<LEGACY>(L);
+                float r;
+#ifdef SVO_LKS_EXPERIMENTS
+                float guard = 0.f;
+                if (EXP == 1) __builtin_amdgcn_s_setprio(3);                       // the chain wave first at the issue arbiter
+                if (EXP == 2) r = chain_b_tree<false>(L, lane, guard);             // no serial chain at all: the bound
+                else if (EXP == 3) {                                               // tree + guard max(P, N) = (sum |t| + |S|) / 2 < 2^24, else the chain
+                    r = chain_b_tree<true>(L, lane, guard);
+                    if (__builtin_expect(__any(guard + __builtin_fabsf(r) >= 33546240.f), 0)) r = chain_b<LEGACY>(L);
+                } else r = chain_b<LEGACY>(L);
+                if (EXP == 1) __builtin_amdgcn_s_setprio(0);
+#else
+                r = chain_b<LEGACY>(L);
+#endif
                 // bbuf = qb0 + qb1; ib1 += bbuf[0] + bbuf[2]; ib2 += bbuf[1] + bbuf[3]  (the tails are already in ib), on the
                 // DPP network inside the row.  Positions: 0 tail x | 1..4 chains 0, 4, 2, 6 | 8 tail y | 9..12 chains 1, 5, 3, 7:
                 // position 1 + 2 = bb0, 3 + 4 = bb2 (9.. : bb1, bb3), then their sum, then the tail at the head of the half row
@@ -637,7 +685,7 @@ __device__ __forceinline__ void lk_call4_sse2(const PyrGeom &g, const uint8_t *s
 
 // Grid: ONE wave per workgroup, a.gx WAVES per batch item walking the item's points in strides of a.gx * 4 slots;
 // the same XCD-aware item mapping as lk_kernel (consecutive workgroup ids go round the 8 XCDs).
-template <bool LEGACY>
+template <bool LEGACY, int EXP = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lk_sse2_kernel(LkArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[LEGACY ? kLdsDwLegacy : kLdsDwSse2];
@@ -672,7 +720,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const uint8_t *sI = a.prev[c] + (int64_t)b * a.slot_stride;
             const uint8_t *sJ = a.next[c] + (int64_t)b * a.slot_stride;
             int st;
-            lk_call4_sse2<LEGACY>(a.g, sI, sJ, cur, nxt, st, live, lds, lane, L);
+            lk_call4_sse2<LEGACY, EXP>(a.g, sI, sJ, cur, nxt, st, live, lds, lane, L);
             if (writer && live) {
                 a.pts_out[c][po] = nxt;
                 a.status[c][po] = (uint8_t)st;
@@ -713,6 +761,13 @@ void launch_lk_sse2(const LkArgs &a0, int batch, int max_pts, hipStream_t st)
         }
         hipLaunchKernelGGL(lk_sse2_kernel<true>, dim3(batch * a.gx), dim3(64), 0, st, a);
     } else {
+#ifdef SVO_LKS_EXPERIMENTS
+        static const int exp_variant = getenv("SVO_LKS_EXP") ? atoi(getenv("SVO_LKS_EXP")) : 0;
+        if (exp_variant == 1) hipLaunchKernelGGL((lk_sse2_kernel<false, 1>), dim3(batch * a.gx), dim3(64), 0, st, a);
+        else if (exp_variant == 2) hipLaunchKernelGGL((lk_sse2_kernel<false, 2>), dim3(batch * a.gx), dim3(64), 0, st, a);
+        else if (exp_variant == 3) hipLaunchKernelGGL((lk_sse2_kernel<false, 3>), dim3(batch * a.gx), dim3(64), 0, st, a);
+        else
+#endif
         hipLaunchKernelGGL(lk_sse2_kernel<false>, dim3(batch * a.gx), dim3(64), 0, st, a);
     }
 }

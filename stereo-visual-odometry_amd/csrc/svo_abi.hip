@@ -380,6 +380,20 @@ extern "C" int svo_signal_stream(svo_ctx *ctx, void *hip_stream)
     return SVO_OK;
 }
 
+// ABI v9: the front end only (everything that reads the caller's frames is on ctx->stream; the pose stage of an overlap-mode
+// batch, which reads context memory only, is on the side stream and is not waited for).
+extern "C" int svo_signal_stream_inputs(svo_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    hipStream_t other = (hipStream_t)hip_stream;
+    if (other == ctx->stream) return SVO_OK;
+    SVO_HIP(hipSetDevice(ctx->device));
+    if (!ctx->ev_order) SVO_HIP(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+    SVO_HIP(hipEventRecord(ctx->ev_order, ctx->stream));
+    SVO_HIP(hipStreamWaitEvent(other, ctx->ev_order, 0));
+    return SVO_OK;
+}
+
 extern "C" int svo_num_levels(const svo_ctx *ctx) { return ctx ? ctx->geom.nlevels : 0; }
 
 extern "C" int svo_enable_timing(svo_ctx *ctx, int on)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = ctypes.CDLL(pkg.library_path())
     missing = [s for s in _declared_symbols() if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.svo_abi_version() == 8
+    assert lib.svo_abi_version() == 9
 
 
 def test_default_config_matches_reference_yaml(pkg):

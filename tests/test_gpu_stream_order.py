@@ -125,7 +125,8 @@ def test_track_batch_orders_frames_and_results_against_torchs_stream(pkg, tc, sy
     late on a busy torch stream (non-blocking upload behind queued work), the result buffer's zero fill is a kernel on that
     stream, and right after the call the frames are dropped and their blocks refilled with noise.  ORB mode reads level 0 in
     place until the end of the front end, so without ordering on both sides the keypoints are garbage.  The binding orders
-    torch's stream before the launch and the library's work before torch's next operation (two event operations each)."""
+    torch's stream before the launch and the kernels that read the frames before torch's next operation
+    (svo_signal_stream_inputs, ABI v9: two event operations each, the pose-stage overlap is kept)."""
     seq = synth.StereoSequence(width=416, height=128, n_frames=6, seed=5)
     fr = [seq.render(t) for t in range(6)]
     hostL = tc.stack([f[0] for f in fr]).pin_memory()
@@ -148,6 +149,7 @@ def test_track_batch_orders_frames_and_results_against_torchs_stream(pkg, tc, sy
             c.track_batch(L, R, results=buf)
             del L, R                                       # the caching allocator hands these blocks to the next tensors
             junk = [tc.randint(0, 255, hostL.shape, dtype=tc.uint8, device="cuda") for _ in range(2)]
+            c.signal_stream(side.cuda_stream)              # the records: complete once the side-stream pose stage is (the caller's call)
             host = buf.to("cpu", non_blocking=True)
         side.synchronize()
         got = np.frombuffer(host.numpy().tobytes(), dtype=pkg.STEP_DTYPE)
