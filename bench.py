@@ -412,6 +412,52 @@ def stream_leg(pkg, stream_mod, L, R, width, height, P1, P2, mode_kw, depths=(1,
     return res
 
 
+def pose_latency_probe(pkg, L, R, width, height, B, ctx_kw, reps=3):
+    """When do the poses of batch k exist once batch k + 1 has been launched?  Two B-pair batches from page-locked host
+    frames through svo_track_uploaded_async, overlap on: batch k's pose stage (side stream) runs beside batch k + 1's front
+    end, whose LK grid fills the chip.  Reported: the LK launch of a batch (HIP events, a synchronous batch) and, per
+    repetition, how long after the SECOND launch the first batch's records were ready (svo_results_ready, polled) and how
+    long the second batch's took.  A pose stage starved of wave slots behind the next LK grid shows as first ~ second
+    (round 5, float-order modes: finalize_chain_kernel waited up to a whole LK launch); the reference's Step_ros returns
+    when the pose exists (src/System.cpp:60-74)."""
+    pitch = (width + 255) // 256 * 256
+    ctx = pkg.Context(width, height, max_batch=B, **ctx_kw)
+    ctx.set_overlap(True)
+    hl, hr = ctx.host_frames(B + 1, pitch), ctx.host_frames(B + 1, pitch)
+    hl[:, :, :width] = L[:B + 1, :, :width].cpu().numpy()
+    hr[:, :, :width] = R[:B + 1, :, :width].cpu().numpy()
+    for buf in (0, 1):
+        ctx.upload_frames(buf, hl, hr)
+        ctx.wait_upload(buf)
+    ctx.track_uploaded(0, B + 1)                                   # warm-up
+    ctx.enable_timing(True)
+    ctx.get_timing()
+    ctx.track_uploaded(0, B + 1)
+    lk_ms = float(dict(ctx.get_timing()).get("lk", 0.0))
+    ctx.enable_timing(False)
+    first, second = [], []
+    for _ in range(reps):
+        ctx.sync()
+        ctx.track_uploaded_async(0, B + 1)
+        ctx.track_uploaded_async(1, B + 1)
+        t0 = time.perf_counter()
+        while ctx.results_ready() == 0:
+            pass
+        first.append(1e3 * (time.perf_counter() - t0))
+        ctx.collect_results(B)
+        while ctx.results_ready() == 0:
+            pass
+        second.append(1e3 * (time.perf_counter() - t0))
+        ctx.collect_results(B)
+    ctx.host_free(hl)
+    ctx.host_free(hr)
+    ctx.close()
+    return {"pairs_per_batch": B, "lk_launch_ms": round(lk_ms, 3),
+            "first_batch_ready_ms_after_second_launch": [round(v, 3) for v in first],
+            "second_batch_ready_ms_after_its_launch": [round(v, 3) for v in second],
+            "definition": "two svo_track_uploaded_async batches back to back, overlap on; records polled with svo_results_ready"}
+
+
 def e2e_leg(args, L, R, P1, width):
     """run_kitti_stereo (the reference's CLI, batched runner) on a KITTI-layout directory of the bench's own S0 frames,
     once from PGM and once from PNG files (the reference's input format): pairs/s from process start to exit."""
@@ -805,6 +851,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl + f", batched frame pairs ({B} per step, {NC} distinct chunks cycled), frames resident in HBM "
                                       "for `value`; `m1` = host-resident frames, H2D included",
+                       "lk_accum": (None if args.mode != "lk" else
+                                    "exact (canonical C0: the five LK sums as exact integers, order-free; NOT an x86 OpenCV's float order -- "
+                                    "see the lk_accum_* legs and value_x86_order)" if args.lk_accum == "exact" else
+                                    args.lk_accum + " (float sums in a restated x86 OpenCV lane order, DESIGN.md section 2)"),
                        "pairs_per_step_per_gpu": B, "mean_keypoints_per_pair": round(mean_kps, 1),
                        "pairs_ok_last_step": n_ok, "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
                        "parallelism": ((f"one sequence in {world} chunks of frame pairs (1-frame halo), RCCL gather of "
@@ -927,7 +977,8 @@ def main():
                                       "lane order of upstream's CV_SSE2 block, bit-identical to oracle/lk.c mode 2)",
                         "roofline": roofline_lk(st_ms, int(round(float(recs["n_prev_kps"].mean()) * B)), B, sse2=True) if st_ms.get("lk") else None,
                         "lk_ms_per_step": round(st_ms.get("lk", 0.0), 4),
-                        "lk_ms_per_step_exact": round(stage_ms.get("lk", 0.0), 4) if stage_ms.get("lk") else None},
+                        "lk_ms_per_step_exact": round(stage_ms.get("lk", 0.0), 4) if stage_ms.get("lk") else None,
+                        "pose_latency": pose_latency_probe(pkg, L, R, W, H, B, dict(P1=P1, P2=P2, lk_accum=pkg.LK_ACCUM_SSE2))},
                        dict(mode="lk", sse2=True, n_check=args.self_check_pairs))
                 # (1b) the other two restated x86 orders, briefly (which one an OpenCV 3 build runs depends on
                 # its version): the same workload, 64 pairs of the last step checked against their oracle modes (4 / 3)
@@ -936,6 +987,8 @@ def main():
                                                         dict(P1=P1, P2=P2, lk_accum=oacc))
                     finish("lk_accum_" + oname, lctx, el, st_ms, recs, f0, max(2, leg_steps // 2), B,
                            {"definition": "the main workload with svo_config.lk_accum = " + oname + " (lk_sse2_kernel, bit-identical to oracle/lk.c mode %d)" % omode,
+                            "roofline": (roofline_lk(st_ms, int(round(float(recs["n_prev_kps"].mean()) * B)), B, sse2=True, profile="lk_" + oname)
+                                         if st_ms.get("lk") else None),
                             "lk_ms_per_step": round(st_ms.get("lk", 0.0), 4)},
                            dict(mode="lk", sse2=omode, n_check=min(64, args.self_check_pairs)))
             if args.mode == "lk":
@@ -1044,6 +1097,13 @@ def main():
         # ---- e2e: the drop-in binary from image FILES (decode + H2D + tracking + pose file, process start included)
         if world == 1 and args.e2e_frames >= 3 and not args.config5 and not args.no_secondary:
             out["e2e"] = e2e_leg(args, L, R, P1, W)
+        # the same workload in the float orders an x86 OpenCV 3 can run (whichever the reference's build has): the slowest of the three
+        x86 = {k: out[k]["value"] for k in ("lk_accum_sse2", "lk_accum_simd128", "lk_accum_sse2_legacy") if isinstance(out.get(k), dict)}
+        if x86:
+            worst = min(x86, key=x86.get)
+            out["value_x86_order"] = {"value": x86[worst], "unit": "stereo pairs/s", "leg": worst, "all": x86,
+                                      "definition": "`value`'s workload with the LK sums in float, in the slowest of the three restated x86 lane orders "
+                                                    "(bit-identical to oracle/lk.c modes 2 / 4 / 3); `value` itself is lk_accum = exact"}
         print(json.dumps(out), flush=True)
         checks = [out.get("self_check")] + [out[k].get("self_check") for k in ("lk_accum_sse2", "orb", "hd") if isinstance(out.get(k), dict)]
         if any(c is not None and not c["ok"] for c in checks):

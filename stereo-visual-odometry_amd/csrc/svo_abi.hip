@@ -270,17 +270,10 @@ extern "C" int svo_create(const svo_config *cfg, int device, svo_ctx **out)
     PHASE("one device allocation + deferred initialisation");
     CK(hipHostMalloc(&ctx->h_stage, (size_t)ctx->stage_pitch * h * 2, hipHostMallocDefault));
     for (int k = 0; k < 2; k++) CK(hipEventCreateWithFlags(&ctx->ev_stage[k], hipEventDisableTiming));
-    {
-        // the pose stage of batch k runs beside the front end of batch k + 1 and ends batch k's latency: its queue goes first
-        // when the dispatcher has a free slot (SVO_SIDE_PRIORITY=0: a plain stream, for A/B runs)
-        int lo = 0, hi = 0;
-        const char *e = getenv("SVO_SIDE_PRIORITY");
-        if (e && e[0] == '0') CK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-        else {
-            CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            CK(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi));
-        }
-    }
+    // (a high-priority side stream was measured in round 6: no difference, 5.80 against 5.80 ms per ORB step and 14.32 against
+    // 14.34 per LK step -- what holds a pose-stage kernel back beside the next front end is free LDS and wave slots on a CU, not
+    // the queue's place at the dispatcher)
+    CK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     CK(hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&ctx->ev_back, hipEventDisableTiming));
     if (B > 1) {

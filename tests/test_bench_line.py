@@ -31,6 +31,11 @@ def test_default_line_carries_the_legs_and_a_green_self_check():
         assert d["value"] > 0 and d["self_check"]["ok"] and d["stage_ms_per_step"][stage] > 0, leg
         assert d["self_check"]["pairs"] == d["self_check"]["pairs_of_step"], leg          # small batches are checked whole
     assert out["lk_accum_sse2"]["lk_ms_per_step"] > out["lk_accum_sse2"]["lk_ms_per_step_exact"] > 0
+    assert out["config"]["lk_accum"].startswith("exact") and out["value_x86_order"]["leg"] in ("lk_accum_sse2", "lk_accum_simd128", "lk_accum_sse2_legacy")
+    assert out["value_x86_order"]["value"] == min(out[k]["value"] for k in ("lk_accum_sse2", "lk_accum_simd128", "lk_accum_sse2_legacy"))
+    assert len(out["lk_accum_sse2"]["pose_latency"]["first_batch_ready_ms_after_second_launch"]) == 3
+    for leg in ("lk_accum_simd128", "lk_accum_sse2_legacy"):
+        assert out[leg]["roofline"]["frac"] > 0, leg
     assert out["orb"]["roofline"]["frac"] > 0 and out["orb"]["cpu_baseline"]["value"] > 0
     assert out["hd"]["mean_keypoints_per_pair"] == 2000.0 and out["hd"]["roofline"]["frac"] > 0
     assert out["hd"]["cpu_baseline"]["cores"] == 1

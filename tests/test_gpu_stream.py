@@ -158,3 +158,32 @@ def test_frame_stream_in_place_producer(pkg, frames11):
     for p, (g, w) in enumerate(zip(got, want)):
         assert int(g["ok"]) == int(w["ok"]) == 1 and int(g["n_tracked"]) == int(w["n_tracked"]), p
         assert g["T_rel_inv"].tobytes() == w["T_rel_inv"].tobytes() and g["pose"].tobytes() == w["pose"].tobytes(), p
+
+
+@pytest.mark.parametrize("accum", ["sse2", "exact"])
+def test_poses_of_a_batch_do_not_wait_for_the_next_lk_launch(pkg, synth, accum):
+    """Step_ros returns when the pose exists (src/System.cpp:60-74); in the pipelined stream the pose stage of batch k runs on
+    the side stream beside batch k + 1's front end.  Round 5: in the float-order LK modes finalize_chain_kernel (then one
+    256-thread workgroup) found no four free wave slots behind lk_sse2_kernel's single-wave workgroups until that grid
+    drained, and batch k's poses arrived a whole LK launch late (profiles/r06_sse2_timeline_before.csv).  As one wave it takes
+    the first slot that frees: after the second launch, the first batch's records must be there long before the second
+    batch's -- the two arrivals at least 60 % of an LK launch apart (starved, they were a pose stage apart).  256 pairs a
+    batch, as the batched runner and the bench use: the next batch's pyramid + FAST kernels (1.2 ms) then cover the hypothesis
+    kernels of the pose stage, and the finalize launch is the one that lands beside the LK grid."""
+    import sys
+    import torch
+    sys.path.insert(0, conftest.ROOT)
+    import bench
+    B = 256
+    dev = torch.device("cuda", 0)
+    seq = synth.StereoSequence(width=1241, height=376, n_frames=B + 1, seed=20200710, device=dev)
+    fr = [seq.render(f) for f in range(B + 1)]
+    L = torch.stack([f[0] for f in fr])
+    R = torch.stack([f[1] for f in fr])
+    P1, P2 = seq.proj()
+    kw = dict(P1=P1, P2=P2, lk_accum=pkg.LK_ACCUM_SSE2 if accum == "sse2" else 0)
+    r = bench.pose_latency_probe(pkg, L, R, 1241, 376, B, kw, reps=3)
+    assert r["lk_launch_ms"] > 1.0, r
+    gaps = [b - a for a, b in zip(r["first_batch_ready_ms_after_second_launch"], r["second_batch_ready_ms_after_its_launch"])]
+    assert sorted(gaps)[1] > 0.6 * r["lk_launch_ms"], r          # all but at most one repetition (host jitter)
+    del L, R
