@@ -1128,15 +1128,15 @@ def main():
             out["e2e"] = e2e_leg(args, n_e2e, lambda t0, t1: (L[t0:t1, :, :W].cpu().numpy(), R[t0:t1, :, :W].cpu().numpy()), P1, W)
             if args.e2e_full_frames > n_e2e:
                 # BASELINE config #2 as worded: the FULL sequence (KITTI-00: 4541 frames), single stream, from image files; frames
-                # beyond the resident chunks are rendered here, written out and dropped (PNG at zlib level 1: the encode is
-                # bench set-up, the runner's inflate does not care)
+                # beyond the resident chunks are rendered here, written out and dropped (the PNG encode runs on a thread pool
+                # beside the renderer)
                 seq_full = synth.StereoSequence(width=W, height=H, n_frames=args.e2e_full_frames, seed=seed, device=dev)
 
                 def rendered(t0, t1):
                     fl, fr = seq_full.render_range(t0, t1)
                     return fl.cpu().numpy(), fr.cpu().numpy()
 
-                out["e2e_full"] = e2e_leg(args, args.e2e_full_frames, rendered, P1, W, png_level=1)
+                out["e2e_full"] = e2e_leg(args, args.e2e_full_frames, rendered, P1, W)
                 out["e2e_full"]["definition"] = ("BASELINE config #2 as worded (full sequence: KITTI-00's 4541 frames, single stream, image files): " +
                                                  out["e2e_full"]["definition"])
         # the same workload in the float orders an x86 OpenCV 3 can run (whichever the reference's build has): the slowest of the three

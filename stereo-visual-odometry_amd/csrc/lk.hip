@@ -561,7 +561,8 @@ void launch_lk(const LkArgs &a0, int batch, int max_pts, hipStream_t st)
     a.gx = chunks < 192 ? chunks : 192;
     a.spread = 0;
     if (batch < 4) {                             // fewer than 768 workgroups: 3 per CU are resident at once
-        const int wide = (max_pts + 3) / 4, room = 768 / batch;
+        static const int room_all = getenv("SVO_LK_SPREAD_ROOM") ? atoi(getenv("SVO_LK_SPREAD_ROOM")) : 768;     // test hook (A/B runs)
+        const int wide = (max_pts + 3) / 4, room = room_all / batch;
         a.gx = wide < room ? wide : room;
         a.spread = 1;
     }

@@ -297,10 +297,21 @@ __device__ __forceinline__ int fast_cornerness(const uint8_t *c, int P)
 // belongs to the cell whose interior holds it, and the suppression ignores neighbours that belong to another cell.
 // Per cell the fixed work (staging, barriers, list bookkeeping, nearly empty last passes of the loops) is a quarter
 // of the one-cell-per-workgroup kernel's, and the overlap columns are tested once instead of twice.
+// Diagnostic build (-DSVO_CF_STAMP, tools/gpu/cf_stamps.sh): a few workgroups of image 2 print the s_memtime ticks their first
+// wave spent per section.
+#ifdef SVO_CF_STAMP
+#define CF_AT(i) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__builtin_amdgcn_s_memtime()); cf_acc[i] += now_ - cf_last; cf_last = now_; }
+#else
+#define CF_AT(i)
+#endif
 __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, const uint8_t *slots, int64_t slot_stride,
                                                            int iniTh, int minTh, float4 *cell_cand, int *cell_cnt,
                                                            int64_t cand_img_stride, int64_t cnt_img_stride, int n_img, OrbL0 z)
 {
+#ifdef SVO_CF_STAMP
+    uint32_t cf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cf_last = 0;
+    CF_AT(7) cf_acc[7] = 0;
+#endif
     int b, blk_all;                                                       // image, workgroup index over all levels
     xcd_image_block(blockIdx.x, g.blks_total, n_img, b, blk_all);
     const int l = level_of_block(g.blk_off, g.nlevels, blk_all);
@@ -366,6 +377,7 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
     // the cell of a window column (its interior is [3 + c wCell, 3 + (c + 1) wCell), the last one ends at cw - 3)
     auto cell_of = [&](int x) { const int xi = x - 3; return (xi >= wCell) + (xi >= 2 * wCell) + (xi >= 3 * wCell); };
     __syncthreads();
+    CF_AT(0)                                                 // prologue + staging
     // Cornerness only matters where it can reach the threshold in force: a corner at threshold t needs one
     // pixel of each opposite pair (0,8), (4,12) beyond t, so positions failing that 4-pixel test at t keep
     // V = 0, and the full arc min/max runs over a compacted list of the survivors.
@@ -446,6 +458,7 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
             }
         }
         __syncthreads();
+        CF_AT(1)                                             // 4-pixel test walk + survivor list
         // cornerness of the survivors; the positions that reach the threshold are compacted again IN PLACE (a
         // write index never passes the block of kCellThreads entries being read), so the NMS passes below only
         // visit possible keypoints instead of every pixel of the window
@@ -473,6 +486,7 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
                 if (cand) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
             }
         }
+        CF_AT(2)                                             // cornerness of the survivors + candidate list
     };
     // phase 1 at the higher of the two thresholds a cell can end up with, phase 2 (all pixels that can
     // reach the lower one) only when the first NMS pass leaves a cell empty
@@ -533,6 +547,7 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
             }
         }
         __syncthreads();
+        CF_AT(3)                                             // NMS pass
         // "if (vKeysCell.empty()) FAST(..., minThFAST)": strict NMS can empty a cell whose corners tie
         bool again = false;
 #pragma unroll
@@ -564,6 +579,12 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
         }
         // (a count may exceed kCellCap: flagged by orb_gather_kernel)
         if (tid < ngroup) cnt[tid] = tid == 0 ? nkc[0] : tid == 1 ? nkc[1] : tid == 2 ? nkc[2] : nkc[3];
+        CF_AT(4)                                             // ordered emission
+#ifdef SVO_CF_STAMP
+        if (tid == 0 && b == 2 && (blk == 0 || blk == 37) && (l == 0 || l == 2 || l == 5))
+            printf("cf l %d blk %d cw %d ch %d nlist %d ncand %d nk %d | stage %u test %u corner %u nms %u emit %u\n", l, blk, cw, ch, s_nlist, s_ncand, nk,
+                   cf_acc[0], cf_acc[1], cf_acc[2], cf_acc[3], cf_acc[4]);
+#endif
     }
 }
 
