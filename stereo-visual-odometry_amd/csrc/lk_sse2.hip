@@ -74,13 +74,15 @@ constexpr int kDumpB = kChainOff[0] + 43, kDumpA = kStageDw - 1;                
 // _mm_mullo / _mm_mulhi_epi16 of (It_k It_k) x (Ix_k Iy_k) -- and adds the converted products one by one: pixels 0, 1, then 4, 5 of a
 // group of eight to qb0, 2, 3, then 6, 7 to qb1).  The eight lane chains are the same lanes as above, but a chain takes TWO terms per
 // group -- pixel k, then pixel k + 4 -- instead of their exact int32 sum: 84 terms (88 read), term t = 4 row + 2 group + (0 | 1).  A
-// slot's staging is 928 words: the tails at 0 / 108, lane chain c at 216 + 88 c; 25.7 KB of LDS per wave, six waves per CU.  (The
-// layout is the plain one: this order is kept for completeness -- whichever block a target OpenCV is found to run can be selected --,
-// not tuned like the two above.)
-constexpr int kStageDwL = 928, kTailYL = 0, kTailXL = 108, kChain0L = 216, kChainStrideL = 88;
-constexpr int kLdsDwLegacy = kTilesDw + kSlots * kStageDwL + 16;                   // 6432 dwords = 25 728 B
-constexpr int kDumpBL = kChain0L + 87, kDumpAL = kStageDwL - 1;
-static_assert(kChain0L + 8 * kChainStrideL <= kStageDwL && a_tail_base(false) + 24 < kStageDwL && kLdsDwLegacy * 4 <= 26 * 1024, "legacy staging");
+// slot's staging is 960 words, six waves per CU.  Round 6: the block order below and the slot stride come from the same search as
+// the madd orders' (tools/model/lds_chain_layout.py legacy): the 22 chain reads and the feeder read are conflict-free in the
+// hardware's four read groups -- in the plain order of round 5 (tails at 0 / 108, chain c at 216 + 88 c, stride 928) every one of
+// them took 8 LDS cycles instead of 4 (profiles/r06_lk_sse2_legacy_r05src_pmc.json: 4.96 G conflict cycles of 11.17 G).
+constexpr int kStageDwL = 960, kTailYL = 180, kTailXL = 468;
+__device__ constexpr int kChainOffL[8] = {88, 584, 0, 764, 676, 288, 376, 860};
+constexpr int kLdsDwLegacy = kTilesDw + kSlots * kStageDwL + 16;                   // 6560 dwords = 26 240 B
+constexpr int kDumpBL = kChainOffL[0] + 87, kDumpAL = kStageDwL - 1;                // padding of lane chain 0 / the last word of the area
+static_assert(kChainOffL[7] + 88 <= kStageDwL - 1 && a_tail_base(false) + 24 < kStageDwL && kLdsDwLegacy * 4 <= 26 * 1024 + 512, "legacy staging");
 template <bool LEGACY> __host__ __device__ constexpr int stage_dw() { return LEGACY ? kStageDwL : kStageDw; }
 static_assert(kStageDw % 64 == 0 && kTailX % 4 == 0 && kTailY % 4 == 0 && kTilesDw % 4 == 0 && kAq0 % 4 == 0 && a_stride(false) % 4 == 0 && a_stride(true) % 4 == 0,
               "chain reads are 16-byte loads; the conflict-free order assumes a slot stride of whole bank rounds");
@@ -134,7 +136,7 @@ __device__ __forceinline__ Sse2Lane make_lane(int lane, uint32_t lds_base, bool 
             // term j = 2 m + xy: pixel m of the lane's eight (m < 4), j = 8 + 2 m + xy: pixel m + 4
             const int c = j & 7, second = j >> 3;
             e = kDumpBL;
-            if (group) e = kChain0L + kChainStrideL * c + 4 * L.row + 2 * (lane & 1) + second;
+            if (group) e = kChainOffL[c] + 4 * L.row + 2 * (lane & 1) + second;
             if (tail && j < 8) e = ((j & 1) ? kTailYL : kTailXL) + 5 * L.row + (j >> 1);              // x = 16..19
             if (tail && (j == 8 || j == 9)) e = ((j & 1) ? kTailYL : kTailXL) + 5 * L.row + 4;         // x = 20
         }
@@ -161,7 +163,7 @@ __device__ __forceinline__ Sse2Lane make_lane(int lane, uint32_t lds_base, bool 
     L.b_tail = f == 0;
     const int fc = f == 0 ? 0 : (f < 4 ? f : 4);                      // 1..4: the lane chain whose terms this position reads
     const int cmap = ((fc - 1) & 1) * 4 + ((fc - 1) >> 1) * 2 + h;
-    L.cb = stage_s + (uint32_t)(fc == 0 ? tail_dw : (LEGACY ? kChain0L + kChainStrideL * (fc == 0 ? 0 : cmap) : kChainOff[fc == 0 ? 0 : cmap])) * 4;
+    L.cb = stage_s + (uint32_t)(fc == 0 ? tail_dw : (LEGACY ? kChainOffL[fc == 0 ? 0 : cmap] : kChainOff[fc == 0 ? 0 : cmap])) * 4;
     L.cbA = stage_s + (uint32_t)(tail_dw + (LEGACY ? 88 : 44) + 4 * f) * 4;
     L.cbB = L.cbA + 32 * 4;
     // A: positions 0..3 the SSE lanes, 4 the tail; 5..11 follow position 4, 12..15 position 0

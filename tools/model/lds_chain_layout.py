@@ -6,7 +6,8 @@ MI355X serves a ds_read_b128 in four groups of sixteen lanes -- {0-3, 12-15, 20-
 broadcast (/opt/skills/guides/MI355X_MICROARCH.md, LDS).  `check` prices the layout the kernel uses (csrc/lk_sse2.hip:
 kChainOff, kTailX, kTailY, kStageDw and the chain-lane positions of make_lane); `search` is the random search over block
 orders and slot strides that found it.
-usage: lds_chain_layout.py [search]"""
+`legacy` does the same for the legacy order's staging (84-term lane chains: 88 words a chain, 22 reads + one feeder read).
+usage: lds_chain_layout.py [search | legacy]"""
 import itertools, random, sys
 
 G = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
@@ -50,8 +51,41 @@ def phase2(off, S, pi=tuple(range(8))):
 
 
 KERNEL = dict(TY=0, c0=108, c7=152, c1=196, c5=240, c3=284, c4=328, c2=372, TX=416, c6=524)
+KERNEL_LEGACY = dict(c2=0, c0=88, TY=180, c5=288, c6=376, TX=468, c1=584, c4=676, c3=764, c7=860)     # kChainOffL / kTailXL / kTailYL, stride 960
+ROUND5_LEGACY = dict(TY=0, TX=108, **{'c%d' % c: 216 + 88 * c for c in range(8)})                      # stride 928
+
+
+def phase2_legacy(off, S):
+    ad = [0] * 64
+    for lane in range(64):
+        s, p = lane >> 4, lane & 15
+        ad[lane] = s * S + off['TY' if p >> 3 else 'TX'] + 88 + 4 * (p & 7)
+    return conflicts(ad)
+
+
+def legacy():
+    xs = ('c0', 'c4', 'c2', 'c6')
+    print("legacy, round-5 plain order, stride 928: extra cycles per chain read (22 of them)", phase1(ROUND5_LEGACY, 928, xs), "| feeder read", phase2_legacy(ROUND5_LEGACY, 928))
+    print("legacy, kernel layout, stride 960:", phase1(KERNEL_LEGACY, 960, xs), "|", phase2_legacy(KERNEL_LEGACY, 960))
+    ents = ['c%d' % c for c in range(8)] + ['TX', 'TY']
+    size = {e: 88 for e in ents}; size['TX'] = size['TY'] = 108
+    random.seed(2)
+    best = []
+    for _ in range(2000):
+        perm = random.sample(ents, 10)
+        off, o = {}, 0
+        for b in perm:
+            off[b] = o; o += size[b] + random.choice([0, 0, 4, 8, 12])
+        for S in range((o + 3) // 4 * 4, (o + 3) // 4 * 4 + 72, 4):
+            if phase1(off, S, xs) == 0: best.append((phase2_legacy(off, S), S, tuple((b, off[b]) for b in perm)))
+    best.sort(key=lambda r: (r[0], r[1]))
+    for b in best[:5]: print(b)
+
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "legacy":
+        legacy()
+        sys.exit(0)
     if len(sys.argv) < 2:
         xs = ('c0', 'c4', 'c2', 'c6')
         print("kernel layout, slot stride 576: phase 1 extra cycles per read", phase1(KERNEL, 576, xs),
