@@ -9,6 +9,8 @@
 #include <sys/stat.h>
 #include <thread>
 #include <zlib.h>
+#include <memory>
+#include "fast_inflate.h"
 
 namespace lzb_vio {
 
@@ -90,6 +92,37 @@ static void png_unfilter_paeth2(uint8_t *A, uint8_t *B, const uint8_t *P, size_t
     B[n - 1] = (uint8_t)(B[n - 1] + paeth_pred(aB, A[n - 1], A[n - 2]));
 }
 
+// FOUR consecutive Paeth rows at once, skewed by one pixel each (step t reconstructs R0[t], R1[t - 1], R2[t - 2], R3[t - 3]): four
+// independent dependency chains in flight instead of two -- the one-shot reader below has the whole filtered image in memory,
+// so it can look three rows ahead.  P = the reconstructed row above R0.
+static void png_unfilter_paeth4(uint8_t *R0, uint8_t *R1, uint8_t *R2, uint8_t *R3, const uint8_t *P, size_t n)
+{
+    uint8_t *rows[4] = {R0, R1, R2, R3};
+    auto px = [&](int r, size_t j) {
+        const uint8_t *up = r ? rows[r - 1] : P;
+        const int a = j ? rows[r][j - 1] : 0, b = up[j], c = j ? up[j - 1] : 0;
+        rows[r][j] = (uint8_t)(rows[r][j] + paeth_pred(a, b, c));
+    };
+    if (n < 8) {
+        for (int r = 0; r < 4; r++) for (size_t j = 0; j < n; j++) px(r, j);
+        return;
+    }
+    for (size_t t = 0; t < 4; t++)
+        for (int r = 0; r <= (int)t && r < 4; r++) px(r, t - (size_t)r);
+    int l0 = R0[3], p0 = R0[2], l1 = R1[2], p1 = R1[1], l2 = R2[1], p2 = R2[0], l3 = R3[0];
+    for (size_t t = 4; t < n; t++) {
+        const int n0 = R0[t] + paeth_pred(l0, P[t], P[t - 1]);
+        const int n1 = R1[t - 1] + paeth_pred(l1, l0, p0);
+        const int n2 = R2[t - 2] + paeth_pred(l2, l1, p1);
+        const int n3 = R3[t - 3] + paeth_pred(l3, l2, p2);
+        p0 = l0; p1 = l1; p2 = l2;
+        l0 = n0 & 0xFF; l1 = n1 & 0xFF; l2 = n2 & 0xFF; l3 = n3 & 0xFF;
+        R0[t] = (uint8_t)l0; R1[t - 1] = (uint8_t)l1; R2[t - 2] = (uint8_t)l2; R3[t - 3] = (uint8_t)l3;
+    }
+    for (size_t t = n; t < n + 3; t++)
+        for (int r = (int)(t - n) + 1; r < 4; r++) px(r, t - (size_t)r);
+}
+
 // PNG row filters (RFC 2083 section 6) undone in place: row = filtered bytes in, reconstructed bytes out;
 // prev = the reconstructed row above (all zero for the first row); bpp = bytes per pixel.  One loop per
 // filter type (the per-byte switch of the first version cost more than the inflate it followed).
@@ -148,6 +181,58 @@ static bool png_decode(const std::vector<uint8_t> &b, GetDst dst_for)
     uint8_t *out = dst_for(w, h, &pitch);
     if (!out || pitch < w) return false;
 
+    // ---- one shot (fast_inflate.h): the whole stream into a per-thread buffer, then the filters with up to four Paeth rows in
+    // flight.  It says yes only to a stream that decoded to exactly the image, ended with the input and matches its Adler-32;
+    // whatever it does not accept goes through zlib below, which stays the judge of what a corrupt file is.
+    {
+        static thread_local std::vector<uint8_t> zbuf, rawbuf;
+        static thread_local std::unique_ptr<finf::Tables> tabs;
+        const size_t raw_bytes = (stride + 1) * (size_t)h;
+        if (!tabs) tabs.reset(new finf::Tables);
+        if (zbuf.size() < idat_bytes + 16) zbuf.resize(idat_bytes + 16);
+        if (rawbuf.size() < raw_bytes + finf::kSlack) rawbuf.resize(raw_bytes + finf::kSlack);
+        size_t zp = 0;
+        for (const auto &c : idat) { memcpy(zbuf.data() + zp, &b[c.first], c.second); zp += c.second; }
+        memset(zbuf.data() + zp, 0, 16);
+        if (!getenv("LZB_VIO_PNG_ZLIB") && finf::inflate_zlib(zbuf.data(), idat_bytes, rawbuf.data(), raw_bytes, *tabs)) {
+            std::vector<uint8_t> zero(stride, 0);
+            const uint8_t *prev = zero.data();
+            uint8_t *raw = rawbuf.data();
+            for (int y = 0; y < h; y++) {
+                uint8_t *src = raw + (stride + 1) * (size_t)y;
+                uint8_t *d = out + (size_t)y * pitch;
+                const int ft = src[0];
+                if (ch == 1) {
+                    memcpy(d, src + 1, stride);
+                    int run = 1;                              // consecutive Paeth rows from here (at most four)
+                    if (ft == 4) while (run < 4 && y + run < h && src[(stride + 1) * (size_t)run] == 4) run++;
+                    if (ft == 4 && run == 4) {
+                        for (int r = 1; r < 4; r++) memcpy(d + (size_t)r * pitch, src + (stride + 1) * (size_t)r + 1, stride);
+                        png_unfilter_paeth4(d, d + pitch, d + 2 * (size_t)pitch, d + 3 * (size_t)pitch, prev, stride);
+                        y += 3;
+                        prev = d + 3 * (size_t)pitch;
+                    } else if (ft == 4 && run >= 2) {
+                        memcpy(d + pitch, src + stride + 2, stride);
+                        png_unfilter_paeth2(d, d + pitch, prev, stride);
+                        y += 1;
+                        prev = d + pitch;
+                    } else {
+                        if (!png_unfilter_row(ft, d, prev, stride, 1)) return false;
+                        prev = d;
+                    }
+                } else {
+                    if (!png_unfilter_row(ft, src + 1, prev, stride, (size_t)ch)) return false;
+                    if (ch == 2) for (int x = 0; x < w; x++) d[x] = src[1 + (size_t)x * 2];
+                    else for (int x = 0; x < w; x++) {
+                        const uint8_t *q = src + 1 + (size_t)x * ch;
+                        d[x] = (uint8_t)((q[0] * 4899 + q[1] * 9617 + q[2] * 1868 + 8192) >> 14);
+                    }
+                    prev = src + 1;                          // the whole filtered image is in memory: the row above stays where it is
+                }
+            }
+            return true;
+        }
+    }
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (inflateInit(&zs) != Z_OK) return false;

@@ -144,10 +144,26 @@ def test_png_reader_stream_shapes(host_built, tmp_path):
     Image.fromarray(big).save(tmp_path / "big.png", compress_level=3)           # several 64 KB IDAT chunks
     files.append(str(tmp_path / "big.png")); want.append(big)
     _write_yaml(tmp_path / "cfg.yaml", "/data/kitti/00")
-    out = subprocess.check_output([os.path.join(host_built, "host_selftest"), str(tmp_path / "cfg.yaml")] + files,
-                                  stderr=subprocess.DEVNULL).decode()
-    for i, im in enumerate(want):
-        assert f"image{i + 1} ok=1 rows={im.shape[0]} cols={im.shape[1]} hash={_hash(im)}" in out, files[i]
+    # the one-shot decoder (fast_inflate.h + four Paeth rows in flight) and the zlib path behind it: the same pixels
+    for env in ({}, {"LZB_VIO_PNG_ZLIB": "1"}):
+        out = subprocess.check_output([os.path.join(host_built, "host_selftest"), str(tmp_path / "cfg.yaml")] + files,
+                                      stderr=subprocess.DEVNULL, env=dict(os.environ, **env)).decode()
+        for i, im in enumerate(want):
+            assert f"image{i + 1} ok=1 rows={im.shape[0]} cols={im.shape[1]} hash={_hash(im)}" in out, (files[i], env)
+
+
+def test_fast_inflate_fuzz(tmp_path):
+    """host/src/fast_inflate.h (the PNG reader's one-shot inflate, written from RFC 1950 / 1951) against zlib under ASan + UBSan:
+    600 random streams of every level / strategy / window size round-trip exactly; bit flips, truncation and wrong sizes are
+    never accepted with wrong bytes (the reader falls back to zlib on a refusal)."""
+    host = os.path.join(conftest.ROOT, "stereo-visual-odometry_amd", "host")
+    exe = tmp_path / "fuzz"
+    subprocess.check_call(["g++", "-O2", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", os.path.join(host, "src"),
+                           os.path.join(host, "tests_host", "fast_inflate_fuzz.cpp"), "-lz", "-o", str(exe)])
+    r = subprocess.run([str(exe), "600"], capture_output=True, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-2000:] + r.stderr.decode()[-2000:]
+    assert "round trips ok 600 / 600" in out and "MISMATCH" not in out and "ACCEPTED" not in out, out[-2000:]
 
 
 def _png_bytes(img, payload_edit=None, rows_in_stream=None):
