@@ -975,6 +975,11 @@ def main():
         if not args.no_legs:
             out["stream"] = stream_leg(pkg, importlib.import_module(entry.PKG_NAME + ".stream"), L, R, W, H, P1, P2,
                                        {k: v for k, v in mode_kw.items()})
+            if args.mode == "lk" and args.lk_accum == "exact":
+                # the same stream with the LK sums in an x86 float order (round 5: the pose stage's last launch could starve behind
+                # lk_sse2_kernel's single-wave workgroups; the stream's latency would have shown it)
+                out["stream_sse2"] = stream_leg(pkg, importlib.import_module(entry.PKG_NAME + ".stream"), L, R, W, H, P1, P2,
+                                                dict(mode_kw, lk_accum=pkg.LK_ACCUM_SSE2), depths=(2, 8, 32))
         # ---- legs on their own contexts (N = 1): the other BASELINE configs and the x86-order LK mode ----------------
         if not args.no_legs:
             O = None

@@ -43,6 +43,8 @@ def test_default_line_carries_the_legs_and_a_green_self_check():
     assert sorted(int(k) for k in st["depths"]) == [1, 2, 4, 8, 16, 32]
     assert all(d["pairs_per_s"] > 0 and d["pairs_ok"] >= d["frames"] - 2 and d["latency_ms_median"] > 0 for d in st["depths"].values())
     assert st["depths"]["8"]["pairs_per_s"] > st["depths"]["1"]["pairs_per_s"]          # depth buys throughput
+    assert sorted(int(k) for k in out["stream_sse2"]["depths"]) == [2, 8, 32]
+    assert all(d["pairs_ok"] >= d["frames"] - 2 and d["latency_ms_median"] > 0 for d in out["stream_sse2"]["depths"].values())
 
 
 def test_self_check_mismatch_exits_non_zero():
