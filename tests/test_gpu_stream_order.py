@@ -111,6 +111,20 @@ def test_carry_frame_needs_a_valid_previous_async_batch(pkg, synth):
     c.track_uploaded_async(1, 3, continue_chain=True, carry_frame=True)      # the valid case
     r1 = c.collect_results(2)
     assert int(r0["ok"].sum()) == 2 and int(r1["ok"].sum()) == 2
+    # a buffer uploaded FROM SLOT 1 (svo_upload_frames_at: frame 0 is to be carried on the device) holds stale pixels in slot 0:
+    # only a launch that carries the previous batch's last frame may read it -- the synchronous entry and a chained launch
+    # without CARRY are refused, and so is a first_slot beyond 1
+    c.upload_frames(0, hl[1:3], hr[1:3], first_slot=1)
+    c.wait_upload(0)
+    with pytest.raises(pkg.SvoError):
+        c.track_uploaded(0, 3)
+    with pytest.raises(pkg.SvoError):
+        c.track_uploaded_async(0, 3, continue_chain=True)
+    with pytest.raises(pkg.SvoError):
+        c.upload_frames(0, hl[2:3], hr[2:3], first_slot=2)
+    c.track_uploaded_async(0, 3, continue_chain=True, carry_frame=True)      # ... and the launch it is meant for is accepted
+    r2 = c.collect_results(2)
+    assert int(r2["ok"].sum()) == 2
     c.add_frame(*fr[0])                                      # the online ring overwrites frame slots 0 / 1
     put(0, 2)
     with pytest.raises(pkg.SvoError):
