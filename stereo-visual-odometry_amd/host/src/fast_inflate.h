@@ -22,7 +22,7 @@
 namespace lzb_vio {
 namespace finf {
 
-constexpr int kSlack = 320;                         // a match may be written up to 258 + 7 bytes past a full buffer before it is refused
+constexpr int kSlack = 320;                         // three literals, or a match's last 16-byte store, may land past a full buffer before it is refused
 constexpr int kLitRoot = 11, kDistRoot = 8;
 constexpr int kLitCap = 2048 + 2048, kDistCap = 256 + 1024;
 constexpr uint32_t OP_LIT = 0, OP_BASE = 16, OP_EOB = 64, OP_PTR = 96, OP_BAD = 128;
@@ -253,30 +253,48 @@ static inline bool inflate_zlib(const uint8_t *in, size_t in_size, uint8_t *out,
             if (lens[256] == 0) return false;
             if (!build_table(lens, hlit, T.lit, kLitRoot, kLitCap, false) || !build_table(lens + hlit, hdist, T.dist, kDistRoot, kDistCap, true)) return false;
         }
-        // ---- the symbols of the block
+        // ---- the symbols of the block.  `e` is always the table entry for the bits at the head of the buffer, looked up as
+        // early as possible: a refill only adds bits ABOVE the ones it holds, so the entry stays valid across it, and the
+        // lookup for the next symbol is issued before a literal is stored or a match is copied (its latency hides there).
         const uint32_t *const lit = T.lit, *const dtab = T.dist;
+        FINF_REFILL();
+        uint32_t e = lit[FINF_BITS(kLitRoot)];
         for (;;) {
             if (ip > in_end + 8 || op > out_end) return false;
-            FINF_REFILL();
-            uint32_t e = lit[FINF_BITS(kLitRoot)];
-            if (((e >> 8) & 0xFF) == OP_LIT) {       // up to three literals per refill: 3 x 11 bits
-                FINF_DROP(e & 0xFF); *op++ = (uint8_t)(e >> 16);
+            uint32_t opc = (e >> 8) & 0xFF;
+            if (opc == OP_LIT) {                     // up to three literals per refill: 3 x 11 of at least 56 bits
+                FINF_DROP(e & 0xFF);
+                uint8_t v = (uint8_t)(e >> 16);
                 e = lit[FINF_BITS(kLitRoot)];
+                *op++ = v;
                 if (((e >> 8) & 0xFF) == OP_LIT) {
-                    FINF_DROP(e & 0xFF); *op++ = (uint8_t)(e >> 16);
+                    FINF_DROP(e & 0xFF);
+                    v = (uint8_t)(e >> 16);
                     e = lit[FINF_BITS(kLitRoot)];
+                    *op++ = v;
                     if (((e >> 8) & 0xFF) == OP_LIT) {
-                        FINF_DROP(e & 0xFF); *op++ = (uint8_t)(e >> 16);
-                        continue;
+                        FINF_DROP(e & 0xFF);
+                        v = (uint8_t)(e >> 16);
+                        e = lit[FINF_BITS(kLitRoot)];
+                        *op++ = v;
                     }
                 }
+                FINF_REFILL();
+                continue;
             }
-            uint32_t opc = (e >> 8) & 0xFF;
+            // at least 56 bits here (every path to this point ends with a refill): pointer 11 + subtable 4 + length extra 5 +
+            // distance 8 + 7 + 13 = 48
             if (opc == OP_PTR) {
                 FINF_DROP(kLitRoot);
                 e = lit[(e >> 16) + FINF_BITS(e & 0xFF)];
                 opc = (e >> 8) & 0xFF;
-                if (opc == OP_LIT) { FINF_DROP(e & 0xFF); *op++ = (uint8_t)(e >> 16); continue; }
+                if (opc == OP_LIT) {
+                    FINF_DROP(e & 0xFF);
+                    *op++ = (uint8_t)(e >> 16);
+                    FINF_REFILL();
+                    e = lit[FINF_BITS(kLitRoot)];
+                    continue;
+                }
             }
             if (opc == OP_EOB) { FINF_DROP(e & 0xFF); break; }
             if (opc >= OP_EOB || opc < OP_BASE) return false;      // OP_BAD (or a pointer inside a subtable: never built)
@@ -284,7 +302,6 @@ static inline bool inflate_zlib(const uint8_t *in, size_t in_size, uint8_t *out,
             const uint32_t lx = opc - OP_BASE;
             const uint32_t len = (e >> 16) + FINF_BITS(lx);
             FINF_DROP(lx);
-            FINF_REFILL();
             uint32_t d = dtab[FINF_BITS(kDistRoot)];
             uint32_t dop = (d >> 8) & 0xFF;
             if (dop == OP_PTR) {
@@ -297,10 +314,18 @@ static inline bool inflate_zlib(const uint8_t *in, size_t in_size, uint8_t *out,
             const uint32_t dx = dop - OP_BASE;
             const uint32_t dist = (d >> 16) + FINF_BITS(dx);
             FINF_DROP(dx);
+            FINF_REFILL();
+            e = lit[FINF_BITS(kLitRoot)];            // the next symbol's entry, before the copy
             if (dist > (size_t)(op - out) || op + len > out_end) return false;
             const uint8_t *s = op - dist;
             uint8_t *t = op, *const te = op + len;
-            if (dist >= 8) {
+            if (dist >= 16) {
+#if defined(__SSE2__)
+                do { _mm_storeu_si128((__m128i *)t, _mm_loadu_si128((const __m128i *)s)); t += 16; s += 16; } while (t < te);
+#else
+                do { store64(t, load64(s)); store64(t + 8, load64(s + 8)); t += 16; s += 16; } while (t < te);
+#endif
+            } else if (dist >= 8) {
                 do { store64(t, load64(s)); t += 8; s += 8; } while (t < te);
             } else if (dist == 1) {
                 const uint64_t v = 0x0101010101010101ull * s[0];
