@@ -1085,9 +1085,27 @@ static void launch_pnp_pipeline(svo_ctx *ctx, PnpArgs a, int n_items, int max_pt
     hipLaunchKernelGGL(pnp_refit_kernel, dim3(n_items), dim3(kRefitThreads), kRefitLdsBytes, st, a);
 }
 
-void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const float2 *x1, const float2 *x2,
-                              const int *n_pts, int n_fixed, const SnapSpec *snap)
+// The count snapshot alone (the part of pnp_begin that must run in FRONT-END order: the next batch's FAST overwrites the live
+// counts): for a triangulation launched on the side stream.
+__global__ __launch_bounds__(256) void snap_counts_kernel(SnapArgs q)
 {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= q.n_pairs) return;
+    const int sp = q.per * (q.fp0 + b * q.fstep), sc = q.per * (q.fc0 + b * q.fstep);
+    q.snap[b] = q.n[sp];
+    q.snap[q.n_pairs + b] = q.n[sc];
+    if (q.ovf) q.snap[2 * q.n_pairs + b] = q.per == 2 ? (q.ovf[sp] | q.ovf[sp + 1] | q.ovf[sc] | q.ovf[sc + 1]) : (q.ovf[sp] | q.ovf[sc]);
+}
+void launch_snap_counts(svo_ctx *ctx, int n_items, const SnapSpec &snap, hipStream_t st)
+{
+    const SnapArgs q{snap.n, snap.ovf, snap.fp0, snap.fc0, snap.fstep, snap.per, n_items, ctx->kp_n_snap};
+    hipLaunchKernelGGL(snap_counts_kernel, dim3((n_items + 255) / 256), dim3(256), 0, st, q);
+}
+
+void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const float2 *x1, const float2 *x2,
+                              const int *n_pts, int n_fixed, const SnapSpec *snap, hipStream_t st)
+{
+    if (!st) st = ctx->stream;
     TriArgs a{};
     memcpy(a.P1, ctx->cfg.P1, sizeof(a.P1));
     memcpy(a.P2, ctx->cfg.P2, sizeof(a.P2));
@@ -1108,7 +1126,7 @@ void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const floa
     a.begin.first_cap = pnp_first_cap(ctx->cfg);
     a.begin.stream = (const uint64_t *)(ws + ws_off_stream(ctx->cfg, B));
     if (snap) a.begin.snap = SnapArgs{snap->n, snap->ovf, snap->fp0, snap->fc0, snap->fstep, snap->per, n_items, ctx->kp_n_snap};
-    hipLaunchKernelGGL(triangulate_kernel, dim3(gx + 1, n_items), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(triangulate_kernel, dim3(gx + 1, n_items), dim3(64), 0, st, a);
 }
 
 void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n_pts, int n_fixed, hipStream_t st)

@@ -67,7 +67,7 @@ static int ingest_frames(svo_ctx *ctx, const uint8_t *L, const uint8_t *R, int p
     return SVO_OK;
 }
 
-static int run_back(svo_ctx *ctx, int n_pairs, const double *pose0_host, svo_step_result *results_dev);
+static int run_back(svo_ctx *ctx, int n_pairs, const double *pose0_host, svo_step_result *results_dev, bool triangulate_first = false);
 
 // A micro-batch of a stream starts with the frame the previous one ended with: instead of building that frame's
 // pyramids and detecting its features again, what the pair needs of it is carried from frame slot `last` to slot 0
@@ -168,6 +168,15 @@ static int run_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, con
     // of the frames involved for the pose stage (FAST of the next batch overwrites kp_n): snap[p] = n_prev of pair p,
     // snap[n_pairs + p] = n_cur of pair p
     const SnapSpec snap{ctx->kp_n, nullptr, fp0, fc0, fstep, 1};
+    // Overlap mode: the triangulation belongs to the pose stage (nothing of the front end reads its points), so it goes to the
+    // side stream with it -- 0.14 ms per 256 pairs, 50 us of a micro-batch's front-end chain --; only the count snapshot stays in
+    // front-end order (SVO_TRI_SIDE=0: the round-5 order, for A/B runs)
+    static const bool tri_side = !(getenv("SVO_TRI_SIDE") && getenv("SVO_TRI_SIDE")[0] == '0');
+    if (tri_side && ctx->overlap && results_dev != nullptr) {
+        launch_snap_counts(ctx, n_pairs, snap, ctx->stream);
+        mark(ctx, kTTri);
+        return run_back(ctx, n_pairs, pose0_host, results_dev, /*triangulate_first*/ true);
+    }
     launch_triangulate_batch(ctx, n_pairs, cap, ctx->cmp[0], ctx->cmp[1], ctx->m_out, 0, &snap);
     mark(ctx, kTTri);
     return run_back(ctx, n_pairs, pose0_host, results_dev);
@@ -175,7 +184,7 @@ static int run_pairs(svo_ctx *ctx, int n_pairs, int fp0, int fc0, int fstep, con
 
 // Pose stage: solvePnPRansac(X, t2_left) (:299 / :200), gates, frame_pose_ chain, optional copy of the
 // records; on the side stream in overlap mode.
-static int run_back(svo_ctx *ctx, int n_pairs, const double *pose0_host, svo_step_result *results_dev)
+static int run_back(svo_ctx *ctx, int n_pairs, const double *pose0_host, svo_step_result *results_dev, bool triangulate_first)
 {
     hipStream_t bs = ctx->stream;
     const bool side = ctx->overlap && results_dev != nullptr;
@@ -184,6 +193,8 @@ static int run_back(svo_ctx *ctx, int n_pairs, const double *pose0_host, svo_ste
         SVO_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_front, 0));
         bs = ctx->side_stream;
     }
+    if (triangulate_first)       // LK mode, overlap: triangulatePoints + the RANSAC start-up of every pair, on the pose stage's stream
+        launch_triangulate_batch(ctx, n_pairs, ctx->cfg.max_keypoints, ctx->cmp[0], ctx->cmp[1], ctx->m_out, 0, nullptr, bs);
     launch_pnp_batch(ctx, n_pairs, ctx->cmp[3], ctx->m_out, 0, bs);
     if (!side) mark(ctx, kTPnp);
     launch_finalize_chain(ctx, n_pairs, ctx->kp_n_snap, ctx->kp_n_snap + n_pairs,

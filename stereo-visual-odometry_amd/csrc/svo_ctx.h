@@ -142,7 +142,8 @@ int geom_workspace_init(svo_ctx *ctx);
 // snap: the frames' keypoint counts / capacity flags to freeze into ctx->kp_n_snap beside the triangulation (null: none)
 struct SnapSpec { const int *n, *ovf; int fp0, fc0, fstep, per; };
 void launch_triangulate_batch(svo_ctx *ctx, int n_items, int max_pts, const float2 *x1, const float2 *x2,
-                              const int *n_pts, int n_fixed, const SnapSpec *snap = nullptr);
+                              const int *n_pts, int n_fixed, const SnapSpec *snap = nullptr, hipStream_t st = nullptr);   // st null: the context's stream
+void launch_snap_counts(svo_ctx *ctx, int n_items, const SnapSpec &snap, hipStream_t st);
 void launch_pnp_batch(svo_ctx *ctx, int n_items, const float2 *img, const int *n_pts, int n_fixed, hipStream_t st);
 // orb.hip
 int orb_alloc(svo_ctx *ctx);
