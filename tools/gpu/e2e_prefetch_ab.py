@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""run_kitti_stereo on an n-frame S0 sequence from PNG and PGM files, decode-ahead on / off (LZB_VIO_PREFETCH), best of 3 each.
+"""run_kitti_stereo on an n-frame S0 sequence from PNG and PGM files, best of 3, alternating an environment switch of the
+runner -- written for round 6's decode-ahead experiment (LZB_VIO_PREFETCH = 1 / 0 in that build; dropped, DESIGN.md section 6:
+the shipped runner ignores the variable, so the script now simply measures the whole-process time four times per format).
 usage: e2e_prefetch_ab.py [n=4541]"""
 import importlib, os, shutil, subprocess, sys, tempfile, time
 from concurrent.futures import ThreadPoolExecutor
