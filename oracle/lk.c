@@ -162,7 +162,11 @@ void orc_lk_set_iter_log(int32_t *log) { g_iter_log = log; }
  *   k = 7  as k = 0 with the positive sums taken from the terms' high halves only (t >> 16, one unit of slack a term: what a
  *          packed 16-bit reduction on the GPU can afford) */
 static uint32_t *g_guard_log = NULL;
-void orc_lk_set_guard_log(uint32_t *log) { g_guard_log = log; }
+/* ... and the claim itself, checked where it is cheap: iterations in which the guard of the current float mode held for all ten
+ * chains but a chain's FLOAT total (before the final six adds) differed from its integer total.  Must stay 0. */
+static long g_guard_violations = 0, g_guard_checked = 0;
+void orc_lk_set_guard_log(uint32_t *log) { g_guard_log = log; if (log) { g_guard_violations = 0; g_guard_checked = 0; } }
+long orc_lk_guard_violations(long *checked) { if (checked) *checked = g_guard_checked; return g_guard_violations; }
 
 /* 0 exact int64 (CANONICAL); float accumulation: 1 raster order (the scalar loop), 2 the round-4 restatement (A: four
  * lanes over x = 0..19, b: madd pairs over x = 0..15 -- the parity target of lk_sse2_kernel), and the two upstream SIMD
@@ -338,6 +342,30 @@ static void lk_point_level(const uint8_t *I, int pitchI, const int16_t *dI, int 
                             q[(k & 1) * 2 + 1] += (float)sy;
                         }
                     }
+                }
+            }
+        }
+        if (g_guard_log && accum >= 2) {
+            /* chain c = 2 k + xy: k = 0, 1 ride qb0[2 k + xy], k = 2, 3 qb1[2 (k - 2) + xy]; the tails are fb1 / fb2 before the final adds */
+            int c, held = 1, bad = 0;
+            int64_t (*g)[2] = accum == 3 ? gprod : gpair;
+            for (c = 0; c < 10; c++) if (g[c][0] >= (1 << 24) || g[c][1] >= (1 << 24)) held = 0;
+            if (held) {
+                for (c = 0; c < 8; c++) {
+                    const int k = c >> 1, xy = c & 1;
+                    const float f = k < 2 ? qb0[2 * k + xy] : qb1[2 * (k - 2) + xy];
+                    if (f != (float)(g[c][0] - g[c][1])) bad = 1;
+                }
+                if (fb1 != (float)(g[8][0] - g[8][1]) || fb2 != (float)(g[9][0] - g[9][1])) bad = 1;
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+                g_guard_checked++;
+                if (bad) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+                    g_guard_violations++;
                 }
             }
         }

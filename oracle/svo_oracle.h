@@ -75,6 +75,7 @@ enum { ORC_COMPAT_TRIANGULATE = 0,   /* 0: 4 x 4 system (3.4); 1: 6 x 4 system w
 void orc_set_opencv_compat(int knob, int value);
 int orc_get_opencv_compat(int knob);
 void orc_lk_set_guard_log(uint32_t *log);   /* tools only: exactness masks per (point, level), see oracle/lk.c */
+long orc_lk_guard_violations(long *checked); /* iterations whose guard held but a float chain total != its integer total (must be 0) */
 void orc_lk_set_iter_log(int32_t *log);      /* tools only: iterations per (point, level) of the next orc_lk_track calls */
 int orc_lk_track(const orc_pyramid *prev, const orc_pyramid *next,
                  const orc_pt2f *prev_pts, int n, orc_pt2f *next_pts, uint8_t *status,

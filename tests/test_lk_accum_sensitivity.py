@@ -100,3 +100,36 @@ def test_lk_accumulation_order_sensitivity_100_pairs(pkg, oracle, synth):
     with open(os.path.join(conftest.ROOT, "gpurun_out", "r03_lk_accum_sensitivity.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))
+
+
+def test_float_chains_are_exact_when_the_order_free_guard_holds(oracle, synth):
+    """The claim behind round 6's (closed) integer fast path for lk_sse2_kernel, profiles/r06_lk_sse2_chain_bound.json: when for
+    every one of the ten b chains max(sum of positive terms, sum of |negative terms|) < 2^24, every float add of the chain is
+    exact in ANY order, so each chain's float total is its integer total.  Checked inside the oracle on every iteration of two
+    circular-LK steps, in all three restated float orders; the guard must hold often enough to mean something."""
+    import ctypes as C
+    lib = oracle.lib()
+    lib.orc_lk_set_guard_log.argtypes = [C.c_void_p]
+    lib.orc_lk_guard_violations.restype = C.c_long
+    lib.orc_lk_guard_violations.argtypes = [C.POINTER(C.c_long)]
+    seq = synth.StereoSequence(width=416, height=128, n_frames=3, seed=7)
+    fr = [tuple(x.numpy() for x in seq.render(t)) for t in range(3)]
+    try:
+        for mode in (2, 3, 4):
+            oracle.set_lk_accum(mode)
+            kp = oracle.fast(fr[0][0])
+            pts = np.stack([kp["x"], kp["y"]], 1).astype(np.float32)
+            log = np.zeros((len(pts), 8, 8), np.uint32)
+            lib.orc_lk_set_guard_log(log.ctypes.data_as(C.c_void_p))
+            ran = 0
+            for a, b in ((fr[0][0], fr[0][1]), (fr[0][1], fr[1][1]), (fr[1][1], fr[1][0]), (fr[1][0], fr[0][0])):
+                oracle.lk_track(a, b, pts, threads=1)       # (the masks are rewritten by every call; the two counters add up)
+                ran += int(np.unpackbits(np.ascontiguousarray(log[:, :, 3]).view(np.uint8)).sum())
+            checked = C.c_long(0)
+            viol = lib.orc_lk_guard_violations(C.byref(checked))
+            lib.orc_lk_set_guard_log(None)
+            assert viol == 0, (mode, viol)
+            assert checked.value > 0.3 * ran > 0, (mode, checked.value, ran)
+    finally:
+        lib.orc_lk_set_guard_log(None)
+        oracle.set_lk_accum(0)
