@@ -1141,9 +1141,13 @@ def main():
                     fl, fr = seq_full.render_range(t0, t1)
                     return fl.cpu().numpy(), fr.cpu().numpy()
 
-                out["e2e_full"] = e2e_leg(args, args.e2e_full_frames, rendered, P1, W)
-                out["e2e_full"]["definition"] = ("BASELINE config #2 as worded (full sequence: KITTI-00's 4541 frames, single stream, image files): " +
-                                                 out["e2e_full"]["definition"])
+                try:                                         # set-up heavy (9 082 files): a full disk must not cost the whole line
+                    out["e2e_full"] = e2e_leg(args, args.e2e_full_frames, rendered, P1, W)
+                except Exception as exc:                     # noqa: BLE001
+                    out["e2e_full"] = {"error": f"{type(exc).__name__}: {exc}"}
+                if "definition" in out["e2e_full"]:
+                    out["e2e_full"]["definition"] = ("BASELINE config #2 as worded (full sequence: KITTI-00's 4541 frames, single stream, image files): " +
+                                                     out["e2e_full"]["definition"])
         # the same workload in the float orders an x86 OpenCV 3 can run (whichever the reference's build has): the slowest of the three
         x86 = {k: out[k]["value"] for k in ("lk_accum_sse2", "lk_accum_simd128", "lk_accum_sse2_legacy") if isinstance(out.get(k), dict)}
         if x86:
