@@ -259,6 +259,17 @@ constexpr int kCellCap = 256;                // candidates kept per cell
 // loops' nearly empty last passes cost less than the occupancy smaller workgroups lose)
 constexpr int kCellThreads = 256;
 static_assert(kCellPitch * kCellMax < (1 << 14), "a window position and a 2-bit cell number share 16 bits");
+// The workgroup's dynamic LDS, carved per level: pixel plane + cornerness plane (kCellPitch x (hCell + 6) bytes each), the
+// survivor / candidate list (one 16-bit entry per TESTED pixel: the window without its 3-pixel rim), the keypoint list and one
+// scratch entry.  Round 6: the lists were three planes' worth (31.3 KB for KITTI's tallest cells: five workgroups per CU); sized
+// by what they can hold, 26.4 KB: six.
+__host__ __device__ constexpr int cellfast_plane(int hCell) { return (kCellPitch * (hCell + 6) + 15) & ~15; }
+__host__ __device__ constexpr int cellfast_listcap(int hCell) { return hCell * (kCellPitch - 6); }
+__host__ __device__ constexpr int cellfast_klistcap(int hCell) { return (kCellPitch / 2 + 4) * ((hCell + 6) / 2 + 1); }
+__host__ __device__ constexpr size_t cellfast_lds_bytes(int hCell)
+{
+    return (size_t)2 * cellfast_plane(hCell) + 2 * (size_t)(cellfast_listcap(hCell) + cellfast_klistcap(hCell) + 1) + 14;
+}
 
 // FAST cornerness V = largest t for which the pixel is a FAST-9/16 corner (0 when < 1):
 // corner at threshold t <=> V >= t, and cornerScore == V.
@@ -306,23 +317,25 @@ __device__ __forceinline__ int fast_cornerness(const uint8_t *c, int P)
 #endif
 __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, const uint8_t *slots, int64_t slot_stride,
                                                            int iniTh, int minTh, float4 *cell_cand, int *cell_cnt,
-                                                           int64_t cand_img_stride, int64_t cnt_img_stride, int n_img, OrbL0 z)
+                                                           int64_t cand_img_stride, int64_t cnt_img_stride, int n_img, OrbL0 z,
+                                                           int blk_lo, int blk_n)       // this launch: workgroups blk_lo .. blk_lo + blk_n - 1 of every image
 {
 #ifdef SVO_CF_STAMP
     uint32_t cf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cf_last = 0;
     CF_AT(7) cf_acc[7] = 0;
 #endif
     int b, blk_all;                                                       // image, workgroup index over all levels
-    xcd_image_block(blockIdx.x, g.blks_total, n_img, b, blk_all);
+    xcd_image_block(blockIdx.x, blk_n, n_img, b, blk_all);
+    blk_all += blk_lo;
     const int l = level_of_block(g.blk_off, g.nlevels, blk_all);
     // dynamic LDS: two byte planes (pixels, cornerness) + the position lists (three planes' worth), kCellPitch
     // columns x (hCell + 6) rows of THIS level
     extern __shared__ __attribute__((aligned(16))) uint8_t cf_smem[];
-    const int plane = (kCellPitch * (g.hCell[l] + 6) + 15) & ~15;
+    const int plane = cellfast_plane(g.hCell[l]);
     uint8_t *raw = cf_smem, *V = cf_smem + plane;
-    uint16_t *list = (uint16_t *)(cf_smem + 2 * plane);      // survivors of the test, then candidates (compacted in place)
-    uint16_t *klist = list + plane;                          // keypoints after the NMS, in any order: position | cell << 14 (at most a
-                                                             // quarter of the window's pixels: a fifth plane of bytes holds plane / 2 of them)
+    uint16_t *list = (uint16_t *)(cf_smem + 2 * plane);      // survivors of the test, then candidates (compacted in place): every TESTED pixel can survive
+    uint16_t *klist = list + cellfast_listcap(g.hCell[l]);   // keypoints after the NMS, in any order: position | cell << 14 (strict 3 x 3 suppression
+                                                             // inside a cell: at most every other pixel of every other row of each cell)
     __shared__ int s_any[kCellGroup], s_nkept[kCellGroup], s_nlist, s_ncand, s_nk;
     const int blk = blk_all - g.blk_off[l];
     const bool in_place = l == 0 && z.img != nullptr;                     // level 0 = the input image itself
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(kCellThreads) void orb_cellfast_kernel(OrbGeom g, c
                 int base = 0;
                 if (lane == 63) base = atomicAdd(&s_nlist, total);
                 int at = __builtin_amdgcn_readlane(base, 63) + incl - mine;
-                uint16_t *scratch = klist + plane / 2;
+                uint16_t *scratch = klist + cellfast_klistcap(g.hCell[l]);
                 for (int st = 0; st < step; st++) {
                     const uint32_t m4 = (uint32_t)(alive >> (4 * st)) & 15u;
                     const int pos = (3 + tRow + st * tR) * kCellPitch + tXb;
@@ -2410,10 +2423,35 @@ int orb_extract_batch(svo_ctx *ctx, const uint8_t *img, const uint8_t *img2, int
     {
         int hmax = 0;
         for (int l = 0; l < L; l++) if (g.ncell[l] > 0 && g.hCell[l] > hmax) hmax = g.hCell[l];
-        if (g.blks_total > 0)
-            hipLaunchKernelGGL(orb_cellfast_kernel, dim3(g.blks_total * n_img), dim3(kCellThreads), (size_t)5 * ((kCellPitch * (hmax + 6) + 15) & ~15) + 16, st,
+        // The dynamic LDS of a launch is sized by its tallest cells, and the size sets how many workgroups a CU holds (the
+        // kernel is issue-bound: 5 -> 6 workgroups per CU took 12 % off it).  A batch therefore launches runs of consecutive levels
+        // that reach the same number of workgroups per CU separately -- KITTI: levels 0-3 and 6 (cells of 31-33 rows, 22 KB) at
+        // seven per CU, levels 4, 5, 7 (37-40 rows, 26 KB) at six --; a launch of a few images stays one launch (latency).
+        // (SVO_ORB_CF_LDS5=1: the round-5 allocation of five planes -- same carve-up, five workgroups per CU --, =2: one launch
+        // sized by the tallest cells, for A/B runs)
+        static const int lds_mode = getenv("SVO_ORB_CF_LDS5") ? atoi(getenv("SVO_ORB_CF_LDS5")) : 0;
+        auto per_cu = [](size_t bytes) { return (int)((size_t)160 * 1024 / (((bytes + 64) + 1023) & ~(size_t)1023)); };
+        const size_t cf_all = lds_mode == 1 ? (size_t)5 * cellfast_plane(hmax) + 16 : cellfast_lds_bytes(hmax);
+        if (g.blks_total > 0 && (lds_mode != 0 || n_img < 16)) {
+            hipLaunchKernelGGL(orb_cellfast_kernel, dim3(g.blks_total * n_img), dim3(kCellThreads), cf_all, st,
                                g, slots, g.slot_bytes, ctx->cfg.orb_ini_th, ctx->cfg.orb_min_th, cell_cand, cell_cnt,
-                               (int64_t)g.cells_total * kCellCap, (int64_t)g.cells_total, n_img, z);
+                               (int64_t)g.cells_total * kCellCap, (int64_t)g.cells_total, n_img, z, 0, g.blks_total);
+        } else if (g.blks_total > 0) {
+            for (int l0 = 0; l0 < L;) {
+                int l1 = l0, hrun = 0;
+                const int cls = per_cu(cellfast_lds_bytes(g.hCell[l0]));
+                while (l1 < L && (g.ncell[l1] == 0 || per_cu(cellfast_lds_bytes(g.hCell[l1])) == cls)) {
+                    if (g.ncell[l1] > 0 && g.hCell[l1] > hrun) hrun = g.hCell[l1];
+                    l1++;
+                }
+                const int lo = g.blk_off[l0], hi = l1 < L ? g.blk_off[l1] : g.blks_total;
+                if (hi > lo)
+                    hipLaunchKernelGGL(orb_cellfast_kernel, dim3((hi - lo) * n_img), dim3(kCellThreads), cellfast_lds_bytes(hrun), st,
+                                       g, slots, g.slot_bytes, ctx->cfg.orb_ini_th, ctx->cfg.orb_min_th, cell_cand, cell_cnt,
+                                       (int64_t)g.cells_total * kCellCap, (int64_t)g.cells_total, n_img, z, lo, hi - lo);
+                l0 = l1;
+            }
+        }
     }
     float4 *lvl_cand = ctx->orb_lvl_cand + (size_t)slot0 * L * kCandCap;
     int *lvl_cnt = ctx->orb_lvl_cnt + (size_t)slot0 * L;
