@@ -222,7 +222,7 @@ def roofline_orb(stage_ms, B, w, h):
     alg_bytes = int(3.09 * w * h * 2 * (B + 1))
     achieved = alg_bytes / (cf_ms * 1e-3) / 1e9
     oprof = newest_profile("orb", orb_source_hash()) if B == 256 else None      # only a profile of THESE kernel sources
-    return {"bound": "hbm", "kernel": "orb_cellfast_kernel (one launch per step over all pyramid levels)",
+    return {"bound": "hbm", "kernel": "orb_cellfast_kernel (a step's launches together: one per run of pyramid levels of one LDS-occupancy class)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": (oprof or {}).get("cellfast_traffic_bytes"), "profile": (oprof or {}).get("_file"),
             "launch_ms": round(cf_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
