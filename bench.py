@@ -986,7 +986,9 @@ def main():
             if not args.no_self_check or args.cpu_pairs > 0:
                 O = entry.load_oracle()
                 O.build()
-            leg_steps, leg_warm = max(2, min(steps, 6)), 1
+            # as many timed steps as the main measurement (at most 20) after two warm-up steps: six steps after one (rounds 3-5) still
+            # carried the pipeline's ramp -- the ORB leg read 3 % below the same workload run as its own process
+            leg_steps, leg_warm = max(2, min(steps, 20)), 2
 
             def finish(name, lctx, el, st_ms, recs, f0, n_steps, Bl, extra, check_kw, frames=(L, R, W), proj=(P1, P2)):
                 """The leg's entry of the JSON line; its last step is checked against the oracle before the context goes."""
